@@ -1,0 +1,200 @@
+"""Rows P1, P2, P2b, P3, P3b: project points/mesh into the V views.  (oracle -- test infrastructure)
+
+P1  follows /root/reference/pointdreamer/ours_utils.py:93-130 (transform + crop/rescale).
+P2  replaces the nvdiffrast call at ours_utils.py:142-147.  nvdiffrast is un-vendored and
+    unpinned (PARITY UNPINNED): this restates its documented contract (pixel-centre sampling,
+    row 0 = y_ndc -1, nearest z/w wins, output (z/w, tri+1)) with the build's own exact rules:
+      * vertices are snapped to 1/256-pixel fixed point; coverage is decided by int64 edge
+        functions at pixel centres with a top-left style tie rule (watertight, no double hits);
+      * depth = (E0*z0 + E1*z1 + E2*z2)/area in float64 (this order, no FMA), rounded to f32;
+      * fragments outside -1 <= z <= 1 are dropped; nearest z wins, ties -> smaller face id.
+P2b follows demo.py:103-104 (torchvision Resize bilinear, no antialias, then .bool()).
+P3  follows ours_utils.py:153-202.
+P3b follows ours_utils.py:204-225 (open3d hidden_point_removal == Katz spherical flip + qhull).
+"""
+import numpy as np
+
+F32 = np.float32
+SUBPIX = 256
+FIX_CLAMP = 1 << 24
+
+
+# ----------------------------------------------------------------------------- P1
+def project_batch(cams, vertices, points, rescale=True, padding=0.05):
+    """ours_utils.py:93-141 without the raster.  Returns dict with pos[V,Vn,4], vertice_uvs,
+    uv_centers[V,1,2], uv_scales[V,1,1], padding, point_uvs[V,N,2], point_depths[V,N]."""
+    vertices = np.asarray(vertices, F32)
+    points = np.asarray(points, F32)
+    V = len(cams)
+    pos = np.zeros((V, vertices.shape[0], 4), F32)
+    tp = np.zeros((V, points.shape[0], 3), F32)
+    for i, cam in enumerate(cams):
+        pos[i, :, :3] = cam.transform(vertices)
+        pos[i, :, 3] = 1.0
+        tp[i] = cam.transform(points)
+    if rescale:
+        vuv = pos[:, :, :2]
+        mn = vuv.min(1)[:, None, :]
+        mx = vuv.max(1)[:, None, :]
+        uv_centers = ((mn + mx) / F32(2)).astype(F32)
+        uv_scales = (mx - mn).max(2)[:, :, None].astype(F32)
+        pad9 = F32(1 - 2 * padding)
+        vuv = (vuv - uv_centers) / uv_scales
+        vuv = vuv * pad9
+        vuv = vuv + F32(0.5)
+        vuv = np.clip(vuv, F32(0), F32(1))
+        pos[:, :, :2] = vuv * F32(2) - F32(1)
+        puv = (tp[..., :2] - uv_centers) / uv_scales
+        puv = puv * pad9
+        puv = puv + F32(0.5)
+        pdep = tp[:, :, 2]
+    else:
+        vuv = np.clip((pos[:, :, :2] + F32(1)) * F32(0.5), F32(0), F32(1))
+        puv = (tp[..., :2] + F32(1)) * F32(0.5)
+        uv_centers, uv_scales, padding = 0, 2, 0
+        pdep = tp[:, :, 2]
+    return dict(pos=pos, vertice_uvs=vuv.astype(F32), uv_centers=uv_centers, uv_scales=uv_scales,
+                padding=padding, point_uvs=puv.astype(F32), point_depths=pdep.astype(F32))
+
+
+# ----------------------------------------------------------------------------- P2
+def snap(ndc, res):
+    """NDC coordinate (f32) -> 1/256-pixel fixed point (int64)."""
+    v = (ndc.astype(F32) * F32(0.5) + F32(0.5)) * F32(res * SUBPIX)
+    v = np.where(np.isfinite(v), v, F32(0))
+    v = np.clip(np.rint(v), -FIX_CLAMP, FIX_CLAMP)
+    return v.astype(np.int64)
+
+
+def rasterize(pos, faces, res):
+    """pos[V,Vn,4] f32 NDC (w ignored, the reference passes w=1), faces[F,3] int.
+    Returns hard_masks[V,R,R] bool, face_idxs[V,R,R] int64 (-1 empty), depths[V,R,R] f32 (0 empty)."""
+    pos = np.asarray(pos, F32)
+    faces = np.asarray(faces, np.int64)
+    V = pos.shape[0]
+    R = int(res)
+    zbuf = np.full((V, R, R), np.inf, np.float64)
+    fid = np.full((V, R, R), -1, np.int64)
+    for v in range(V):
+        X = snap(pos[v, :, 0], R)
+        Y = snap(pos[v, :, 1], R)
+        Z = pos[v, :, 2].astype(np.float64)
+        for f in range(faces.shape[0]):
+            i0, i1, i2 = faces[f]
+            x0, y0, x1, y1, x2, y2 = X[i0], Y[i0], X[i1], Y[i1], X[i2], Y[i2]
+            area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
+            if area == 0:
+                continue
+            z0, z1, z2 = Z[i0], Z[i1], Z[i2]
+            if area < 0:                                  # normalise orientation: swap v1, v2
+                x1, y1, x2, y2 = x2, y2, x1, y1
+                z1, z2 = z2, z1
+                area = -area
+            jmin = max(0, -((-(min(x0, x1, x2) - 128)) // SUBPIX))
+            jmax = min(R - 1, (max(x0, x1, x2) - 128) // SUBPIX)
+            imin = max(0, -((-(min(y0, y1, y2) - 128)) // SUBPIX))
+            imax = min(R - 1, (max(y0, y1, y2) - 128) // SUBPIX)
+            if jmin > jmax or imin > imax:
+                continue
+            px = (np.arange(jmin, jmax + 1, dtype=np.int64) * SUBPIX + 128)[None, :]
+            py = (np.arange(imin, imax + 1, dtype=np.int64) * SUBPIX + 128)[:, None]
+
+            def edge(ax, ay, bx, by):
+                dx, dy = bx - ax, by - ay
+                E = dx * (py - ay) - dy * (px - ax)
+                incl = (dy > 0) or (dy == 0 and dx > 0)
+                return E, (E > 0) | ((E == 0) & incl)
+            E0, in0 = edge(x1, y1, x2, y2)               # weight of v0
+            E1, in1 = edge(x2, y2, x0, y0)               # weight of v1
+            E2, in2 = edge(x0, y0, x1, y1)               # weight of v2
+            inside = in0 & in1 & in2
+            if not inside.any():
+                continue
+            zd = (E0.astype(np.float64) * z0 + E1.astype(np.float64) * z1) + E2.astype(np.float64) * z2
+            z = (zd / np.float64(area)).astype(F32)
+            ok = inside & (z >= F32(-1)) & (z <= F32(1))
+            sub_z = zbuf[v, imin:imax + 1, jmin:jmax + 1]
+            sub_f = fid[v, imin:imax + 1, jmin:jmax + 1]
+            upd = ok & (z.astype(np.float64) < sub_z)    # strict: ties keep the smaller face id
+            sub_z[upd] = z[upd]
+            sub_f[upd] = f
+    hard = fid >= 0
+    depth = np.where(hard, zbuf, 0.0).astype(F32)
+    return hard, fid, depth
+
+
+# ----------------------------------------------------------------------------- P2b
+def resize_mask_bilinear_nonzero(mask, out_h, out_w):
+    """torchvision 0.15/0.16 transforms.Resize on a bool/float mask tensor followed by .bool():
+    bilinear, align_corners=False, antialias off => output is True iff any source pixel with a
+    non-zero bilinear weight is True.  (demo.py:103-104, ours_utils.py:989-995.)
+    Source index arithmetic is torch's area_pixel_compute_source_index in float32."""
+    mask = np.asarray(mask).astype(bool)
+    in_h, in_w = mask.shape[-2:]
+
+    def taps(n_in, n_out):
+        scale = F32(n_in) / F32(n_out)
+        d = np.arange(n_out, dtype=F32)
+        src = scale * (d + F32(0.5)) - F32(0.5)
+        src = np.where(src < 0, F32(0), src).astype(F32)
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(F32)).astype(F32)
+        l0 = (F32(1) - l1).astype(F32)
+        return i0, i1, l0 > 0, l1 > 0
+    r0, r1, wr0, wr1 = taps(in_h, out_h)
+    c0, c1, wc0, wc1 = taps(in_w, out_w)
+    m = mask
+    out = (m[..., r0[:, None], c0[None, :]] & (wr0[:, None] & wc0[None, :])) | \
+          (m[..., r0[:, None], c1[None, :]] & (wr0[:, None] & wc1[None, :])) | \
+          (m[..., r1[:, None], c0[None, :]] & (wr1[:, None] & wc0[None, :])) | \
+          (m[..., r1[:, None], c1[None, :]] & (wr1[:, None] & wc1[None, :]))
+    return out
+
+
+def downsample_masks(hard_masks, res):
+    return resize_mask_bilinear_nonzero(hard_masks, res, res)
+
+
+# ----------------------------------------------------------------------------- P3
+def point_validation_by_depth(cam_res, point_uvs, point_depths, mesh_depths, offset=0.0):
+    """ours_utils.py:153-202.  Returns visibility[V,N] bool, point_pixels[V,N,2] int64 (row,col)."""
+    point_uvs = np.asarray(point_uvs, F32)
+    pp = point_uvs * F32(cam_res)
+    pp = np.clip(pp, F32(0), F32(cam_res - 1))
+    with np.errstate(invalid='ignore'):
+        pp = pp.astype(np.int64)
+    rows, cols = pp[:, :, 1], pp[:, :, 0]
+    V = point_uvs.shape[0]
+    ref = np.asarray(mesh_depths, F32)[np.arange(V)[:, None], rows, cols]
+    vis = (np.asarray(point_depths, F32) - ref) <= F32(offset)
+    return vis, np.stack([rows, cols], -1)
+
+
+def point_pixels_for_res(point_uvs, res):
+    """demo.py:121-125: long(uv*res), swap to (row,col), clip."""
+    pp = (np.asarray(point_uvs, F32) * F32(res))
+    with np.errstate(invalid='ignore'):
+        pp = pp.astype(np.int64)
+    pp = np.stack([pp[:, :, 1], pp[:, :, 0]], -1)
+    return np.clip(pp, 0, res - 1)
+
+
+# ----------------------------------------------------------------------------- P3b
+def point_validation_by_hpr(points, eye_positions, radius):
+    """ours_utils.py:204-225 -> open3d PointCloud.hidden_point_removal(eye, radius):
+    Katz et al. spherical flip  p' = q + 2(radius-|q|) q/|q|, q = p-eye (float64), then the
+    visible set = vertices of the convex hull of {p'} U {0} (qhull).  PARITY UNPINNED (open3d
+    absent); scipy.spatial.ConvexHull drives the same qhull library."""
+    from scipy.spatial import ConvexHull
+    points = np.asarray(points, np.float64)
+    out = np.zeros((len(eye_positions), points.shape[0]), bool)
+    for i, eye in enumerate(eye_positions):
+        q = points - np.asarray(eye, np.float64)[None]
+        n = np.linalg.norm(q, axis=1, keepdims=True)
+        n = np.maximum(n, 1e-300)
+        flipped = q + 2 * (radius - n) * q / n
+        hull = ConvexHull(np.concatenate([flipped, np.zeros((1, 3))], 0))
+        vid = hull.vertices
+        out[i, vid[vid < points.shape[0]]] = True
+    return out
