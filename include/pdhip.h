@@ -1,0 +1,132 @@
+/* pdhip.h -- C ABI of libpdhip.so: the MI355X (gfx950) implementation of PointDreamer's
+ * project -> inpaint -> unproject texturing path.
+ *
+ * The reference (YuQiao0303/PointDreamer) exposes no FFI for this path; the boundary is the set of
+ * Python call signatures demo.colorize_one_mesh uses (demo.py:93-95, 107-110, 127-129, 150-151,
+ * 172-177, 203).  Each entry point below names the reference function (file:line) it replaces.
+ * The Python shims in pointdreamer_amd/ keep the reference's names and tensor contracts and route
+ * every call here through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a BORROWED device pointer (HBM) owned by the caller, contiguous, row-major;
+ *     "bool" tensors are uint8 (torch.bool layout); index tensors are int64 unless stated;
+ *   - every call enqueues asynchronously on `stream` (a hipStream_t; NULL = default stream) and never
+ *     synchronises, except the few calls documented as returning a host value;
+ *   - return value: 0 = OK, negative = error (PDHIP_E_*); pdhip_last_error() gives a thread-local
+ *     message.  Nothing throws across the ABI;
+ *   - the library holds no global mutable state; scratch memory is passed in by the caller
+ *     (workspace pointers) or lives in an opaque handle created by *_create and freed by *_destroy.
+ *   - camera parameters: 16 float32 per view = R(9, row-major world->camera) t(3) fx fy A B,
+ *     NDC = (fx*xc/-zc, fy*yc/-zc, (A*zc+B)/-zc); see DESIGN.md "Arithmetic contract".
+ */
+#ifndef PDHIP_H
+#define PDHIP_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDHIP_OK 0
+#define PDHIP_E_ARG (-1)      /* invalid argument */
+#define PDHIP_E_HIP (-2)      /* HIP runtime error (message has the hipError string) */
+#define PDHIP_E_STATE (-3)    /* handle in wrong state (e.g. weights missing) */
+#define PDHIP_E_NOMEM (-4)
+
+int pdhip_version(void);
+const char* pdhip_last_error(void);
+
+/* ---- P1: ours_utils.get_rendered_hard_mask_and_face_idx_batch, transform + crop part
+ *      (pointdreamer/ours_utils.py:93-141).  minmax_ws: 4*V uint32 scratch.
+ *      uv_centers[V,2], uv_scales[V] are written only when rescale != 0. */
+int pdhip_project_points(const float* cam_params, int V, const float* vertices, int Vn,
+                         const float* points, int N, int rescale, double padding,
+                         float* pos /*[V,Vn,4]*/, float* vertice_uvs /*[V,Vn,2]*/,
+                         float* uv_centers, float* uv_scales,
+                         float* point_uvs /*[V,N,2]*/, float* point_depths /*[V,N]*/,
+                         uint32_t* minmax_ws, void* stream);
+
+/* ---- P2: the nvdiffrast.rasterize call at ours_utils.py:142-147 (also extract_texture_map.py:57).
+ *      zkey_ws: V*R*R uint64 scratch.  Outputs hard_masks[V,R,R] u8, face_idxs[V,R,R] i64 (-1 empty),
+ *      depths[V,R,R] f32 (0 empty). */
+int pdhip_raster_mesh(const float* pos /*[V,Vn,4]*/, int V, int Vn, const int32_t* faces /*[F,3]*/, int F,
+                      int R, uint64_t* zkey_ws, uint8_t* hard_masks, int64_t* face_idxs, float* depths,
+                      void* stream);
+
+/* ---- P2b: torchvision Resize(bilinear, no antialias) + .bool() on masks (demo.py:103-104,
+ *      ours_utils.py:989-995): out is 1 iff any source pixel with non-zero bilinear weight is set. */
+int pdhip_resize_mask(const uint8_t* in /*[B,in_h,in_w]*/, int B, int in_h, int in_w,
+                      uint8_t* out /*[B,out_h,out_w]*/, int out_h, int out_w, void* stream);
+
+/* ---- P3: ours_utils.get_point_validation_by_depth (ours_utils.py:153-202).
+ *      point_pixels (row,col) may be NULL. */
+int pdhip_point_visibility(int cam_res, const float* point_uvs /*[V,N,2]*/, const float* point_depths /*[V,N]*/,
+                           const float* mesh_depths /*[V,R,R]*/, int V, int N, float offset,
+                           uint8_t* visibility /*[V,N]*/, int64_t* point_pixels /*[V,N,2]*/, void* stream);
+
+/* ---- demo.py:121-125: point_pixels = clip(long(uv*res)) as (row,col). */
+int pdhip_point_pixels(const float* point_uvs /*[V,N,2]*/, int V, int N, int res,
+                       int64_t* point_pixels /*[V,N,2]*/, void* stream);
+
+/* ---- P4-P6: ours_utils.get_sparse_images -> get_one_sparse_img -> paint_pixels /
+ *      get_forground_inner_edge_mask (ours_utils.py:848-882, 954-1044, 456-532), all V views.
+ *      ws: pdhip_sparse_views_ws_bytes(V,N,res) bytes.  Outputs are already flipped vertically and
+ *      sparse is multiplied by mask0 (ours_utils.py:866).  Duplicate splats: largest write index wins. */
+size_t pdhip_sparse_views_ws_bytes(int V, int N, int res);
+int pdhip_sparse_views(const int64_t* point_pixels /*[V,N,2]*/, const float* colors /*[N,3]*/,
+                       const uint8_t* validation /*[V,N]*/, const uint8_t* hard_masks /*[V,res,res]*/,
+                       int V, int N, int res, int point_size, int edge_point_size, double mask_ratio_thresh,
+                       float* sparse /*[V,3,res,res]*/, float* mask0, float* mask2,
+                       float* scale_factors /*[V]*/, float* mask_ratios /*[V] or NULL*/,
+                       void* ws, void* stream);
+
+/* ---- I0 / Uq5: ours_utils.naive_inpainting(method='nearest') (ours_utils.py:610-643) and
+ *      unproject.dilate_atlas (unproject.py:480-504): every pixel takes the value of its
+ *      Euclidean-nearest site; ties -> lexicographically smallest (row,col).
+ *      img/out: B images; element (b,c,y,x) at b*batch_stride + c*chan_stride + (y*W+x)*pix_stride.
+ *      mask: per image H*W; mask_is_f32 != 0 -> float (site iff != 0), else uint8.
+ *      mask_batch_stride in elements.  ws: B*H*W int32. */
+int pdhip_nearest_fill(const float* img, float* out, int B, int C, int H, int W,
+                       int64_t batch_stride, int64_t chan_stride, int64_t pix_stride,
+                       const void* mask, int mask_is_f32, int64_t mask_batch_stride,
+                       int32_t* ws, void* stream);
+
+/* ---- Uq1+Uq2: unproject.unproject texel transform + depth visibility (unproject.py:219-284).
+ *      visibility[V,A,A] u8 (0 outside the chart mask). */
+int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos /*[A,A,3]*/,
+                           const uint8_t* mask /*[A,A]*/, int A, const float* uv_centers /*[V,2]*/,
+                           const float* uv_scales /*[V]*/, double padding,
+                           const float* mesh_depths /*[V,R,R]*/, int R, float offset,
+                           uint8_t* visibility, void* stream);
+
+/* ---- N1-N3: unproject.get_shrinked_per_view_per_pixel_visibility_torch (unproject.py:429-475),
+ *      utils_2d.detect_edges_in_gray_by_scharr_torch_batch (:799-827), dilate_torch_batch (:833-845).
+ *      kernels: K host ints (odd, or kernels[0]==0 -> NBF off: out = visibility).
+ *      out[K,V,A,A] u8.  ws: 2*V*A*A bytes. */
+int pdhip_nbf_shrink(const uint8_t* mask /*[A,A]*/, const uint8_t* visibility /*[V,A,A]*/, int V, int A,
+                     const int32_t* kernels, int K, uint8_t* out, uint8_t* ws, void* stream);
+
+/* ---- Uq3+Uq4: view selection + colour gather (unproject.py:298-400).
+ *      shrinked[K,V,A,A] (K = number of NBF levels actually consulted), visibility[V,A,A] raw.
+ *      view_ids[A,A] int32: chosen view, -100 unseen, -1 outside the chart mask.
+ *      atlas[A,A,3] f32, painted[A,A] u8. */
+int pdhip_view_select_blend(const float* cam_params, int V, const float* gb_pos, const uint8_t* mask,
+                            const int64_t* face_id /*[A,A]*/, int A, const float* f_normals /*[F,3]*/,
+                            const float* base_dirs /*[V,3]*/, const float* uv_centers, const float* uv_scales,
+                            double padding, const float* scale_factors /*[V]*/,
+                            const uint8_t* shrinked, int K, const uint8_t* visibility,
+                            int complete_unseen_by_projection,
+                            const float* inpainted /*[V,3,r,r]*/, int r,
+                            float* atlas, uint8_t* painted, int32_t* view_ids, void* stream);
+
+/* ---- texel compaction in row-major order (unproject.py:223-233): points[P,3], coords[P,2] i64,
+ *      optional gather of view_ids[A,A] -> point_view_ids[P] i64.  Writes P to *count_dev (int32).
+ *      ws: (A+1) int32. */
+int pdhip_compact_texels(const float* gb_pos, const uint8_t* mask, int A, const int32_t* view_ids,
+                         float* points, int64_t* coords, int64_t* point_view_ids, int32_t* count_dev,
+                         int32_t* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

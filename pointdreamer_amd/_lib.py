@@ -1,0 +1,87 @@
+"""ctypes binding of libpdhip.so (include/pdhip.h).  No fallback: if the HIP library is missing or a
+call fails, this raises -- the product never computes on the CPU or through the oracle."""
+import ctypes as C
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpdhip.so')
+
+
+class PdhipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
+
+_SIGS = {
+    'pdhip_version': (C.c_int, []),
+    'pdhip_last_error': (C.c_char_p, []),
+    'pdhip_project_points': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_raster_mesh': (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
+    'pdhip_resize_mask': (C.c_int, [vp, i32, i32, i32, vp, i32, i32, vp]),
+    'pdhip_point_visibility': (C.c_int, [i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
+    'pdhip_point_pixels': (C.c_int, [vp, i32, i32, i32, vp, vp]),
+    'pdhip_sparse_views_ws_bytes': (sz, [i32, i32, i32]),
+    'pdhip_sparse_views': (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_nearest_fill': (C.c_int, [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp, i32, i64, vp, vp]),
+    'pdhip_texel_visibility': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, f64, vp, i32, f32, vp, vp]),
+    'pdhip_nbf_shrink': (C.c_int, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
+    'pdhip_view_select_blend': (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp, i32, vp, i32,
+                                          vp, vp, vp, vp]),
+    'pdhip_compact_texels': (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+}
+
+
+def register(name, restype, argtypes):
+    """Used by the nn binding module to add its entry points to the same table."""
+    _SIGS[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PdhipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(make -C pointdreamer_amd/csrc).  There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(_lib, name)          # AttributeError here == ABI mismatch, fail loudly
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pdhip_last_error()
+        raise PdhipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None, allow_none=False):
+    """Device pointer of a contiguous CUDA(HIP) tensor, with dtype check."""
+    if t is None:
+        if allow_none:
+            return C.c_void_p(0)
+        raise PdhipError("null tensor")
+    if not t.is_cuda:
+        raise PdhipError("pointdreamer_amd needs tensors on the GPU (cuda:N == HIP device); got a CPU tensor. "
+                         "There is no CPU path.")
+    if not t.is_contiguous():
+        raise PdhipError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise PdhipError(f"expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def as_u8(t):
+    """torch.bool <-> uint8 views share storage (bool is one byte, values 0/1)."""
+    return t.view(torch.uint8) if t.dtype == torch.bool else t

@@ -1,0 +1,16 @@
+// libpdhip: version + thread-local error message (never throws across the C ABI).
+#include "common.h"
+#include <string.h>
+
+namespace pdhip {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace pdhip
+
+extern "C" int pdhip_version(void) { return 100; }
+extern "C" const char* pdhip_last_error(void) { return pdhip::g_err; }

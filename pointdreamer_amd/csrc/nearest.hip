@@ -1,0 +1,93 @@
+// Rows I0 and Uq5: exact nearest-site fill (replaces scipy.interpolate.griddata(method='nearest') at
+// pointdreamer/ours_utils.py:610-643 and unproject.dilate_atlas, unproject.py:480-504).
+// Separable exact Euclidean search: (1) per column, nearest site row for every row (ties -> smaller row);
+// (2) per pixel, scan columns outward from its own, key = (dist2, row', col'), stop once dx*dx > best dist2.
+// Tie rule: lexicographically smallest (row', col') among all sites at minimal distance (oracle/inpaint.py).
+// Integer work; HBM-bound (mask read + near_row write/read + colour gather).
+#include "common.h"
+using namespace pdhip;
+
+template <bool F32MASK>
+__global__ void k_nearest_cols(const void* __restrict__ mask, int64_t mask_bstride, int H, int W,
+                               int32_t* __restrict__ near_row) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    int32_t* nr = near_row + (size_t)b * H * W;
+    auto site = [&](int r) -> bool {
+        if (F32MASK) return reinterpret_cast<const float*>(mask)[(size_t)b * mask_bstride + (size_t)r * W + c] != 0.0f;
+        return reinterpret_cast<const uint8_t*>(mask)[(size_t)b * mask_bstride + (size_t)r * W + c] != 0;
+    };
+    int last = -1;
+    for (int r = 0; r < H; ++r) {              // nearest site at or above
+        if (site(r)) last = r;
+        nr[(size_t)r * W + c] = last;
+    }
+    int next = -1;
+    for (int r = H - 1; r >= 0; --r) {         // merge with nearest site at or below; ties -> up (smaller row)
+        if (site(r)) next = r;
+        int up = nr[(size_t)r * W + c];
+        int pick = up;
+        if (next >= 0 && (up < 0 || (next - r) < (r - up))) pick = next;
+        nr[(size_t)r * W + c] = pick;
+    }
+}
+
+__global__ void k_nearest_rows(const int32_t* __restrict__ near_row, int H, int W, const float* __restrict__ img,
+                               float* __restrict__ out, int C, int64_t bstride, int64_t cstride, int64_t pstride) {
+    extern __shared__ int32_t s_nr[];          // near_row of this image row
+    const int b = blockIdx.y, r = blockIdx.x;
+    const int32_t* nr = near_row + ((size_t)b * H + r) * W;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) s_nr[c] = nr[c];
+    __syncthreads();
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        unsigned long long best = ~0ull;
+        long long best_d2 = 0x7fffffffffffLL;
+        for (int dx = 0; dx < W; ++dx) {
+            long long dx2 = (long long)dx * dx;
+            if (dx2 > best_d2) break;
+            int c1 = c - dx, c2 = c + dx;
+            if (c1 < 0 && c2 >= W) break;
+            if (c1 >= 0) {
+                int rr = s_nr[c1];
+                if (rr >= 0) {
+                    long long dy = r - rr, d2 = dx2 + dy * dy;
+                    unsigned long long key = ((unsigned long long)d2 << 32) | ((unsigned long long)rr << 16) | (unsigned)c1;
+                    if (key < best) { best = key; best_d2 = d2; }
+                }
+            }
+            if (dx > 0 && c2 < W) {
+                int rr = s_nr[c2];
+                if (rr >= 0) {
+                    long long dy = r - rr, d2 = dx2 + dy * dy;
+                    unsigned long long key = ((unsigned long long)d2 << 32) | ((unsigned long long)rr << 16) | (unsigned)c2;
+                    if (key < best) { best = key; best_d2 = d2; }
+                }
+            }
+        }
+        const size_t dst = (size_t)b * bstride + ((size_t)r * W + c) * pstride;
+        if (best == ~0ull) {                    // no site anywhere: keep the input
+            for (int ch = 0; ch < C; ++ch) out[dst + ch * cstride] = img[dst + ch * cstride];
+            continue;
+        }
+        int sr = (int)((best >> 16) & 0xffff), sc = (int)(best & 0xffff);
+        const size_t src = (size_t)b * bstride + ((size_t)sr * W + sc) * pstride;
+        for (int ch = 0; ch < C; ++ch) out[dst + ch * cstride] = img[src + ch * cstride];
+    }
+}
+
+extern "C" int pdhip_nearest_fill(const float* img, float* out, int B, int C, int H, int W, int64_t batch_stride,
+                                  int64_t chan_stride, int64_t pix_stride, const void* mask, int mask_is_f32,
+                                  int64_t mask_batch_stride, int32_t* ws, void* stream) {
+    PD_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H <= 65535 && W <= 65535, "pdhip_nearest_fill: bad sizes");
+    PD_REQUIRE(img && out && mask && ws, "pdhip_nearest_fill: null pointer");
+    PD_REQUIRE(img != out, "pdhip_nearest_fill: in-place operation is not supported");
+    hipStream_t s = as_stream(stream);
+    dim3 g1(cdiv(W, 64), B);
+    if (mask_is_f32) k_nearest_cols<true><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, ws);
+    else k_nearest_cols<false><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, ws);
+    dim3 g2(H, B);
+    k_nearest_rows<<<g2, 256, W * sizeof(int32_t), s>>>(ws, H, W, img, out, C, batch_stride, chan_stride, pix_stride);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}

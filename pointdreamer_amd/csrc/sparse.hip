@@ -1,0 +1,292 @@
+// Rows P4, P5, P6: sparse per-view images and masks for all V views, no host round trip.
+// Reference: pointdreamer/ours_utils.py:848-882 (get_sparse_images), :954-1044 (get_one_sparse_img),
+// :456-495 (paint_pixels), :497-532 (get_forground_inner_edge_mask 'dilate').
+// Build rules (oracle/sparse.py): duplicate writes -> largest write-order index wins (atomicMax on the
+// write index, resolved in a compose pass); edge pixel -> nearest valid point by exact integer distance,
+// ties -> smallest point index; degenerate view (no valid point / no foreground) -> all background.
+// Compiled with -ffp-contract=off.
+#include "common.h"
+using namespace pdhip;
+
+struct ViewParams {
+    float scale;
+    int after_res;
+    int pad;
+    int degenerate;
+};
+
+struct SparseWs {
+    ViewParams* params;   // [V]
+    uint32_t* counts;     // [V][2]
+    uint8_t* mask_new;    // [V][r*r]
+    uint32_t* winA;       // [V][r*r]
+    uint32_t* winB;       // [V][r*r]
+    int32_t* nn_idx;      // [V][r*r]
+    int32_t* pp;          // [V][N] packed (row<<16|col) or -1
+};
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static SparseWs carve(void* ws, int V, int N, int res, size_t* total) {
+    size_t off = 0;
+    char* base = (char*)ws;
+    size_t px = (size_t)V * res * res;
+    SparseWs w;
+    w.params = (ViewParams*)(base + off); off += align256(sizeof(ViewParams) * V);
+    w.counts = (uint32_t*)(base + off); off += align256(8 * (size_t)V);
+    w.mask_new = (uint8_t*)(base + off); off += align256(px);
+    w.winA = (uint32_t*)(base + off); off += align256(4 * px);
+    w.winB = (uint32_t*)(base + off); off += align256(4 * px);
+    w.nn_idx = (int32_t*)(base + off); off += align256(4 * px);
+    w.pp = (int32_t*)(base + off); off += align256(4 * (size_t)V * (N > 0 ? N : 1));
+    if (total) *total = off;
+    return w;
+}
+
+extern "C" size_t pdhip_sparse_views_ws_bytes(int V, int N, int res) {
+    size_t t = 0;
+    carve(nullptr, V, N, res, &t);
+    return t;
+}
+
+__global__ void k_sparse_counts(const uint8_t* __restrict__ hard, const uint8_t* __restrict__ valid, int N, int res,
+                                float thresh_f, float one_minus_thresh_f, ViewParams* __restrict__ params,
+                                uint32_t* __restrict__ counts) {
+    const int v = blockIdx.x;
+    __shared__ uint32_t s_fg[4], s_va[4];
+    uint32_t fg = 0, va = 0;
+    for (int i = threadIdx.x; i < res * res; i += blockDim.x) fg += hard[(size_t)v * res * res + i] ? 1 : 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) va += valid[(size_t)v * N + i] ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { fg += __shfl_xor(fg, off); va += __shfl_xor(va, off); }
+    if ((threadIdx.x & 63) == 0) { s_fg[threadIdx.x >> 6] = fg; s_va[threadIdx.x >> 6] = va; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        fg = s_fg[0] + s_fg[1] + s_fg[2] + s_fg[3];
+        va = s_va[0] + s_va[1] + s_va[2] + s_va[3];
+        counts[2 * v] = fg; counts[2 * v + 1] = va;
+        ViewParams p;
+        p.scale = 1.0f; p.after_res = res; p.pad = 0;
+        p.degenerate = (fg == 0 || va == 0) ? 1 : 0;
+        if (!p.degenerate) {
+            float fgf = (float)fg, vaf = (float)va;
+            float ratio = 1.0f - vaf / fgf;
+            if (ratio > thresh_f) {
+                float wanted = vaf / one_minus_thresh_f;
+                p.scale = wanted / fgf;
+                int ar = (int)floorf((float)res * p.scale);
+                if (((res - ar) % 2) == 1) ar += 1;
+                p.after_res = ar;
+                p.pad = (res - ar) / 2;
+            }
+        }
+        params[v] = p;
+    }
+}
+
+__device__ __forceinline__ void bilinear_taps_s(int n_in, int n_out, int d, int& i0, int& i1, bool& w0, bool& w1) {
+    float scale = (float)n_in / (float)n_out;
+    float src = scale * ((float)d + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = min((int)src, n_in - 1);
+    i1 = min(i0 + 1, n_in - 1);
+    float l1 = src - (float)i0;
+    float l0 = 1.0f - l1;
+    w0 = l0 > 0.f;
+    w1 = l1 > 0.f;
+}
+
+// new foreground mask (Resize+Pad when the view is rescaled) and winner-buffer init
+__global__ void k_sparse_mask(const uint8_t* __restrict__ hard, int res, const ViewParams* __restrict__ params,
+                              uint8_t* __restrict__ mask_new, uint32_t* __restrict__ winA, uint32_t* __restrict__ winB) {
+    const int v = blockIdx.y;
+    const ViewParams p = params[v];
+    const uint8_t* src = hard + (size_t)v * res * res;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < res * res; idx += gridDim.x * blockDim.x) {
+        uint8_t m;
+        if (p.after_res == res) {
+            m = src[idx] ? 1 : 0;
+        } else {
+            int y = idx / res - p.pad, x = idx % res - p.pad;
+            m = 0;
+            if (y >= 0 && y < p.after_res && x >= 0 && x < p.after_res) {
+                int r0, r1, c0, c1;
+                bool wr0, wr1, wc0, wc1;
+                bilinear_taps_s(res, p.after_res, y, r0, r1, wr0, wr1);
+                bilinear_taps_s(res, p.after_res, x, c0, c1, wc0, wc1);
+                m = ((wr0 && wc0 && src[r0 * res + c0]) || (wr0 && wc1 && src[r0 * res + c1]) ||
+                     (wr1 && wc0 && src[r1 * res + c0]) || (wr1 && wc1 && src[r1 * res + c1])) ? 1 : 0;
+            }
+        }
+        size_t o = (size_t)v * res * res + idx;
+        mask_new[o] = m;
+        winA[o] = 0;
+        winB[o] = 0;
+    }
+}
+
+// P5: splat valid points (write index -> atomicMax), remember the (rescaled) pixel of every point
+__global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* __restrict__ valid, int N, int res,
+                               int point_size, const ViewParams* __restrict__ params, uint32_t* __restrict__ winA,
+                               int32_t* __restrict__ pp) {
+    const int v = blockIdx.y;
+    const ViewParams p = params[v];
+    const int g = 2 * point_size - 1;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        size_t o = (size_t)v * N + n;
+        int packed = -1;
+        if (valid[o] && !p.degenerate) {
+            int row = (int)pix[2 * o], col = (int)pix[2 * o + 1];
+            if (p.after_res != res) {
+                float ur = (float)row / (float)res, uc = (float)col / (float)res;
+                ur = ur * 2.0f - 1.0f; uc = uc * 2.0f - 1.0f;
+                ur = ur * p.scale; uc = uc * p.scale;
+                ur = (ur + 1.0f) * 0.5f; uc = (uc + 1.0f) * 0.5f;
+                row = clip_to_int(ur * (float)res, res - 1);
+                col = clip_to_int(uc * (float)res, res - 1);
+            }
+            packed = (row << 16) | col;
+            for (int a = 0; a < g; ++a) {
+                int rr = row + a - (point_size - 1);
+                if (rr < 0 || rr >= res) continue;
+                for (int b = 0; b < g; ++b) {
+                    int cc = col + b - (point_size - 1);
+                    if (cc < 0 || cc >= res) continue;
+                    atomicMax(&winA[(size_t)v * res * res + rr * res + cc], (uint32_t)(n * g * g + a * g + b + 1));
+                }
+            }
+        }
+        pp[o] = packed;
+    }
+}
+
+// P6 + edge colouring: one block per (view,row); for each inner-edge pixel all threads scan the points
+__global__ void k_sparse_edges(const uint8_t* __restrict__ mask_new, int N, int res, int edge_point_size,
+                               const ViewParams* __restrict__ params, const int32_t* __restrict__ pp,
+                               uint32_t* __restrict__ winB, int32_t* __restrict__ nn_idx) {
+    const int v = blockIdx.y, row = blockIdx.x;
+    const ViewParams p = params[v];
+    if (p.degenerate) return;
+    extern __shared__ int s_edge[];            // [res] edge columns, then reduction scratch
+    __shared__ int s_n;
+    __shared__ unsigned long long s_red[4];
+    const uint8_t* m = mask_new + (size_t)v * res * res;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int col = threadIdx.x; col < res; col += blockDim.x) {
+        bool fg = m[row * res + col];
+        bool bgn = false;
+        if (fg) {
+            for (int dy = -1; dy <= 1; ++dy) {
+                int y = row + dy;
+                if (y < 0 || y >= res) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int x = col + dx;
+                    if (x < 0 || x >= res) continue;
+                    bgn |= !m[y * res + x];
+                }
+            }
+        }
+        if (fg && bgn) s_edge[atomicAdd(&s_n, 1)] = col;
+    }
+    __syncthreads();
+    const int ne = s_n;
+    const int ge = 2 * edge_point_size - 1;
+    const int32_t* ppv = pp + (size_t)v * N;
+    for (int e = 0; e < ne; ++e) {
+        const int col = s_edge[e];
+        unsigned long long best = ~0ull;
+        for (int n = threadIdx.x; n < N; n += blockDim.x) {
+            int q = ppv[n];
+            if (q < 0) continue;
+            int dr = row - (q >> 16), dc = col - (q & 0xffff);
+            unsigned long long key = ((unsigned long long)(unsigned)(dr * dr + dc * dc) << 32) | (unsigned)n;
+            best = key < best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = __shfl_xor(best, off);
+            best = o < best ? o : best;
+        }
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < (int)(blockDim.x >> 6); ++k) best = s_red[k] < best ? s_red[k] : best;
+            const int lin = row * res + col;
+            nn_idx[(size_t)v * res * res + lin] = (int)(best & 0xffffffffu);
+            for (int a = 0; a < ge; ++a) {
+                int rr = row + a - (edge_point_size - 1);
+                if (rr < 0 || rr >= res) continue;
+                for (int b = 0; b < ge; ++b) {
+                    int cc = col + b - (edge_point_size - 1);
+                    if (cc < 0 || cc >= res) continue;
+                    atomicMax(&winB[(size_t)v * res * res + rr * res + cc], (uint32_t)(lin * ge * ge + a * ge + b + 1));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// compose + vertical flip + sparse*mask0
+__global__ void k_sparse_compose(const float* __restrict__ colors, int res, int point_size, int edge_point_size,
+                                 const ViewParams* __restrict__ params, const uint8_t* __restrict__ mask_new,
+                                 const uint32_t* __restrict__ winA, const uint32_t* __restrict__ winB,
+                                 const int32_t* __restrict__ nn_idx, float* __restrict__ sparse,
+                                 float* __restrict__ mask0, float* __restrict__ mask2, float* __restrict__ scale_factors) {
+    const int v = blockIdx.y;
+    const int g2 = (2 * point_size - 1) * (2 * point_size - 1);
+    const int ge2 = (2 * edge_point_size - 1) * (2 * edge_point_size - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_factors[v] = params[v].scale;
+    const size_t plane = (size_t)res * res;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < res * res; idx += gridDim.x * blockDim.x) {
+        int y = idx / res, x = idx - y * res;
+        size_t src = (size_t)v * plane + (size_t)(res - 1 - y) * res + x;
+        float fg = mask_new[src] ? 1.0f : 0.0f;
+        uint32_t wb = winB[src], wa = winA[src];
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, m2 = 1.0f - fg;
+        int n = -1;
+        if (wb) n = nn_idx[(size_t)v * plane + (wb - 1) / ge2];
+        else if (wa) n = (int)((wa - 1) / g2);
+        if (n >= 0) {
+            c0 = colors[3 * n]; c1 = colors[3 * n + 1]; c2 = colors[3 * n + 2];
+            m2 = 1.0f;
+        }
+        size_t o = (size_t)v * 3 * plane + idx;
+        sparse[o] = c0 * fg; sparse[o + plane] = c1 * fg; sparse[o + 2 * plane] = c2 * fg;
+        mask0[o] = fg; mask0[o + plane] = fg; mask0[o + 2 * plane] = fg;
+        mask2[o] = m2; mask2[o + plane] = m2; mask2[o + 2 * plane] = m2;
+    }
+}
+
+extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colors, const uint8_t* validation,
+                                  const uint8_t* hard_masks, int V, int N, int res, int point_size,
+                                  int edge_point_size, double mask_ratio_thresh, float* sparse, float* mask0,
+                                  float* mask2, float* scale_factors, float* mask_ratios, void* ws, void* stream) {
+    (void)mask_ratios;
+    PD_REQUIRE(V > 0 && N >= 0 && res > 0 && res <= 32768, "pdhip_sparse_views: bad sizes V=%d N=%d res=%d", V, N, res);
+    PD_REQUIRE(point_size >= 1 && edge_point_size >= 1 && point_size <= 8 && edge_point_size <= 8,
+               "pdhip_sparse_views: point sizes must be in [1,8]");
+    PD_REQUIRE((long long)N * 225 < 0x7fffffffLL && (long long)res * res * 225 < 0x7fffffffLL,
+               "pdhip_sparse_views: write-order index overflows 32 bits");
+    PD_REQUIRE(hard_masks && sparse && mask0 && mask2 && scale_factors && ws && (N == 0 || (point_pixels && colors && validation)),
+               "pdhip_sparse_views: null pointer");
+    hipStream_t s = as_stream(stream);
+    SparseWs w = carve(ws, V, N, res, nullptr);
+    const float thr = (float)mask_ratio_thresh;
+    const float omt = (float)(1.0 - mask_ratio_thresh);
+    k_sparse_counts<<<V, 256, 0, s>>>(hard_masks, validation, N, res, thr, omt, w.params, w.counts);
+    dim3 gm(min(cdiv((long long)res * res, 256), 256), V);
+    k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB);
+    if (N > 0) {
+        dim3 gs(min(cdiv(N, 256), 256), V);
+        k_sparse_splat<<<gs, 256, 0, s>>>(point_pixels, validation, N, res, point_size, w.params, w.winA, w.pp);
+        dim3 ge(res, V);
+        k_sparse_edges<<<ge, 256, res * sizeof(int), s>>>(w.mask_new, N, res, edge_point_size, w.params, w.pp, w.winB,
+                                                         w.nn_idx);
+    }
+    k_sparse_compose<<<gm, 256, 0, s>>>(colors, res, point_size, edge_point_size, w.params, w.mask_new, w.winA, w.winB,
+                                        w.nn_idx, sparse, mask0, mask2, scale_factors);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}

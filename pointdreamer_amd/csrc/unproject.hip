@@ -1,0 +1,269 @@
+// Rows Uq1-Uq4, N1-N3: UV-space unprojection with Non-Border-First view selection.
+// Reference: pointdreamer/unproject.py:201-425 (unproject), :429-475 (shrink), utils/utils_2d.py:799-845.
+// Dense [A,A] formulation: every atlas texel is one thread; the reference's compacted [P] lists are
+// produced on demand by pdhip_compact_texels (row-major order == boolean-mask order).
+// Compiled with -ffp-contract=off (arithmetic contract in oracle/unproject.py).
+#include "common.h"
+using namespace pdhip;
+
+#define MAXV 32
+
+// ------------------------------------------------------------------------------ Uq1 + Uq2
+__global__ void k_texel_visibility(const float* __restrict__ cams, int V, const float* __restrict__ gb_pos,
+                                   const uint8_t* __restrict__ mask, int A, const float* __restrict__ uv_centers,
+                                   const float* __restrict__ uv_scales, float pad9, const float* __restrict__ mesh,
+                                   int R, float offset, uint8_t* __restrict__ vis) {
+    const size_t n = (size_t)A * A;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const bool m = mask[idx];
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (m) { x = gb_pos[3 * idx]; y = gb_pos[3 * idx + 1]; z = gb_pos[3 * idx + 2]; }
+        for (int v = 0; v < V; ++v) {
+            uint8_t o = 0;
+            if (m) {
+                const Cam c = load_cam(cams + 16 * v);
+                float xn, yn, zn;
+                cam_transform(c, x, y, z, xn, yn, zn);
+                float u = ((xn - uv_centers[2 * v]) / uv_scales[v]) * pad9 + 0.5f;
+                float w = ((yn - uv_centers[2 * v + 1]) / uv_scales[v]) * pad9 + 0.5f;
+                int col = clip_to_int(u * (float)R, R - 1);
+                int row = clip_to_int(w * (float)R, R - 1);
+                float ref = mesh[((size_t)v * R + row) * R + col];
+                o = ((zn - ref) <= offset) ? 1 : 0;
+            }
+            vis[(size_t)v * n + idx] = o;
+        }
+    }
+}
+
+extern "C" int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos, const uint8_t* mask, int A,
+                                      const float* uv_centers, const float* uv_scales, double padding,
+                                      const float* mesh_depths, int R, float offset, uint8_t* visibility, void* stream) {
+    PD_REQUIRE(V > 0 && V <= MAXV && A > 0 && R > 0, "pdhip_texel_visibility: bad sizes V=%d A=%d R=%d", V, A, R);
+    PD_REQUIRE(cam_params && gb_pos && mask && uv_centers && uv_scales && mesh_depths && visibility,
+               "pdhip_texel_visibility: null pointer");
+    const float pad9 = (float)(1.0 - 2.0 * padding);
+    k_texel_visibility<<<min(cdiv((long long)A * A, 256), 4096), 256, 0, as_stream(stream)>>>(
+        cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// ------------------------------------------------------------------------------ N1-N3
+__device__ __forceinline__ int px(const uint8_t* img, int A, int y, int x) {
+    return (y >= 0 && y < A && x >= 0 && x < A) ? (img[(size_t)y * A + x] ? 1 : 0) : 0;
+}
+__device__ __forceinline__ bool scharr_edge(const uint8_t* img, int A, int y, int x) {
+    int gx = 3 * (px(img, A, y - 1, x + 1) - px(img, A, y - 1, x - 1)) + 10 * (px(img, A, y, x + 1) - px(img, A, y, x - 1)) +
+             3 * (px(img, A, y + 1, x + 1) - px(img, A, y + 1, x - 1));
+    int gy = 3 * (px(img, A, y + 1, x - 1) - px(img, A, y - 1, x - 1)) + 10 * (px(img, A, y + 1, x) - px(img, A, y - 1, x)) +
+             3 * (px(img, A, y + 1, x + 1) - px(img, A, y - 1, x + 1));
+    return gx != 0 || gy != 0;
+}
+
+// N1: edges_v = scharr(vis_v) & ~scharr(chart mask)
+__global__ void k_nbf_edges(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ vis, int A,
+                            uint8_t* __restrict__ edges) {
+    const int v = blockIdx.y;
+    const size_t n = (size_t)A * A;
+    const uint8_t* vv = vis + (size_t)v * n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(idx / A), x = (int)(idx - (size_t)y * A);
+        bool e = scharr_edge(vv, A, y, x) && !scharr_edge(mask, A, y, x);
+        edges[(size_t)v * n + idx] = e ? 1 : 0;
+    }
+}
+
+// N2 horizontal: OR over [x-r, x+r] (reflect padding adds nothing to an OR window)
+__global__ void k_nbf_dilate_h(const uint8_t* __restrict__ in, int A, int r, uint8_t* __restrict__ out) {
+    const int v = blockIdx.y;
+    const size_t n = (size_t)A * A;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(idx / A), x = (int)(idx - (size_t)y * A);
+        const uint8_t* row = in + (size_t)v * n + (size_t)y * A;
+        int lo = max(0, x - r), hi = min(A - 1, x + r);
+        uint8_t o = 0;
+        for (int k = lo; k <= hi; ++k) o |= row[k];
+        out[(size_t)v * n + idx] = o ? 1 : 0;
+    }
+}
+
+// N2 vertical + N3: shrunk = vis & ~border
+__global__ void k_nbf_dilate_v_shrink(const uint8_t* __restrict__ tmp, const uint8_t* __restrict__ vis, int A, int r,
+                                      uint8_t* __restrict__ out) {
+    const int v = blockIdx.y;
+    const size_t n = (size_t)A * A;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        int y = (int)(idx / A), x = (int)(idx - (size_t)y * A);
+        int lo = max(0, y - r), hi = min(A - 1, y + r);
+        uint8_t b = 0;
+        for (int k = lo; k <= hi; ++k) b |= tmp[(size_t)v * n + (size_t)k * A + x];
+        out[(size_t)v * n + idx] = (vis[(size_t)v * n + idx] && !b) ? 1 : 0;
+    }
+}
+
+extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, int V, int A, const int32_t* kernels,
+                                int K, uint8_t* out, uint8_t* ws, void* stream) {
+    PD_REQUIRE(V > 0 && A > 0 && K > 0 && kernels, "pdhip_nbf_shrink: bad sizes");
+    PD_REQUIRE(mask && visibility && out, "pdhip_nbf_shrink: null pointer");
+    hipStream_t s = as_stream(stream);
+    const size_t n = (size_t)V * A * A;
+    if (kernels[0] == 0) {                      // NBF off (unproject.py:436-437): single level == raw visibility
+        PD_HIP(hipMemcpyAsync(out, visibility, n, hipMemcpyDeviceToDevice, s));
+        return PDHIP_OK;
+    }
+    PD_REQUIRE(ws, "pdhip_nbf_shrink: workspace required");
+    for (int k = 0; k < K; ++k)
+        PD_REQUIRE(kernels[k] >= 1 && (kernels[k] & 1), "pdhip_nbf_shrink: kernel sizes must be odd and >= 1 (got %d)", kernels[k]);
+    uint8_t* edges = ws;
+    uint8_t* tmp = ws + n;
+    dim3 g(min(cdiv((long long)A * A, 256), 2048), V);
+    k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges);
+    for (int k = 0; k < K; ++k) {
+        int r = (kernels[k] - 1) / 2;
+        k_nbf_dilate_h<<<g, 256, 0, s>>>(edges, A, r, tmp);
+        k_nbf_dilate_v_shrink<<<g, 256, 0, s>>>(tmp, visibility, A, r, out + (size_t)k * n);
+    }
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// ------------------------------------------------------------------------------ Uq3 + Uq4
+__global__ void k_view_select_blend(const float* __restrict__ cams, int V, const float* __restrict__ gb_pos,
+                                    const uint8_t* __restrict__ mask, const int64_t* __restrict__ face_id, int A,
+                                    const float* __restrict__ f_normals, const float* __restrict__ base_dirs,
+                                    const float* __restrict__ uv_centers, const float* __restrict__ uv_scales, float pad9,
+                                    const float* __restrict__ scale_factors, const uint8_t* __restrict__ shrinked, int K,
+                                    const uint8_t* __restrict__ visibility, int complete,
+                                    const float* __restrict__ inpainted, int r, float* __restrict__ atlas,
+                                    uint8_t* __restrict__ painted, int32_t* __restrict__ view_ids) {
+    const size_t n = (size_t)A * A;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        uint8_t pt = 0;
+        int vid = -1;
+        if (mask[idx]) {
+            // candidate views: level 0, then looser levels only while nothing is visible (unproject.py:324-356)
+            uint32_t cand = 0;
+            for (int k = 0; k < K; ++k) {
+                if (k > 0 && cand) break;
+                for (int v = 0; v < V; ++v) cand |= (shrinked[((size_t)k * V + v) * n + idx] ? 1u : 0u) << v;
+            }
+            if (complete && !cand)
+                for (int v = 0; v < V; ++v) cand |= (visibility[(size_t)v * n + idx] ? 1u : 0u) << v;
+            // similarity of the face normal with every view direction, softmax in view order
+            const int64_t f = face_id[idx];
+            const float n0 = f_normals[3 * f], n1 = f_normals[3 * f + 1], n2 = f_normals[3 * f + 2];
+            float sim[MAXV];
+            float mx = -INFINITY;
+            for (int v = 0; v < V; ++v) {
+                sim[v] = (n0 * base_dirs[3 * v] + n1 * base_dirs[3 * v + 1]) + n2 * base_dirs[3 * v + 2];
+                mx = fmaxf(mx, sim[v]);
+            }
+            float sum = 0.f;
+            for (int v = 0; v < V; ++v) {
+                sim[v] = (float)exp((double)(sim[v] - mx));
+                sum = sum + sim[v];
+            }
+            float best = -INFINITY;
+            int bi = 0;
+            for (int v = 0; v < V; ++v) {
+                float w = ((cand >> v) & 1u) ? sim[v] / sum : -100.0f;
+                if (w > best) { best = w; bi = v; }
+            }
+            vid = bi;
+            if (!complete && !cand) vid = -100;
+            if (vid >= 0) {
+                const Cam c = load_cam(cams + 16 * vid);
+                float xn, yn, zn;
+                cam_transform(c, gb_pos[3 * idx], gb_pos[3 * idx + 1], gb_pos[3 * idx + 2], xn, yn, zn);
+                float u = (((xn - uv_centers[2 * vid]) / uv_scales[vid]) * scale_factors[vid]) * pad9 + 0.5f;
+                float w = (((yn - uv_centers[2 * vid + 1]) / uv_scales[vid]) * scale_factors[vid]) * pad9 + 0.5f;
+                int col = clip_to_int(u * (float)r, r - 1);
+                int row = clip_to_int(w * (float)r, r - 1);
+                const float* img = inpainted + (size_t)vid * 3 * r * r + (size_t)(r - 1 - row) * r + col;
+                o0 = img[0]; o1 = img[(size_t)r * r]; o2 = img[2 * (size_t)r * r];
+                pt = 1;
+            }
+        }
+        atlas[3 * idx] = o0; atlas[3 * idx + 1] = o1; atlas[3 * idx + 2] = o2;
+        painted[idx] = pt;
+        view_ids[idx] = vid;
+    }
+}
+
+extern "C" int pdhip_view_select_blend(const float* cam_params, int V, const float* gb_pos, const uint8_t* mask,
+                                       const int64_t* face_id, int A, const float* f_normals, const float* base_dirs,
+                                       const float* uv_centers, const float* uv_scales, double padding,
+                                       const float* scale_factors, const uint8_t* shrinked, int K,
+                                       const uint8_t* visibility, int complete_unseen_by_projection,
+                                       const float* inpainted, int r, float* atlas, uint8_t* painted,
+                                       int32_t* view_ids, void* stream) {
+    PD_REQUIRE(V > 0 && V <= MAXV && A > 0 && K > 0 && r > 0, "pdhip_view_select_blend: bad sizes V=%d A=%d K=%d r=%d", V, A, K, r);
+    PD_REQUIRE(cam_params && gb_pos && mask && face_id && f_normals && base_dirs && uv_centers && uv_scales &&
+                   scale_factors && shrinked && visibility && inpainted && atlas && painted && view_ids,
+               "pdhip_view_select_blend: null pointer");
+    const float pad9 = (float)(1.0 - 2.0 * padding);
+    k_view_select_blend<<<min(cdiv((long long)A * A, 256), 4096), 256, 0, as_stream(stream)>>>(
+        cam_params, V, gb_pos, mask, face_id, A, f_normals, base_dirs, uv_centers, uv_scales, pad9, scale_factors,
+        shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted, view_ids);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// ------------------------------------------------------------------------------ compaction
+__global__ void k_compact_count(const uint8_t* __restrict__ mask, int A, int32_t* __restrict__ row_cnt) {
+    const int row = blockIdx.x;
+    __shared__ int s[4];
+    int c = 0;
+    for (int x = threadIdx.x; x < A; x += blockDim.x) c += mask[(size_t)row * A + x] ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) row_cnt[row] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ void k_compact_scan(int32_t* __restrict__ row_cnt, int A, int32_t* __restrict__ count_dev) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < A; ++i) { int c = row_cnt[i]; row_cnt[i] = acc; acc += c; }
+        row_cnt[A] = acc;
+        *count_dev = acc;
+    }
+}
+
+__global__ void k_compact_write(const float* __restrict__ gb_pos, const uint8_t* __restrict__ mask, int A,
+                                const int32_t* __restrict__ view_ids, const int32_t* __restrict__ row_off,
+                                float* __restrict__ points, int64_t* __restrict__ coords, int64_t* __restrict__ pvid) {
+    const int row = blockIdx.x;                 // one wave per row: ranks via ballot prefix
+    int base = row_off[row];
+    const int lane = threadIdx.x;
+    for (int x0 = 0; x0 < A; x0 += 64) {
+        int x = x0 + lane;
+        bool m = x < A && mask[(size_t)row * A + x];
+        unsigned long long bal = __ballot(m);
+        if (m) {
+            int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+            size_t idx = (size_t)row * A + x;
+            if (points) { points[3 * rank] = gb_pos[3 * idx]; points[3 * rank + 1] = gb_pos[3 * idx + 1]; points[3 * rank + 2] = gb_pos[3 * idx + 2]; }
+            if (coords) { coords[2 * rank] = row; coords[2 * rank + 1] = x; }
+            if (pvid) pvid[rank] = view_ids[idx];
+        }
+        base += __popcll(bal);
+    }
+}
+
+extern "C" int pdhip_compact_texels(const float* gb_pos, const uint8_t* mask, int A, const int32_t* view_ids,
+                                    float* points, int64_t* coords, int64_t* point_view_ids, int32_t* count_dev,
+                                    int32_t* ws, void* stream) {
+    PD_REQUIRE(A > 0 && mask && ws && count_dev, "pdhip_compact_texels: bad arguments");
+    PD_REQUIRE(!points || gb_pos, "pdhip_compact_texels: points requested without gb_pos");
+    PD_REQUIRE(!point_view_ids || view_ids, "pdhip_compact_texels: point_view_ids requested without view_ids");
+    hipStream_t s = as_stream(stream);
+    k_compact_count<<<A, 256, 0, s>>>(mask, A, ws);
+    k_compact_scan<<<1, 64, 0, s>>>(ws, A, count_dev);
+    k_compact_write<<<A, 64, 0, s>>>(gb_pos, mask, A, view_ids, ws, points, coords, point_view_ids);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}

@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's pointdreamer/ours_utils.py for the texturing hot path.
+
+Same function names, argument meaning, return order and tensor contracts as the reference
+(/root/reference/pointdreamer/ours_utils.py) so that demo.colorize_one_mesh-style callers switch by
+changing the import; every function routes to one C-ABI entry point of libpdhip.so (include/pdhip.h).
+Torch is used for device memory and streams only.  There is no CPU path: CPU tensors raise.
+"""
+import os
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr, as_u8, stream, check
+from .camera_utils import stack_params
+from . import io_utils
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.PdhipError("expected a GPU tensor; pointdreamer_amd has no CPU path")
+    return t.device
+
+
+def transform_points(cams, pts):
+    """cam.transform for a list of cameras: pts[M,3] -> [V,M,3] NDC (kaolin Camera.transform contract)."""
+    L = _lib.lib()
+    pts = pts.reshape(-1, 3).float().contiguous()
+    V, M = len(cams), pts.shape[0]
+    dev = _dev(pts)
+    cp = stack_params(cams)
+    pos = torch.empty((V, M, 4), device=dev)
+    vuv = torch.empty((V, M, 2), device=dev)
+    ws = torch.empty((4 * V,), dtype=torch.int32, device=dev)
+    check(L.pdhip_project_points(ptr(cp), V, ptr(pts), M, None, 0, 0, 0.0, ptr(pos), ptr(vuv), None, None, None, None,
+                                 ptr(ws), stream()), 'pdhip_project_points')
+    return pos[..., :3]
+
+
+def get_rendered_hard_mask_and_face_idx_batch(cams, vertices, faces, points, glctx=None, rescale=True, padding=0.05):
+    """ours_utils.py:93-150.  Returns, in the reference's order:
+    hard_masks[V,R,R] bool, face_idxs[V,R,R] int64, mesh_normalized_depths[V,R,R] f32, vertice_uvs[V,Vn,2],
+    uv_centers[V,1,2], uv_scales[V,1,1], padding, point_uvs[V,N,2], point_depths[V,N].  `glctx` is ignored."""
+    L = _lib.lib()
+    dev = _dev(vertices)
+    vertices = vertices.float().contiguous()
+    points = points.float().contiguous()
+    faces32 = faces.to(torch.int32).contiguous()
+    V, Vn, N, F = len(cams), vertices.shape[0], points.shape[0], faces32.shape[0]
+    R = int(cams[0].height)
+    cp = stack_params(cams)
+    pos = torch.empty((V, Vn, 4), device=dev)
+    vuv = torch.empty((V, Vn, 2), device=dev)
+    uvc = torch.empty((V, 1, 2), device=dev)
+    uvs = torch.empty((V, 1, 1), device=dev)
+    puv = torch.empty((V, N, 2), device=dev)
+    pdep = torch.empty((V, N), device=dev)
+    ws = torch.empty((4 * V,), dtype=torch.int32, device=dev)
+    check(L.pdhip_project_points(ptr(cp), V, ptr(vertices), Vn, ptr(points), N, 1 if rescale else 0, float(padding),
+                                 ptr(pos), ptr(vuv), ptr(uvc), ptr(uvs), ptr(puv), ptr(pdep), ptr(ws), stream()),
+          'pdhip_project_points')
+    zkey = torch.empty((V, R, R), dtype=torch.int64, device=dev)
+    hard = torch.empty((V, R, R), dtype=torch.bool, device=dev)
+    fidx = torch.empty((V, R, R), dtype=torch.int64, device=dev)
+    depth = torch.empty((V, R, R), device=dev)
+    check(L.pdhip_raster_mesh(ptr(pos), V, Vn, ptr(faces32), F, R, ptr(zkey), ptr(as_u8(hard)), ptr(fidx), ptr(depth),
+                              stream()), 'pdhip_raster_mesh')
+    if rescale:
+        return hard, fidx, depth, vuv, uvc, uvs, padding, puv, pdep
+    return hard, fidx, depth, vuv, 0, 2, 0, puv, pdep
+
+
+def resize_masks(hard_masks, res):
+    """demo.py:103-104: transforms.Resize((res,res))(mask.float()).bool() on [V,R,R] masks."""
+    L = _lib.lib()
+    hard_masks = hard_masks.contiguous()
+    V, H, W = hard_masks.shape
+    out = torch.empty((V, res, res), dtype=torch.bool, device=_dev(hard_masks))
+    check(L.pdhip_resize_mask(ptr(as_u8(hard_masks)), V, H, W, ptr(as_u8(out)), res, res, stream()), 'pdhip_resize_mask')
+    return out
+
+
+def get_point_validation_by_depth(cam_res, point_uvs, point_depths, mesh_depths, offset=0, vis=False):
+    """ours_utils.py:153-202 -> (visibility[V,N] bool, point_pixels[V,N,2] int64 (row,col))."""
+    L = _lib.lib()
+    dev = _dev(point_uvs)
+    point_uvs = point_uvs.float().contiguous()
+    point_depths = point_depths.float().contiguous()
+    mesh_depths = mesh_depths.float().contiguous()
+    V, N = point_depths.shape
+    visb = torch.empty((V, N), dtype=torch.bool, device=dev)
+    pix = torch.empty((V, N, 2), dtype=torch.int64, device=dev)
+    check(L.pdhip_point_visibility(int(cam_res), ptr(point_uvs), ptr(point_depths), ptr(mesh_depths), V, N, float(offset),
+                                   ptr(as_u8(visb)), ptr(pix), stream()), 'pdhip_point_visibility')
+    return visb, pix
+
+
+def get_point_pixels(point_uvs, res):
+    """demo.py:121-125."""
+    L = _lib.lib()
+    point_uvs = point_uvs.float().contiguous()
+    V, N = point_uvs.shape[:2]
+    pix = torch.empty((V, N, 2), dtype=torch.int64, device=_dev(point_uvs))
+    check(L.pdhip_point_pixels(ptr(point_uvs), V, N, int(res), ptr(pix), stream()), 'pdhip_point_pixels')
+    return pix
+
+
+def get_point_validation_by_o3d(points, eye_positions=None, hidden_point_removal_radius=None):
+    """ours_utils.py:204-225 (Open3D hidden_point_removal per view) -> [V,N] bool."""
+    from .hpr import hidden_point_removal
+    return hidden_point_removal(points, eye_positions, hidden_point_removal_radius)
+
+
+def get_sparse_images(point_pixels, colors, point_validation, hard_masks, save_path, view_num, res, point_size,
+                      edge_point_size, mask_ratio_thresh):
+    """ours_utils.py:848-882 -> sparse_imgs[V,3,r,r], hard_mask0s, hard_mask2s, scale_factors[V]."""
+    L = _lib.lib()
+    dev = _dev(point_pixels)
+    point_pixels = point_pixels.to(torch.int64).contiguous()
+    colors = colors.float().contiguous()
+    point_validation = point_validation.contiguous()
+    hard_masks = hard_masks.contiguous()
+    V, N = point_pixels.shape[:2]
+    assert V == view_num and hard_masks.shape[-1] == res
+    sparse = torch.empty((V, 3, res, res), device=dev)
+    m0 = torch.empty_like(sparse)
+    m2 = torch.empty_like(sparse)
+    sf = torch.empty((V,), device=dev)
+    ws = torch.empty((L.pdhip_sparse_views_ws_bytes(V, N, res),), dtype=torch.uint8, device=dev)
+    check(L.pdhip_sparse_views(ptr(point_pixels), ptr(colors), ptr(as_u8(point_validation)), ptr(as_u8(hard_masks)),
+                               V, N, res, int(point_size), int(edge_point_size), float(mask_ratio_thresh),
+                               ptr(sparse), ptr(m0), ptr(m2), ptr(sf), None, ptr(ws), stream()), 'pdhip_sparse_views')
+    if save_path is not None:
+        os.makedirs(save_path, exist_ok=True)
+        for i in range(V):
+            save_mask = (m0[i][0] * m2[i][0]).unsqueeze(0)
+            io_utils.save_CHW_RGBA_img(torch.cat([sparse[i], save_mask]).cpu().numpy(), os.path.join(save_path, f'{i}_sparse.png'))
+            io_utils.save_CHW_RGB_img(m0[i].cpu().numpy(), os.path.join(save_path, f'{i}_mask0.png'))
+            io_utils.save_CHW_RGB_img(m2[i].cpu().numpy(), os.path.join(save_path, f'{i}_mask2.png'))
+    return sparse, m0, m2, sf
+
+
+def nearest_fill(img, site_mask, layout='CHW'):
+    """Batched exact nearest-site fill.  img [B,C,H,W] (layout 'CHW') or [B,H,W,C] ('HWC') float32;
+    site_mask [B,H,W] bool/uint8 or float (site iff != 0)."""
+    L = _lib.lib()
+    img = img.float().contiguous()
+    dev = _dev(img)
+    if layout == 'CHW':
+        B, Cn, H, W = img.shape
+        bs, cs, ps = Cn * H * W, H * W, 1
+    else:
+        B, H, W, Cn = img.shape
+        bs, cs, ps = H * W * Cn, 1, Cn
+    site_mask = site_mask.contiguous()
+    is_f32 = 1 if site_mask.dtype == torch.float32 else 0
+    if not is_f32:
+        site_mask = as_u8(site_mask)
+        if site_mask.dtype != torch.uint8:
+            raise _lib.PdhipError("site mask must be bool, uint8 or float32")
+    out = torch.empty_like(img)
+    ws = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    check(L.pdhip_nearest_fill(ptr(img), ptr(out), B, Cn, H, W, bs, cs, ps, ptr(site_mask), is_f32, H * W, ptr(ws),
+                               stream()), 'pdhip_nearest_fill')
+    return out
+
+
+def naive_inpainting(img, no_need_inpaint_mask2, method='linear'):
+    """ours_utils.py:610-643.  img[C,H,W], mask2[C,H,W] (channel 0 used) -> [C,H,W] float32 on the GPU.
+    Only method='nearest' is built (exact, tie rule in DESIGN.md); 'linear' needs a Delaunay
+    triangulation and is out of scope for this round."""
+    if method != 'nearest':
+        raise NotImplementedError("texture_gen_method='linear' (scipy Delaunay) is not built; use 'nearest' or 'DDNM_inpaint'")
+    m = no_need_inpaint_mask2[0:1].contiguous()
+    if m.dtype not in (torch.float32, torch.bool, torch.uint8):
+        m = m.float()
+    return nearest_fill(img.unsqueeze(0), m, 'CHW')[0]
+
+
+def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpainter, view_num, method='linear'):
+    """ours_utils.py:884-951 -> inpainted[V,3,r,r]."""
+    if method == 'DDNM_inpaint':
+        out = inpainter.inpaint_views(sparse_imgs, hard_mask2s[:, 0].contiguous())
+        if save_path is not None:
+            os.makedirs(save_path, exist_ok=True)
+            for i in range(view_num):
+                rgba = torch.cat([out[i], hard_mask0s[i][0].unsqueeze(0)])
+                io_utils.save_CHW_RGBA_img(rgba.cpu().numpy(), os.path.join(save_path, f'{i}_inpainted.png'))
+        return out
+    if method != 'nearest':
+        raise NotImplementedError(f"texture_gen_method={method!r} is not built (DDNM_inpaint | nearest)")
+    m = hard_mask2s[:, 0].contiguous()
+    out = nearest_fill(sparse_imgs, m, 'CHW')
+    if save_path is not None:
+        os.makedirs(save_path, exist_ok=True)
+        for i in range(view_num):
+            io_utils.save_CHW_RGB_img(out[i].cpu().numpy(), os.path.join(save_path, f'{i}_inpainted.png'))
+    return out

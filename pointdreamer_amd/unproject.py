@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference's pointdreamer/unproject.py (rows Uq1-Uq5, N1-N3): same names,
+argument order and return tuples (/root/reference/pointdreamer/unproject.py:201-425, 429-475, 480-504);
+each routes to libpdhip.so.  The debug PNG triptychs the reference always writes
+(unproject.py:459-474) are not produced: they are not consumed by anything downstream."""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import ptr, as_u8, stream, check
+from .camera_utils import stack_params
+from .ours_utils import nearest_fill, _dev
+
+
+def _as_vec(x, V, dev):
+    if torch.is_tensor(x):
+        return x.to(dev).float().reshape(-1).contiguous()
+    return torch.full((V,), float(x), device=dev)
+
+
+def texel_visibility(cams, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, cam_res, offset=0.0001):
+    """Uq1+Uq2 (unproject.py:219-284) -> visibility[V,A,A] bool."""
+    L = _lib.lib()
+    dev = _dev(gb_pos)
+    V = len(cams)
+    A = mask.shape[1]
+    cp = stack_params(cams)
+    gb = gb_pos[0].float().contiguous()
+    m = as_u8(mask[0, :, :, 0].contiguous())
+    uvc = uv_centers.float().reshape(V, 2).contiguous()
+    uvs = uv_scales.float().reshape(V).contiguous()
+    md = mesh_normalized_depths.float().contiguous()
+    vis = torch.empty((V, A, A), dtype=torch.bool, device=dev)
+    check(L.pdhip_texel_visibility(ptr(cp), V, ptr(gb), ptr(m), A, ptr(uvc), ptr(uvs), float(padding), ptr(md),
+                                   int(cam_res), float(offset), ptr(as_u8(vis)), stream()), 'pdhip_texel_visibility')
+    return vis
+
+
+def get_shrinked_per_view_per_pixel_visibility_torch(per_pixel_mask, per_atlas_pixel_per_view_visibility,
+                                                     kernel_sizes=[21], save_path=None):
+    """unproject.py:429-475.  per_pixel_mask[A,A] bool, visibility [A,A,V] bool (reference layout)
+    -> [K,V,A,A] bool."""
+    vis = per_atlas_pixel_per_view_visibility.permute(2, 0, 1).contiguous()
+    return shrink_visibility(per_pixel_mask, vis, kernel_sizes)
+
+
+def shrink_visibility(per_pixel_mask, vis_VAA, kernel_sizes):
+    L = _lib.lib()
+    dev = _dev(vis_VAA)
+    V, A, _ = vis_VAA.shape
+    ks = [int(k) for k in kernel_sizes]
+    K = 1 if ks[0] == 0 else len(ks)
+    arr = (C.c_int32 * len(ks))(*ks)
+    out = torch.empty((K, V, A, A), dtype=torch.bool, device=dev)
+    ws = torch.empty((2, V, A, A), dtype=torch.uint8, device=dev)
+    check(L.pdhip_nbf_shrink(ptr(as_u8(per_pixel_mask.contiguous())), ptr(as_u8(vis_VAA.contiguous())), V, A, arr, K,
+                             ptr(as_u8(out)), ptr(ws), stream()), 'pdhip_nbf_shrink')
+    return out
+
+
+def unproject_dense(inpainted_images, f_normals, view_img_res, cams, cam_res, base_dirs, gb_pos, mask,
+                    per_atlas_pixel_face_id, uv_centers, uv_scales, padding, inpaint_scale_factors,
+                    mesh_normalized_depths, edge_dilate_kernels, complete_unseen_by_projection=False):
+    """The whole of unproject() in its dense [A,A] form (no compaction, no host sync).
+    Returns atlas[A,A,3], shrinked[V,A,A] bool (last level), view_ids[A,A] int32, painted[A,A] bool, vis[V,A,A]."""
+    L = _lib.lib()
+    dev = _dev(gb_pos)
+    V = len(cams)
+    A = mask.shape[1]
+    if uv_scales is None or uv_centers is None or inpaint_scale_factors is None or padding is None:
+        # unproject.py:260-262: uv = xy*0.5+0.5  ==  centre 0, scale 2, padding 0, factor 1
+        uv_centers = torch.zeros((V, 1, 2), device=dev)
+        uv_scales = torch.full((V, 1, 1), 2.0, device=dev)
+        inpaint_scale_factors, padding = torch.ones((V,), device=dev), 0.0
+    if not torch.is_tensor(uv_centers):
+        uv_centers = torch.full((V, 1, 2), float(uv_centers), device=dev)
+    if not torch.is_tensor(uv_scales):
+        uv_scales = torch.full((V, 1, 1), float(uv_scales), device=dev)
+    vis = texel_visibility(cams, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, cam_res)
+    per_pixel_mask = mask[0, :, :, 0].contiguous()
+    kernel_sizes = list(edge_dilate_kernels) * (A // 256)          # list repetition, unproject.py:289
+    if len(kernel_sizes) == 0:
+        raise _lib.PdhipError("atlas resolution < 256 gives an empty kernel list in the reference (IndexError); use A >= 256")
+    per_kernel = shrink_visibility(per_pixel_mask, vis, kernel_sizes)
+    K = min(len(edge_dilate_kernels), per_kernel.shape[0])
+    cp = stack_params(cams)
+    gb = gb_pos[0].float().contiguous()
+    fid = per_atlas_pixel_face_id[0].to(torch.int64).contiguous()
+    fn = f_normals.float().contiguous()
+    bd = base_dirs.float().contiguous()
+    uvc = uv_centers.float().reshape(V, 2).contiguous()
+    uvs = uv_scales.float().reshape(V).contiguous()
+    sf = _as_vec(inpaint_scale_factors, V, dev)
+    img = inpainted_images.float().contiguous()
+    atlas = torch.empty((A, A, 3), device=dev)
+    painted = torch.empty((A, A), dtype=torch.bool, device=dev)
+    view_ids = torch.empty((A, A), dtype=torch.int32, device=dev)
+    check(L.pdhip_view_select_blend(ptr(cp), V, ptr(gb), ptr(as_u8(per_pixel_mask)), ptr(fid), A, ptr(fn), ptr(bd),
+                                    ptr(uvc), ptr(uvs), float(padding), ptr(sf), ptr(as_u8(per_kernel)), K,
+                                    ptr(as_u8(vis)), 1 if complete_unseen_by_projection else 0, ptr(img),
+                                    int(view_img_res), ptr(atlas), ptr(as_u8(painted)), ptr(view_ids), stream()),
+          'pdhip_view_select_blend')
+    return atlas, per_kernel[K - 1], view_ids, painted, vis
+
+
+def compact_texels(gb_pos, mask, view_ids):
+    """Row-major compaction of the chart texels (unproject.py:223-233): points[P,3], coords[P,2], view ids[P]."""
+    L = _lib.lib()
+    dev = _dev(gb_pos)
+    A = mask.shape[1]
+    gb = gb_pos[0].float().contiguous()
+    m = as_u8(mask[0, :, :, 0].contiguous())
+    n = A * A
+    points = torch.empty((n, 3), device=dev)
+    coords = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    pvid = torch.empty((n,), dtype=torch.int64, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((A + 1,), dtype=torch.int32, device=dev)
+    check(L.pdhip_compact_texels(ptr(gb), ptr(m), A, ptr(view_ids.contiguous()), ptr(points), ptr(coords), ptr(pvid),
+                                 ptr(cnt), ptr(ws), stream()), 'pdhip_compact_texels')
+    P = int(cnt.item())                                              # the one host sync (the reference syncs here too)
+    return points[:P], coords[:P], pvid[:P]
+
+
+def unproject(inpainted_images, vertices, f_normals, view_img_res, cams, cam_res, base_dirs, gb_pos, mask,
+              per_atlas_pixel_face_id, uv_centers, uv_scales, padding, inpaint_scale_factors, mesh_normalized_depths,
+              edge_dilate_kernels, save_img_path, complete_unseen_by_projection=False):
+    """unproject.py:201-425, same 18 positional arguments and the same 6-tuple:
+    atlas_img[A,A,3], shrinked_per_view_per_pixel_visibility[V,A,A], point_view_ids[P], points_atlas_pixel_coord[P,2],
+    points[P,3], atlas_painted_mask[A,A]."""
+    atlas, shr, view_ids, painted, _ = unproject_dense(
+        inpainted_images, f_normals, view_img_res, cams, cam_res, base_dirs, gb_pos, mask, per_atlas_pixel_face_id,
+        uv_centers, uv_scales, padding, inpaint_scale_factors, mesh_normalized_depths, edge_dilate_kernels,
+        complete_unseen_by_projection)
+    points, coords, pvid = compact_texels(gb_pos, mask, view_ids)
+    return atlas, shr, pvid, coords, points, painted
+
+
+def dilate_atlas(atlas_img, mask):
+    """unproject.py:480-504: atlas_img[A,A,3], mask[1,A,A,1] bool -> [A,A,3] (float32 on the GPU)."""
+    m = mask[..., 0].contiguous()
+    return nearest_fill(atlas_img.unsqueeze(0), m, 'HWC')[0]
