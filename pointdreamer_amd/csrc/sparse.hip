@@ -13,6 +13,7 @@ struct ViewParams {
     int after_res;
     int pad;
     int degenerate;
+    int rescaled;   // mask_ratio > thresh branch taken (after_res may still equal res)
 };
 
 struct SparseWs {
@@ -66,12 +67,13 @@ __global__ void k_sparse_counts(const uint8_t* __restrict__ hard, const uint8_t*
         va = s_va[0] + s_va[1] + s_va[2] + s_va[3];
         counts[2 * v] = fg; counts[2 * v + 1] = va;
         ViewParams p;
-        p.scale = 1.0f; p.after_res = res; p.pad = 0;
+        p.scale = 1.0f; p.after_res = res; p.pad = 0; p.rescaled = 0;
         p.degenerate = (fg == 0 || va == 0) ? 1 : 0;
         if (!p.degenerate) {
             float fgf = (float)fg, vaf = (float)va;
             float ratio = 1.0f - vaf / fgf;
             if (ratio > thresh_f) {
+                p.rescaled = 1;
                 float wanted = vaf / one_minus_thresh_f;
                 p.scale = wanted / fgf;
                 int ar = (int)floorf((float)res * p.scale);
@@ -104,7 +106,7 @@ __global__ void k_sparse_mask(const uint8_t* __restrict__ hard, int res, const V
     const uint8_t* src = hard + (size_t)v * res * res;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < res * res; idx += gridDim.x * blockDim.x) {
         uint8_t m;
-        if (p.after_res == res) {
+        if (!p.rescaled) {
             m = src[idx] ? 1 : 0;
         } else {
             int y = idx / res - p.pad, x = idx % res - p.pad;
@@ -137,7 +139,7 @@ __global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* _
         int packed = -1;
         if (valid[o] && !p.degenerate) {
             int row = (int)pix[2 * o], col = (int)pix[2 * o + 1];
-            if (p.after_res != res) {
+            if (p.rescaled) {
                 float ur = (float)row / (float)res, uc = (float)col / (float)res;
                 ur = ur * 2.0f - 1.0f; uc = uc * 2.0f - 1.0f;
                 ur = ur * p.scale; uc = uc * p.scale;

@@ -1,0 +1,58 @@
+"""The texturing hot path as one call: project -> inpaint -> unproject (-> dilate).
+
+`colorize_one_mesh` keeps the keyword surface of the reference's demo.colorize_one_mesh
+(/root/reference/demo.py:38-253) for the stages this build covers.  Stages outside SURVEY 8 rows (a)-(e)
+(`complete_unseen_by` 'neighbor'/'optimize', `optimize_color`) raise NotImplementedError instead of
+silently doing something else; `complete_unseen_by='unproject'`, `optimize_from=None` is the measured path.
+"""
+import torch
+
+from . import ours_utils as ou
+from . import unproject as up
+
+
+def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, camera_info, view_num, res, cam_res,
+                      device=None, save_img_path=None, point_validation_by_o3d=True,
+                      refine_point_validation_by_remove_abnormal_depth=False, hidden_point_removal_radius=100,
+                      texture_gen_method='DDNM_inpaint', point_size=1, edge_point_size=1, crop_img=True,
+                      crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None, edge_dilate_kernels=(21,),
+                      complete_unseen_by='unproject', inpainter=None, glctx=None, logger=None,
+                      xatlas_texture_res=1024, refine_res=512, return_intermediates=False, **kwargs):
+    if refine_point_validation_by_remove_abnormal_depth:
+        raise NotImplementedError("refine_point_validation_by_remove_abnormal_depth (off in every shipped config) is not built")
+    if complete_unseen_by != 'unproject':
+        raise NotImplementedError(f"complete_unseen_by={complete_unseen_by!r}: only 'unproject' is built (SURVEY 8f lists "
+                                  "'neighbor' and 'optimize' as next)")
+    if optimize_from not in (None, 'None'):
+        raise NotImplementedError("optimize_color (optimize_from != None) is SURVEY 8f item 1: not built yet")
+    cams = camera_info['cams']
+    base_dirs = camera_info['base_dirs']
+    eye_positions = camera_info['eye_positions']
+    gb_pos = xatlas_dict['gb_pos']
+    mask = xatlas_dict['mask']
+    face_id = xatlas_dict['per_atlas_pixel_face_id']
+    with torch.no_grad():
+        hard_masks, face_idxs, mesh_depths, vertice_uvs, uv_centers, uv_scales, padding, point_uvs, point_depths = \
+            ou.get_rendered_hard_mask_and_face_idx_batch(cams, vertices, faces, coords, glctx=glctx, rescale=crop_img,
+                                                         padding=crop_padding)
+        if cam_res != res:
+            hard_masks = ou.resize_masks(hard_masks, res)
+        point_validation, _ = ou.get_point_validation_by_depth(cam_res, point_uvs, point_depths, mesh_depths, offset=0.0001)
+        if point_validation_by_o3d:
+            pv2 = ou.get_point_validation_by_o3d(coords, eye_positions, hidden_point_removal_radius)
+            point_validation = torch.logical_or(point_validation, pv2)
+        point_pixels = ou.get_point_pixels(point_uvs, res)
+        sparse_imgs, hard_mask0s, hard_mask2s, scale_factors = ou.get_sparse_images(
+            point_pixels, colors, point_validation, hard_masks, save_img_path, view_num, res, point_size,
+            edge_point_size, mask_ratio_thresh)
+        inpainted = ou.get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_img_path, inpainter, view_num,
+                                            method=texture_gen_method)
+        atlas, shrinked, view_ids, painted, vis = up.unproject_dense(
+            inpainted, f_normals, res, cams, cam_res, base_dirs, gb_pos, mask, face_id, uv_centers, uv_scales, padding,
+            scale_factors, mesh_depths, list(edge_dilate_kernels), True)
+        atlas = up.dilate_atlas(atlas, mask)
+    if return_intermediates:
+        return dict(atlas=atlas, inpainted=inpainted, sparse=sparse_imgs, mask0=hard_mask0s, mask2=hard_mask2s,
+                    view_ids=view_ids, painted=painted, shrinked=shrinked, visibility=vis,
+                    point_validation=point_validation, scale_factors=scale_factors, mesh_depths=mesh_depths)
+    return vertices, xatlas_dict.get('uvs'), faces, xatlas_dict.get('mesh_tex_idx'), atlas, mask

@@ -81,7 +81,8 @@ def test_p1_p2_project_and_raster_vs_oracle(pd, n_points, stacks, slices, V, R):
     assert out2[4] == 0 and out2[5] == 2 and out2[6] == 0
 
 
-@pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz"])
+@pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz",
+                                  "proj_sparse_scale_near1.npz"])
 def test_p1_to_p6_vs_reference_golden(pd, name):
     g = load_golden(name)
     R, r = int(g['cam_res']), int(g['res'])

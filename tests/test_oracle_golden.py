@@ -6,7 +6,8 @@ from oracle import camera as ocam, project as oproj, sparse as osparse, inpaint 
 from oracle import unproject as ounp
 
 
-@pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz"])
+@pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz",
+                                  "proj_sparse_scale_near1.npz"])
 def test_p3_depth_visibility_bit_exact(name):
     g = load_golden(name)
     vis, pix = oproj.point_validation_by_depth(int(g['cam_res']), g['point_uvs'], g['point_depths'],
@@ -15,7 +16,8 @@ def test_p3_depth_visibility_bit_exact(name):
     assert np.array_equal(pix, g['ref_point_pixels_R'])
 
 
-@pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz"])
+@pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz",
+                                  "proj_sparse_scale_near1.npz"])
 def test_p4_p6_sparse_images_bit_exact(name):
     g = load_golden(name)
     V = g['point_uvs'].shape[0]

@@ -113,6 +113,7 @@ def main():
     s, m2 = gen_proj_sparse(ou, 'proj_sparse_rescale.npz', 300, seed=2)
     gen_nearest(ou, 'nearest_rescale.npz', s, m2)
     gen_proj_sparse(ou, 'proj_sparse_ps2.npz', 600, seed=4, point_size=2, edge_point_size=2)
+    gen_proj_sparse(ou, 'proj_sparse_scale_near1.npz', 1500, seed=9)   # mask_ratio branch taken but after_res == res
     gen_unproject(ou, up, u2, 'unproject_k21.npz', [21], False)
     gen_unproject(ou, up, u2, 'unproject_k21_complete.npz', [21], True)
     gen_unproject(ou, up, u2, 'unproject_k0.npz', [0], True)
