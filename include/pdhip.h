@@ -126,6 +126,56 @@ int pdhip_compact_texels(const float* gb_pos, const uint8_t* mask, int A, const 
                          float* points, int64_t* coords, int64_t* point_view_ids, int32_t* count_dev,
                          int32_t* ws, void* stream);
 
+/* =============================== rows U1 + D1: guided-diffusion UNet + DDNM ===============================
+ * Replaces models/DDNM/ddnm_inpainting.py:15-44 (Inpainter), guided_diffusion/diffusion.py:435-570
+ * (get_model, simplified_ddnm_inpainting) and guided_diffusion/unet.py:396-664 (UNetModel, fp16 torso).
+ * The handle owns the repacked weights and an activation arena sized for max_batch images. */
+typedef struct pdhip_unet pdhip_unet;
+
+/* script_util.create_model (script_util.py:130-185): channel_mult / attention_ds are the already-resolved
+ * integer tuples (for 256x256: mult (1,1,2,2,4,4), attention_ds (8,16,32)). */
+int pdhip_unet_create(int image_size, int model_channels, int num_res_blocks, const int* channel_mult, int n_mult,
+                      const int* attention_ds, int n_att, int num_head_channels, int out_channels, int max_batch,
+                      pdhip_unet** out);
+void pdhip_unet_destroy(pdhip_unet* u);
+long long pdhip_unet_arena_bytes(const pdhip_unet* u);
+int pdhip_unet_num_tensors(const pdhip_unet* u);
+/* model.load_state_dict (diffusion.py:453): one call per state-dict entry, reference key names, PyTorch layouts
+ * (conv OIHW, linear [out,in]); data is a device pointer to float32 (is_f16 = 0) or float16 (1). */
+int pdhip_unet_load_tensor(pdhip_unet* u, const char* name, const void* data, int is_f16, const int64_t* shape, int ndim,
+                           void* stream);
+int pdhip_unet_missing_tensors(const pdhip_unet* u, char* buf, int buf_len);
+/* UNetModel.forward (unet.py:635-664): x[N,3,S,S] f32, t[N] f32 -> out[N,out_channels,S,S] f32. */
+int pdhip_unet_forward(pdhip_unet* u, const float* x, const float* t, int N, float* out, void* stream);
+/* HIP-event timing of the dominant kernel (3x3 implicit-GEMM conv launches) on the launch stream. */
+int pdhip_unet_profile(pdhip_unet* u, int enable);
+int pdhip_unet_profile_read(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches);
+
+/* D1 schedule (diffusion.py:46-113, 770-812): 100 steps t = 990..0; host arrays (any may be NULL). coefs[100][6] =
+ * sqrt(1-a_t), sqrt(a_t), sqrt(a_next), sigma_t, c1, c2. */
+int pdhip_ddnm_schedule(float* at, float* at_next, int* t, int* t_next, float* coefs);
+/* y = mask * (2*img - 1)   (diffusion.py:477-484). */
+int pdhip_ddnm_prepare(const float* masked_imgs /*[N,3,HW]*/, const float* masks /*[N,HW]*/, float* y, int N, int HW, void* stream);
+/* one fused update (diffusion.py:529-552), in place on x; eps NULL -> on-device Philox noise. */
+int pdhip_ddnm_step(float* x, const float* et, int et_channels, const float* y, const float* mask, const float* eps,
+                    uint64_t seed, int step, int N, int HW, void* stream);
+/* simplified_ddnm_inpainting for N images at once (the reference loops views serially at batch 1):
+ * masked_imgs[N,3,S,S] in [0,1], masks[N,S,S] (1 = keep), optional injected x_T[N,3,S,S] and eps_tape[n_steps,N,3,S,S];
+ * out[N,3,S,S] in [0,1]. */
+int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
+                      const float* eps_tape, uint64_t seed, int n_steps, float* out, void* stream);
+
+/* stand-alone operators of the engine (NHWC f16); also the unit-test surface of the kernels */
+int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed /*[Cout][taps*Cin] f16*/, void* stream);
+int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*Cin]*/, const float* bias, const void* residual,
+                          void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, const void* zero_page,
+                          void* stream);
+int pdhip_groupnorm_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film /*[N][2C] or NULL*/, int N,
+                             int H, int W, int C, int silu, int resample, void* y, float* stats_ws, float* ws,
+                             long long ws_floats, void* stream);
+int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim, void* stream);
+int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

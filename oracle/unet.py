@@ -1,0 +1,213 @@
+"""Row U1: the guided-diffusion UNet, restated functionally in plain torch fp32 on the CPU.
+(oracle -- test infrastructure)
+
+Follows /root/reference/models/DDNM/guided_diffusion/unet.py:396-664 (UNetModel), :143-256 (ResBlock with
+scale-shift norm and resblock up/down), :259-305 (AttentionBlock), :328-354 (QKVAttentionLegacy),
+:81-140 (Upsample nearest x2 / Downsample AvgPool2d(2)), nn.py:17-19 (GroupNorm32(32, C)), :103-121
+(timestep_embedding), script_util.py:130-185 (create_model: channel_mult by image size, attention_ds).
+Weights are a flat dict with the reference's state-dict key names, so the same dict loads into the imported
+reference module (tests do exactly that to pin this restatement) and into the HIP engine.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+
+def default_channel_mult(image_size):
+    return {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}[image_size]
+
+
+def make_config(image_size=256, num_channels=256, num_res_blocks=2, attention_resolutions="32,16,8",
+                num_head_channels=64, learn_sigma=True, channel_mult=None):
+    cm = tuple(channel_mult) if channel_mult else default_channel_mult(image_size)
+    ads = tuple(image_size // int(r) for r in attention_resolutions.split(","))
+    return dict(image_size=image_size, model_channels=num_channels, num_res_blocks=num_res_blocks, attention_ds=ads,
+                num_head_channels=num_head_channels, out_channels=6 if learn_sigma else 3, channel_mult=cm)
+
+
+def build_plan(cfg):
+    """List of blocks mirroring UNetModel.__init__ (unet.py:481-617).  Each entry:
+    ('conv_in', name, cin, cout) | ('res', name, cin, cout, mode) | ('attn', name, ch) with mode in
+    {'same','down','up'}; grouped as input_blocks / middle / output_blocks."""
+    mc = cfg['model_channels']
+    ch = int(cfg['channel_mult'][0] * mc)
+    inp = [[('conv_in', 'input_blocks.0.0', 3, ch)]]
+    chans = [ch]
+    ds = 1
+    n = 1
+    for level, mult in enumerate(cfg['channel_mult']):
+        for _ in range(cfg['num_res_blocks']):
+            out = int(mult * mc)
+            layers = [('res', f'input_blocks.{n}.0', ch, out, 'same')]
+            ch = out
+            if ds in cfg['attention_ds']:
+                layers.append(('attn', f'input_blocks.{n}.1', ch))
+            inp.append(layers)
+            chans.append(ch)
+            n += 1
+        if level != len(cfg['channel_mult']) - 1:
+            inp.append([('res', f'input_blocks.{n}.0', ch, ch, 'down')])
+            chans.append(ch)
+            ds *= 2
+            n += 1
+    mid = [('res', 'middle_block.0', ch, ch, 'same'), ('attn', 'middle_block.1', ch), ('res', 'middle_block.2', ch, ch, 'same')]
+    outb = []
+    n = 0
+    for level, mult in list(enumerate(cfg['channel_mult']))[::-1]:
+        for i in range(cfg['num_res_blocks'] + 1):
+            ich = chans.pop()
+            out = int(mc * mult)
+            layers = [('res', f'output_blocks.{n}.0', ch + ich, out, 'same')]
+            ch = out
+            k = 1
+            if ds in cfg['attention_ds']:
+                layers.append(('attn', f'output_blocks.{n}.{k}', ch))
+                k += 1
+            if level and i == cfg['num_res_blocks']:
+                layers.append(('res', f'output_blocks.{n}.{k}', ch, ch, 'up'))
+                ds //= 2
+            outb.append(layers)
+            n += 1
+    return dict(input=inp, middle=mid, output=outb, final_ch=ch)
+
+
+def param_shapes(cfg):
+    """name -> shape for every tensor of the reference state dict (566 tensors at the 256x256 config)."""
+    mc = cfg['model_channels']
+    ted = mc * 4
+    plan = build_plan(cfg)
+    shapes = {'time_embed.0.weight': (ted, mc), 'time_embed.0.bias': (ted,),
+              'time_embed.2.weight': (ted, ted), 'time_embed.2.bias': (ted,)}
+
+    def add(block):
+        kind, name = block[0], block[1]
+        if kind == 'conv_in':
+            shapes[name + '.weight'] = (block[3], block[2], 3, 3)
+            shapes[name + '.bias'] = (block[3],)
+        elif kind == 'res':
+            cin, cout = block[2], block[3]
+            shapes[name + '.in_layers.0.weight'] = (cin,)
+            shapes[name + '.in_layers.0.bias'] = (cin,)
+            shapes[name + '.in_layers.2.weight'] = (cout, cin, 3, 3)
+            shapes[name + '.in_layers.2.bias'] = (cout,)
+            shapes[name + '.emb_layers.1.weight'] = (2 * cout, ted)
+            shapes[name + '.emb_layers.1.bias'] = (2 * cout,)
+            shapes[name + '.out_layers.0.weight'] = (cout,)
+            shapes[name + '.out_layers.0.bias'] = (cout,)
+            shapes[name + '.out_layers.3.weight'] = (cout, cout, 3, 3)
+            shapes[name + '.out_layers.3.bias'] = (cout,)
+            if cin != cout:
+                shapes[name + '.skip_connection.weight'] = (cout, cin, 1, 1)
+                shapes[name + '.skip_connection.bias'] = (cout,)
+        else:
+            c = block[2]
+            shapes[name + '.norm.weight'] = (c,)
+            shapes[name + '.norm.bias'] = (c,)
+            shapes[name + '.qkv.weight'] = (3 * c, c, 1)
+            shapes[name + '.qkv.bias'] = (3 * c,)
+            shapes[name + '.proj_out.weight'] = (c, c, 1)
+            shapes[name + '.proj_out.bias'] = (c,)
+    for layers in plan['input'] + [plan['middle']] + plan['output']:
+        for b in layers:
+            add(b)
+    fc = plan['final_ch']
+    shapes['out.0.weight'] = (fc,)
+    shapes['out.0.bias'] = (fc,)
+    shapes['out.2.weight'] = (cfg['out_channels'], fc, 3, 3)
+    shapes['out.2.bias'] = (cfg['out_channels'],)
+    return shapes
+
+
+def random_weights(cfg, seed=0, std=0.02):
+    """Seeded stand-in for the absent checkpoint: conv/linear ~ N(0, std^2) scaled by fan-in so
+    activations stay O(1), GroupNorm affine (1 +- small, small), and the reference's zero-initialised layers
+    (out_layers.3, proj_out, out.2) re-randomised -- otherwise the net returns exact zeros."""
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+    for name, shp in param_shapes(cfg).items():
+        if len(shp) == 1:
+            is_norm_w = name.endswith('.weight') and ('.in_layers.0.' in name or '.out_layers.0.' in name or
+                                                      '.norm.' in name or name.startswith('out.0.'))
+            t = torch.randn(shp, generator=g) * 0.05
+            w[name] = (1.0 + t) if is_norm_w else t
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            w[name] = torch.randn(shp, generator=g) * (1.0 / math.sqrt(fan_in))
+    return w
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def _gn(x, w, name):
+    return F.group_norm(x.float(), 32, w[name + '.weight'], w[name + '.bias'], eps=1e-5)
+
+
+def _resblock(x, emb, w, name, cin, cout, mode):
+    h = F.silu(_gn(x, w, name + '.in_layers.0'))
+    if mode == 'down':
+        h = F.avg_pool2d(h, 2)
+        x = F.avg_pool2d(x, 2)
+    elif mode == 'up':
+        h = F.interpolate(h, scale_factor=2, mode='nearest')
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    h = F.conv2d(h, w[name + '.in_layers.2.weight'], w[name + '.in_layers.2.bias'], padding=1)
+    e = F.linear(F.silu(emb), w[name + '.emb_layers.1.weight'], w[name + '.emb_layers.1.bias'])[:, :, None, None]
+    scale, shift = torch.chunk(e, 2, dim=1)
+    h = _gn(h, w, name + '.out_layers.0') * (1 + scale) + shift
+    h = F.conv2d(F.silu(h), w[name + '.out_layers.3.weight'], w[name + '.out_layers.3.bias'], padding=1)
+    if cin != cout:
+        x = F.conv2d(x, w[name + '.skip_connection.weight'], w[name + '.skip_connection.bias'])
+    return x + h
+
+
+def _attention(x, w, name, head_ch):
+    b, c, H, W = x.shape
+    xf = x.reshape(b, c, -1)
+    qkv = F.conv1d(_gn(xf, w, name + '.norm'), w[name + '.qkv.weight'], w[name + '.qkv.bias'])
+    heads = c // head_ch
+    q, k, v = qkv.reshape(b * heads, head_ch * 3, -1).split(head_ch, dim=1)     # QKVAttentionLegacy
+    scale = 1 / math.sqrt(math.sqrt(head_ch))
+    weight = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    weight = torch.softmax(weight.float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", weight, v).reshape(b, -1, H * W)
+    h = F.conv1d(a, w[name + '.proj_out.weight'], w[name + '.proj_out.bias'])
+    return (xf + h).reshape(b, c, H, W)
+
+
+def forward(cfg, w, x, timesteps, plan=None, taps=None):
+    """UNetModel.forward (unet.py:635-664) in fp32.  x[N,3,S,S], timesteps[N] -> [N,out_channels,S,S].
+    `taps` (optional dict) receives intermediate activations by block name for per-block parity tests."""
+    plan = plan or build_plan(cfg)
+    mc = cfg['model_channels']
+    emb = F.linear(timestep_embedding(timesteps, mc), w['time_embed.0.weight'], w['time_embed.0.bias'])
+    emb = F.linear(F.silu(emb), w['time_embed.2.weight'], w['time_embed.2.bias'])
+
+    def run(layers, h):
+        for b in layers:
+            if b[0] == 'conv_in':
+                h = F.conv2d(h, w[b[1] + '.weight'], w[b[1] + '.bias'], padding=1)
+            elif b[0] == 'res':
+                h = _resblock(h, emb, w, b[1], b[2], b[3], b[4])
+            else:
+                h = _attention(h, w, b[1], cfg['num_head_channels'])
+            if taps is not None:
+                taps[b[1]] = h
+        return h
+    hs = []
+    h = x.float()
+    for layers in plan['input']:
+        h = run(layers, h)
+        hs.append(h)
+    h = run(plan['middle'], h)
+    for layers in plan['output']:
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = run(layers, h)
+    h = F.silu(_gn(h, w, 'out.0'))
+    return F.conv2d(h, w['out.2.weight'], w['out.2.bias'], padding=1)

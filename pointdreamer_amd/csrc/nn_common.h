@@ -1,0 +1,52 @@
+// Shared declarations of the UNet engine (row U1/D1) translation units.
+#pragma once
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace pdnn {
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+// ---- implicit-GEMM convolution (nn_gemm.hip)
+// X [N,H,W,Cin] f16 (NHWC), Wt [Cout_pad][TAPS*Cin] f16 (k = tap*Cin + c, tap = ky*3+kx; Cout_pad % 128 == 0),
+// bias f32 [Cout] (may be null), residual [N,H,W,Cout] f16 (may be null), Y [N,H,W,Cout] f16.
+// taps: 1 (1x1 conv / linear over pixels) or 9 (3x3, pad 1).  Cin % 32 == 0.
+int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
+               int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s);
+
+// ---- normalisation / elementwise (nn_norm.hip)
+// GroupNorm(32) statistics of X [N,HW,C] f16 -> stats [N][32][2] (mean, rstd) f32.  ws: N*chunks*32*2 floats.
+int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, float* ws, size_t ws_floats, hipStream_t s);
+// y = silu?( GN(x)*gamma+beta [*(1+scale)+shift] ), optional 2x resample; RESAMPLE: 0 none, 1 avgpool2, 2 nearest-up2.
+// film: rows of (scale[C] | shift[C]) f32, row n at film + n*film_stride, or null.  Output f16 NHWC (or f32 when out_f32).
+int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
+             long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s);
+int resample2x(const half_t* X, int N, int H, int W, int C, int mode, half_t* Y, hipStream_t s);
+int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long pixels, half_t* Y, hipStream_t s);
+
+// ---- attention (nn_attn.hip): QKVAttentionLegacy on qkv [N,T,3C] f16 (per head h: q|k|v at channel h*3*D), out [N,T,C].
+int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStream_t s);
+
+// ---- small dense ops (nn_misc.hip)
+int conv_in_3x3(const float* x_nchw, const half_t* Wt /*[Cout][27] k=(ky*3+kx)*3+c*/, const float* bias, half_t* Y, int N,
+                int H, int W, int Cout, hipStream_t s);
+int conv_out_3x3_f32(const float* X_nhwc, const float* Wt /*[Cout][9*Cin]*/, const float* bias, float* y_nchw, int N, int H,
+                     int W, int Cin, int Cout, hipStream_t s);
+int timestep_mlp(const float* t, int N, int mc, const float* w0, const float* b0, const float* w2, const float* b2,
+                 float* emb_silu /*[N][4mc] = silu(time_embed(t))*/, float* tmp, hipStream_t s);
+int gemv_rows(const float* Wm /*[R][K]*/, const float* b, const float* x /*[N][K]*/, float* y /*[N][R]*/, int R, int K, int N,
+              hipStream_t s);
+
+// ---- DDNM (nn_misc.hip)
+struct DdnmCoef { float sqrt_1m_at, sqrt_at, sqrt_at_next, sigma_t, c1, c2; };
+int ddnm_update(float* x /*[N,3,HW] in/out*/, const float* et /*[N,Cet,HW], first 3 used*/, int Cet, const float* y,
+                const float* mask /*[N,HW]*/, const float* eps /*null -> philox*/, unsigned long long seed,
+                unsigned long long step, DdnmCoef co, int N, int HW, hipStream_t s);
+int ddnm_prepare(const float* masked_img, const float* mask, float* y, int N, int HW, hipStream_t s);
+int ddnm_finish(const float* x, float* out, long long n, hipStream_t s);
+int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s);
+
+}  // namespace pdnn

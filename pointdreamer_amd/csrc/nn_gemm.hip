@@ -1,0 +1,187 @@
+// Row U1: implicit-GEMM convolution on the gfx950 matrix cores -- the dominant kernel of the DDNM path
+// (94.5 % of the UNet's 1 119.8 GMAC are 3x3 convolutions).  Replaces the cuDNN fp16
+// conv calls behind nn.Conv2d / nn.Conv1d(k=1) in models/DDNM/guided_diffusion/unet.py:143-305.
+//
+//   Y[m, n] = sum_k A[m, k] * Wt[n, k] + bias[n] (+ residual[m, n])
+//   m = (image, y, x) pixel, n = output channel, k = (tap, input channel), A gathered on the fly from the
+//   NHWC f16 activation with zero padding -- no im2col buffer.
+//
+// Structure (MI355X-first): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 each =
+// 4x4 v_mfma_f32_16x16x32_f16 accumulators), K-step 32, both operand tiles staged HBM->LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction), double-buffered; the LDS image
+// is lane-linear so the bank swizzle is applied on the per-lane SOURCE address and mirrored on the
+// ds_read_b128 side (cdna guide rule 21).  Out-of-image taps read a 16-byte zero page instead of branching.
+// Workgroup ids are remapped so that the n-tiles sharing one activation tile run back-to-back on one XCD (L2 reuse).
+// Epilogue: accumulators -> LDS transpose -> 16-byte coalesced NHWC stores with bias and residual fused.
+#include "nn_common.h"
+using namespace pdhip;
+namespace pdnn {
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define TILE_BYTES (BM * BK * 2)           // 8 KiB per operand tile
+#define STAGE_BYTES (2 * TILE_BYTES)
+#define CS_LD 136                          // epilogue tile leading dimension (halfs)
+#define SMEM_BYTES (BM * CS_LD * 2)        // 34 816 B >= 2 stages (32 768 B)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// 16-byte slot permutation inside a 64-byte tile row: slot = chunk ^ swz(row); conflict-free for the
+// ds_read_b128 lane groups (derivation in DESIGN.md "conv kernel": s = [0,2,3,1][(row >> 2) & 3]).
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
+                                                    const float* __restrict__ bias, const half_t* __restrict__ residual,
+                                                    half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
+                                                    int n_tiles, int total_tiles, const half_t* __restrict__ zero_page) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile id: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tile ids
+    int tile;
+    {
+        const int b = blockIdx.x, q = total_tiles >> 3, r = total_tiles & 7, xcd = b & 7, i = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    const long long M = (long long)N * H * W;
+    const int K = TAPS * Cin;
+    const int kc = Cin / BK;                 // K-steps per tap
+    const int KI = TAPS * kc;
+
+    // ---- loader role: this lane stages rows {wave*32 + i*16 + (lane>>2)}, 16-byte slot (lane&3) of each tile.
+    // Running source pointers: advanced by BK halfs per K-step, re-derived once per filter tap (uniform branch).
+    const int lrow = lane >> 2, lpos = lane & 3;
+    int py[2], pxx[2];
+    long long pbase[2];                      // element offset of (pixel, channel-chunk), or -1 for rows beyond M
+    const half_t* bp[2];
+    const half_t* ap[2];
+    int astep[2];
+    const long long zoff = zero_page - X;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 32 + i * 16 + lrow;
+        const int c = lpos ^ swz(r);
+        const long long m = (long long)m0 + r;
+        const bool inm = m < M;
+        const long long mm = inm ? m : 0;
+        const int img = (int)(mm / ((long long)H * W));
+        const int rem = (int)(mm - (long long)img * H * W);
+        py[i] = inm ? rem / W : -100000;
+        pxx[i] = rem - (rem / W) * W;
+        pbase[i] = (((long long)img * H + rem / W) * W + pxx[i]) * Cin + c * 8;
+        bp[i] = Wt + (size_t)(n0 + r) * K + c * 8;
+    }
+    auto set_tap = [&](int tap) {
+        const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int yy = py[i] + dy, xx = pxx[i] + dx;
+            const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+            const long long off = pbase[i] + ((long long)dy * W + dx) * Cin;
+            ap[i] = X + (ok ? off : zoff);
+            astep[i] = ok ? BK : 0;
+        }
+    };
+    char* const wave_dst = smem + (wave * 2) * 1024;
+    int ntap = 0, nc = 0;
+    set_tap(0);
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(ap[i], wave_dst + stage * STAGE_BYTES + i * 1024);
+            glds16(bp[i], wave_dst + stage * STAGE_BYTES + TILE_BYTES + i * 1024);
+            ap[i] += astep[i];
+            bp[i] += BK;
+        }
+        if (++nc == kc) {
+            nc = 0;
+            if (++ntap < TAPS) set_tap(ntap);
+        }
+    };
+
+    // ---- consumer role: fragment byte offset inside a 16-row group (row = lane&15, k-chunk = lane>>4)
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
+    float4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    int cur = 0;
+    for (int it = 0; it < KI; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // stage `cur` landed; everyone is done reading stage cur^1
+        if (it + 1 < KI) issue(cur ^ 1);
+        const char* As = smem + cur * STAGE_BYTES + (wm * 64) * 64 + frag_off;
+        const char* Bs = smem + cur * STAGE_BYTES + TILE_BYTES + (wn * 64) * 64 + frag_off;
+        half8 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        cur ^= 1;
+    }
+    __syncthreads();                                       // all fragment reads done before the tile is reused
+
+    // ---- epilogue: acc (+bias) -> f16 -> LDS [128][CS_LD] -> coalesced 16-byte rows (+residual)
+    half_t* Cs = reinterpret_cast<half_t*>(smem);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + (lane & 15);
+        const float bv = (bias != nullptr && n0 + nl < Cout) ? bias[n0 + nl] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(ml + r) * CS_LD + nl] = (half_t)(acc[i][j][r] + bv);
+        }
+    }
+    __syncthreads();
+    const int col8 = (tid & 15) * 8;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = p * 16 + (tid >> 4);
+        const long long m = (long long)m0 + row;
+        if (m < M && n0 + col8 < Cout) {
+            half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
+            const size_t o = (size_t)m * Cout + n0 + col8;
+            if (residual != nullptr) {
+                const half8 rv = *reinterpret_cast<const half8*>(residual + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<half8*>(Y + o) = v;
+        }
+    }
+}
+
+int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
+               int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s) {
+    PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
+    PD_REQUIRE(Cin % BK == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
+               "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
+    const long long M = (long long)N * H * W;
+    const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = Cout_pad / BN;
+    const int total = m_tiles * n_tiles;
+    if (taps == 9)
+        k_conv_igemm<9><<<total, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page);
+    else
+        k_conv_igemm<1><<<total, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+}  // namespace pdnn

@@ -1,0 +1,276 @@
+// Rows U1 / D1: the small dense ops around the conv torso and the fused DDNM update.
+//  * first conv 3->C (unet.py:483, f16) and the f32 output head conv C->6 (unet.py:613-617, stays f32);
+//  * timestep embedding + time_embed MLP (nn.py:103-121, unet.py:472-476) and the per-ResBlock
+//    emb_layers Linear (unet.py:199-205) as one batched GEMV over the concatenated weight rows (all f32);
+//  * DDNM masked-projection step (models/DDNM/guided_diffusion/diffusion.py:529-552) as ONE elementwise
+//    kernel (the reference runs ~15 torch kernels + randn_like + two host round trips per step), with
+//    either injected noise (parity tests) or on-device Philox4x32-10 + Box-Muller noise.
+#include "nn_common.h"
+using namespace pdhip;
+namespace pdnn {
+
+// ------------------------------------------------------------------------------------------------
+// conv_in: x f32 NCHW [N,3,H,W] -> (x.half()) conv3x3 -> Y f16 NHWC [N,H,W,Cout].  K = 27, weights in LDS.
+__global__ __launch_bounds__(256) void k_conv_in(const float* __restrict__ x, const half_t* __restrict__ Wt,
+                                                 const float* __restrict__ bias, half_t* __restrict__ Y, int H, int W,
+                                                 int Cout) {
+    extern __shared__ float s_w[];                 // [Cout][27] + bias [Cout]
+    for (int i = threadIdx.x; i < Cout * 27; i += blockDim.x) s_w[i] = (float)Wt[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) s_w[Cout * 27 + i] = bias[i];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const int opp = Cout >> 3;
+    const long long total = (long long)H * W * opp;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int oc = (int)(idx % opp);
+        const int p = (int)(idx / opp);
+        const int y = p / W, xx = p - y * W;
+        float in[27];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y + ky - 1, xc = xx + kx - 1;
+                const bool ok = yy >= 0 && yy < H && xc >= 0 && xc < W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    in[(ky * 3 + kx) * 3 + c] = ok ? (float)(half_t)x[(((size_t)n * 3 + c) * H + yy) * W + xc] : 0.f;
+            }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = oc * 8 + e;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) a += in[k] * s_w[co * 27 + k];
+            o[e] = (half_t)(a + s_w[Cout * 27 + co]);
+        }
+        *reinterpret_cast<half8*>(Y + ((size_t)n * H * W + p) * Cout + oc * 8) = o;
+    }
+}
+
+int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t* Y, int N, int H, int W, int Cout,
+                hipStream_t s) {
+    PD_REQUIRE(Cout % 8 == 0 && Cout <= 1024, "conv_in_3x3: bad Cout %d", Cout);
+    dim3 g((unsigned)std::min<long long>(((long long)H * W * (Cout / 8) + 255) / 256, 4096), N);
+    k_conv_in<<<g, 256, (size_t)Cout * 28 * sizeof(float), s>>>(x_nchw, Wt, bias, Y, H, W, Cout);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_out: X f32 NHWC [N,H,W,Cin] -> conv3x3 (f32 weights [Cout][9*Cin], k = tap*Cin + c) -> y f32 NCHW.
+// One wave per output pixel: lanes split the 9*Cin reduction (coalesced 256-B reads), shuffle-reduce per output.
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv_out(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                  const float* __restrict__ bias, float* __restrict__ y, int H, int W, int Cin,
+                                                  long long pixels) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long p = wave; p < pixels; p += nwaves) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        const long long n = p / ((long long)W * H);
+        float acc[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            const float* src = X + (((size_t)n * H + sy) * W + sx) * Cin;
+            for (int c = lane; c < Cin; c += 64) {
+                const float v = src[c];
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) acc[o] += v * Wt[(size_t)o * 9 * Cin + (size_t)tap * Cin + c];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float a = acc[o];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            if (lane == 0) y[(((size_t)n * COUT + o) * H + yy) * W + xx] = a + bias[o];
+        }
+    }
+}
+
+int conv_out_3x3_f32(const float* X_nhwc, const float* Wt, const float* bias, float* y_nchw, int N, int H, int W, int Cin,
+                     int Cout, hipStream_t s) {
+    PD_REQUIRE(Cout == 6 || Cout == 3, "conv_out_3x3_f32: Cout must be 3 or 6");
+    const long long pixels = (long long)N * H * W;
+    const int grid = (int)std::min<long long>((pixels + 3) / 4, 16384);
+    if (Cout == 6) k_conv_out<6><<<grid, 256, 0, s>>>(X_nhwc, Wt, bias, y_nchw, H, W, Cin, pixels);
+    else k_conv_out<3><<<grid, 256, 0, s>>>(X_nhwc, Wt, bias, y_nchw, H, W, Cin, pixels);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[n][r] = b[r] + sum_k W[r][k] x[n][k]   (one wave per output row r, all batch entries), f32.
+__global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm, const float* __restrict__ b,
+                                                   const float* __restrict__ x, float* __restrict__ y, int R, int K, int N,
+                                                   int silu_out) {
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= R) return;
+    for (int n0 = 0; n0 < N; n0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float w = Wm[(size_t)r * K + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (n0 + j < N) acc[j] += w * x[(size_t)(n0 + j) * K + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = acc[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            if (lane == 0 && n0 + j < N) {
+                a += b[r];
+                if (silu_out) a = a / (1.0f + expf(-a));
+                y[(size_t)(n0 + j) * R + r] = a;
+            }
+        }
+    }
+}
+
+static int gemv_launch(const float* Wm, const float* b, const float* x, float* y, int R, int K, int N, int silu_out, hipStream_t s) {
+    k_gemv_rows<<<cdiv((long long)R * 64, 256), 256, 0, s>>>(Wm, b, x, y, R, K, N, silu_out);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+int gemv_rows(const float* Wm, const float* b, const float* x, float* y, int R, int K, int N, hipStream_t s) {
+    return gemv_launch(Wm, b, x, y, R, K, N, 0, s);
+}
+
+__global__ void k_timestep_embedding(const float* __restrict__ t, int N, int mc, float* __restrict__ e) {
+    const int half = mc / 2;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N * half; idx += gridDim.x * blockDim.x) {
+        const int n = idx / half, i = idx - n * half;
+        const float freq = expf(-logf(10000.0f) * (float)i / (float)half);
+        const float a = t[n] * freq;
+        e[(size_t)n * mc + i] = cosf(a);
+        e[(size_t)n * mc + half + i] = sinf(a);
+    }
+}
+
+// emb_silu = silu( W2 silu(W0 temb + b0) + b2 )  -- every ResBlock applies SiLU to emb before its Linear.
+int timestep_mlp(const float* t, int N, int mc, const float* w0, const float* b0, const float* w2, const float* b2,
+                 float* emb_silu, float* tmp, hipStream_t s) {
+    float* temb = tmp;                        // [N][mc]
+    float* h1 = tmp + (size_t)N * mc;         // [N][4mc]
+    k_timestep_embedding<<<cdiv((long long)N * mc / 2, 256), 256, 0, s>>>(t, N, mc, temb);
+    int rc = gemv_launch(w0, b0, temb, h1, 4 * mc, mc, N, 1, s);
+    if (rc) return rc;
+    return gemv_launch(w2, b2, h1, emb_silu, 4 * mc, 4 * mc, N, 1, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG + Box-Muller: stateless N(0,1) stream (seed, stream id, element index).
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ void normal4(unsigned long long seed, unsigned long long stream_id, unsigned long long quad, float out[4]) {
+    uint32_t c[4] = {(uint32_t)quad, (uint32_t)(quad >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u0 = ((float)c[0] + 0.5f) * 2.3283064365386963e-10f, u1 = ((float)c[1] + 0.5f) * 2.3283064365386963e-10f;
+    const float u2 = ((float)c[2] + 0.5f) * 2.3283064365386963e-10f, u3 = ((float)c[3] + 0.5f) * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    out[0] = r0 * cosf(6.283185307179586f * u1); out[1] = r0 * sinf(6.283185307179586f * u1);
+    out[2] = r1 * cosf(6.283185307179586f * u3); out[3] = r1 * sinf(6.283185307179586f * u3);
+}
+
+__global__ void k_philox_normal(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long stream_id) {
+    const long long quads = (n + 3) / 4;
+    for (long long qd = blockIdx.x * (long long)blockDim.x + threadIdx.x; qd < quads; qd += (long long)gridDim.x * blockDim.x) {
+        float z[4];
+        normal4(seed, stream_id, (unsigned long long)qd, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (qd * 4 + e < n) out[qd * 4 + e] = z[e];
+    }
+}
+
+int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s) {
+    k_philox_normal<<<(int)std::min<long long>(((n + 3) / 4 + 255) / 256, 4096), 256, 0, s>>>(out, n, seed, stream_id);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// D1.  y = mask * (2 img - 1);  step: x0 = (x - e sqrt(1-a_t))/sqrt(a_t); x0h = x0 - m (m x0 - y);
+//      x' = sqrt(a_next) x0h + sigma_t (c1 eps + c2 e);  finish: clamp((x+1)/2, 0, 1).
+__global__ void k_ddnm_prepare(const float* __restrict__ img, const float* __restrict__ mask, float* __restrict__ y, int HW,
+                               long long total) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / (3LL * HW);
+        const int p = (int)(i % HW);
+        y[i] = (2.0f * img[i] - 1.0f) * mask[n * HW + p];
+    }
+}
+int ddnm_prepare(const float* masked_img, const float* mask, float* y, int N, int HW, hipStream_t s) {
+    const long long total = (long long)N * 3 * HW;
+    k_ddnm_prepare<<<(int)std::min<long long>((total + 255) / 256, 4096), 256, 0, s>>>(masked_img, mask, y, HW, total);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+__global__ void k_ddnm_update(float* __restrict__ x, const float* __restrict__ et, int Cet, const float* __restrict__ y,
+                              const float* __restrict__ mask, const float* __restrict__ eps, unsigned long long seed,
+                              unsigned long long step, DdnmCoef co, int HW, long long total) {
+    // one thread = 4 consecutive elements (HW % 4 == 0), so one Philox call feeds it
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q * 4 < total; q += (long long)gridDim.x * blockDim.x) {
+        const long long i = q * 4;
+        const long long n = i / (3LL * HW);
+        const int c = (int)((i / HW) % 3);
+        const int p = (int)(i % HW);
+        float z[4];
+        if (eps) { const float4 e4 = *reinterpret_cast<const float4*>(eps + i); z[0] = e4.x; z[1] = e4.y; z[2] = e4.z; z[3] = e4.w; }
+        else normal4(seed, step, (unsigned long long)q, z);
+        const float4 x4 = *reinterpret_cast<const float4*>(x + i);
+        const float4 e4 = *reinterpret_cast<const float4*>(et + ((size_t)n * Cet + c) * HW + p);
+        const float4 y4 = *reinterpret_cast<const float4*>(y + i);
+        const float4 m4 = *reinterpret_cast<const float4*>(mask + n * HW + p);
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, ev[4] = {e4.x, e4.y, e4.z, e4.w};
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float x0 = (xv[k] - ev[k] * co.sqrt_1m_at) / co.sqrt_at;
+            const float x0h = x0 - mv[k] * (mv[k] * x0 - yv[k]);
+            o[k] = co.sqrt_at_next * x0h + co.sigma_t * (co.c1 * z[k] + co.c2 * ev[k]);
+        }
+        *reinterpret_cast<float4*>(x + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+int ddnm_update(float* x, const float* et, int Cet, const float* y, const float* mask, const float* eps,
+                unsigned long long seed, unsigned long long step, DdnmCoef co, int N, int HW, hipStream_t s) {
+    PD_REQUIRE(HW % 4 == 0, "ddnm_update: H*W must be a multiple of 4");
+    const long long total = (long long)N * 3 * HW;
+    k_ddnm_update<<<(int)std::min<long long>((total / 4 + 255) / 256, 4096), 256, 0, s>>>(x, et, Cet, y, mask, eps, seed, step, co,
+                                                                                       HW, total);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+__global__ void k_ddnm_finish(const float* __restrict__ x, float* __restrict__ out, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
+}
+int ddnm_finish(const float* x, float* out, long long n, hipStream_t s) {
+    k_ddnm_finish<<<(int)std::min<long long>((n + 255) / 256, 4096), 256, 0, s>>>(x, out, n);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+}  // namespace pdnn

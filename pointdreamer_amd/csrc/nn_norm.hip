@@ -1,0 +1,221 @@
+// Row U1: GroupNorm32 statistics / apply (+SiLU, FiLM scale-shift, 2x resample), channel concat.
+// Replaces nn.GroupNorm (GroupNorm32, nn.py:17-19), nn.SiLU, the scale-shift conditioning of
+// ResBlock._forward (unet.py:248-252), Upsample/Downsample without conv (unet.py:100-140) and th.cat
+// (unet.py:661).  All HBM-bound streaming kernels over NHWC f16 with 16-byte accesses.
+// Rounding points follow the reference's fp16 torso: GN output -> f16, each FiLM op -> f16, SiLU -> f16.
+#include "nn_common.h"
+using namespace pdhip;
+namespace pdnn {
+
+#define GN_PIX_PER_BLOCK 256
+
+// partial sums: grid (chunks, N); each block covers GN_PIX_PER_BLOCK pixels x all channels.
+// thread -> (pixel sub-slot, channel octet); deterministic two-level reduction (no float atomics).
+__global__ __launch_bounds__(256) void k_gn_partial(const half_t* __restrict__ X, int HW, int C, float* __restrict__ part) {
+    extern __shared__ float s_acc[];                 // [pps][C][2]
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int opp = C >> 3;                          // octets per pixel
+    const int pps = max(1, 256 / opp);               // pixel sub-slots handled concurrently
+    const int tid = threadIdx.x;
+    const int sub = tid / opp, oct = tid - sub * opp;
+    const int p0 = chunk * GN_PIX_PER_BLOCK;
+    const int p1 = min(HW, p0 + GN_PIX_PER_BLOCK);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (sub < pps) {
+        for (int oc = oct; oc < opp; oc += 256) {    // opp > 256 only when C > 2048 (not in this net); keeps it general
+            for (int p = p0 + sub; p < p1; p += pps) {
+                const half8 v = *reinterpret_cast<const half8*>(X + ((size_t)n * HW + p) * C + oc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s_acc[((size_t)sub * C + oc * 8 + e) * 2] = s[e];
+                s_acc[((size_t)sub * C + oc * 8 + e) * 2 + 1] = q[e];
+                s[e] = 0.f; q[e] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {                                   // one thread per group, fixed summation order
+        const int cg = C / 32;
+        double ds = 0.0, dq = 0.0;
+        for (int sb = 0; sb < pps; ++sb)
+            for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+                ds += (double)s_acc[((size_t)sb * C + c) * 2];
+                dq += (double)s_acc[((size_t)sb * C + c) * 2 + 1];
+            }
+        float* o = part + (((size_t)n * gridDim.x + chunk) * 32 + tid) * 2;
+        o[0] = (float)ds; o[1] = (float)dq;
+    }
+}
+
+__global__ void k_gn_finalize(const float* __restrict__ part, int chunks, int HW, int C, float eps, float* __restrict__ stats) {
+    const int n = blockIdx.x, g = threadIdx.x;
+    if (g >= 32) return;
+    double ds = 0.0, dq = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        ds += (double)part[(((size_t)n * chunks + c) * 32 + g) * 2];
+        dq += (double)part[(((size_t)n * chunks + c) * 32 + g) * 2 + 1];
+    }
+    const double cnt = (double)HW * (C / 32);
+    const double mean = ds / cnt;
+    double var = dq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((size_t)n * 32 + g) * 2] = (float)mean;
+    stats[((size_t)n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, float* ws, size_t ws_floats, hipStream_t s) {
+    PD_REQUIRE(C % 32 == 0, "gn_stats: C %% 32 != 0 (C=%d)", C);
+    const int chunks = cdiv(HW, GN_PIX_PER_BLOCK);
+    PD_REQUIRE((size_t)N * chunks * 64 <= ws_floats, "gn_stats: workspace too small");
+    const int opp = C >> 3;
+    const int pps = max(1, 256 / opp);
+    const size_t smem = (size_t)pps * C * 2 * sizeof(float);
+    PD_REQUIRE(smem <= 64 * 1024, "gn_stats: C too large (%d)", C);
+    dim3 g(chunks, N);
+    k_gn_partial<<<g, 256, smem, s>>>(X, HW, C, ws);
+    k_gn_finalize<<<N, 32, 0, s>>>(ws, chunks, HW, C, eps, stats);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// one thread = one output pixel's channel octet.  RES: 0 none, 1 avgpool2 (of activated values), 2 nearest-up2.
+template <int RES, bool OUT_F32>
+__global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, const float* __restrict__ stats,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ film, long long film_stride, int H, int W,
+                                                  int C, int silu, void* __restrict__ Yv, long long total_oct) {
+    const int opp = C >> 3, cg = C / 32;
+    const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_oct; idx += (long long)gridDim.x * blockDim.x) {
+        const int oc = (int)(idx % opp);
+        const long long pix = idx / opp;
+        const int xo = (int)(pix % Wo);
+        const int yo = (int)((pix / Wo) % Ho);
+        const int n = (int)(pix / ((long long)Wo * Ho));
+        const int c0 = oc * 8;
+        float g8[8], b8[8], mean[8], rstd[8], sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e, grp = c / cg;
+            g8[e] = gamma[c]; b8[e] = beta[c];
+            mean[e] = stats[((size_t)n * 32 + grp) * 2];
+            rstd[e] = stats[((size_t)n * 32 + grp) * 2 + 1];
+            if (film) { sc[e] = film[(size_t)n * film_stride + c]; sh[e] = film[(size_t)n * film_stride + C + c]; }
+        }
+        auto act = [&](int yi, int xi, float* o) {
+            const half8 v = *reinterpret_cast<const half8*>(X + (((size_t)n * H + yi) * W + xi) * C + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = ((float)v[e] - mean[e]) * rstd[e] * g8[e] + b8[e];
+                if (!OUT_F32) f = (float)(half_t)f;                          // GroupNorm32 returns x.dtype (f16)
+                if (film) {
+                    const float t1 = (float)(half_t)(1.0f + (float)(half_t)sc[e]);
+                    f = (float)(half_t)(f * t1);
+                    f = (float)(half_t)(f + (float)(half_t)sh[e]);
+                }
+                if (silu) { f = silu_f(f); if (!OUT_F32) f = (float)(half_t)f; }
+                o[e] = f;
+            }
+        };
+        float r[8];
+        if (RES == 1) {
+            float a[8], b[8], c[8], d[8];
+            act(2 * yo, 2 * xo, a); act(2 * yo, 2 * xo + 1, b); act(2 * yo + 1, 2 * xo, c); act(2 * yo + 1, 2 * xo + 1, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (a[e] + b[e] + c[e] + d[e]) * 0.25f;
+        } else if (RES == 2) {
+            act(yo >> 1, xo >> 1, r);
+        } else {
+            act(yo, xo, r);
+        }
+        const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * C + c0;
+        if (OUT_F32) {
+            float* Y = reinterpret_cast<float*>(Yv);
+            *reinterpret_cast<float4*>(Y + o) = make_float4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<float4*>(Y + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+        } else {
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)r[e];
+            *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(Yv) + o) = hv;
+        }
+    }
+}
+
+int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
+             long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s) {
+    PD_REQUIRE(C % 32 == 0 && resample >= 0 && resample <= 2, "gn_apply: bad arguments");
+    PD_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avgpool needs even H, W");
+    PD_REQUIRE(!out_f32 || resample == 0, "gn_apply: f32 output only without resampling");
+    const int Ho = resample == 1 ? H / 2 : (resample == 2 ? H * 2 : H), Wo = resample == 1 ? W / 2 : (resample == 2 ? W * 2 : W);
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 65536);
+    if (out_f32) k_gn_apply<0, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
+    else if (resample == 0) k_gn_apply<0, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
+    else if (resample == 1) k_gn_apply<1, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
+    else k_gn_apply<2, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// x_upd of up/down ResBlocks: plain AvgPool2d(2) (mode 1) or nearest x2 (mode 2) on the raw activation
+__global__ __launch_bounds__(256) void k_resample(const half_t* __restrict__ X, int H, int W, int C, int mode,
+                                                  half_t* __restrict__ Y, long long total_oct) {
+    const int opp = C >> 3;
+    const int Ho = mode == 1 ? H / 2 : H * 2, Wo = mode == 1 ? W / 2 : W * 2;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_oct; idx += (long long)gridDim.x * blockDim.x) {
+        const int oc = (int)(idx % opp);
+        const long long pix = idx / opp;
+        const int xo = (int)(pix % Wo), yo = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+        half8 out;
+        if (mode == 1) {
+            const half_t* p = X + (((size_t)n * H + 2 * yo) * W + 2 * xo) * C + oc * 8;
+            const half8 a = *reinterpret_cast<const half8*>(p), b = *reinterpret_cast<const half8*>(p + C);
+            const half8 c = *reinterpret_cast<const half8*>(p + (size_t)W * C), d = *reinterpret_cast<const half8*>(p + (size_t)W * C + C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (half_t)(((float)a[e] + (float)b[e] + (float)c[e] + (float)d[e]) * 0.25f);
+        } else {
+            out = *reinterpret_cast<const half8*>(X + (((size_t)n * H + (yo >> 1)) * W + (xo >> 1)) * C + oc * 8);
+        }
+        *reinterpret_cast<half8*>(Y + (((size_t)n * Ho + yo) * Wo + xo) * C + oc * 8) = out;
+    }
+}
+
+int resample2x(const half_t* X, int N, int H, int W, int C, int mode, half_t* Y, hipStream_t s) {
+    PD_REQUIRE((mode == 1 || mode == 2) && C % 8 == 0, "resample2x: bad arguments");
+    const int Ho = mode == 1 ? H / 2 : H * 2, Wo = mode == 1 ? W / 2 : W * 2;
+    const long long total = (long long)N * Ho * Wo * (C / 8);
+    k_resample<<<(int)std::min<long long>((total + 255) / 256, 65536), 256, 0, s>>>(X, H, W, C, mode, Y, total);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_concat(const half_t* __restrict__ A, int Ca, const half_t* __restrict__ B, int Cb,
+                                                long long pixels, half_t* __restrict__ Y) {
+    const int oa = Ca >> 3, ob = Cb >> 3, ot = oa + ob;
+    const long long total = pixels * ot;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long p = idx / ot;
+        const int o = (int)(idx - p * ot);
+        const half8 v = (o < oa) ? *reinterpret_cast<const half8*>(A + (size_t)p * Ca + o * 8)
+                                 : *reinterpret_cast<const half8*>(B + (size_t)p * Cb + (o - oa) * 8);
+        *reinterpret_cast<half8*>(Y + (size_t)p * (Ca + Cb) + o * 8) = v;
+    }
+}
+
+int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long pixels, half_t* Y, hipStream_t s) {
+    PD_REQUIRE(Ca % 8 == 0 && Cb % 8 == 0, "concat_channels: channels must be multiples of 8");
+    const long long total = pixels * ((Ca + Cb) / 8);
+    k_concat<<<(int)std::min<long long>((total + 255) / 256, 65536), 256, 0, s>>>(A, Ca, B, Cb, pixels, Y);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+}  // namespace pdnn

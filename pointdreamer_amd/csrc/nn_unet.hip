@@ -1,0 +1,632 @@
+// Rows U1 + D1: the guided-diffusion UNet engine and the DDNM sampler behind the C ABI.
+// Graph construction mirrors UNetModel.__init__ (models/DDNM/guided_diffusion/unet.py:481-617) as configured
+// by script_util.create_model (:130-185); weights are loaded under the reference's state-dict names
+// (`input_blocks.N.M.in_layers.2.weight`, ...) and repacked on the device into the kernels' layouts:
+//   conv3x3 / conv1x1 / conv1d(k=1) weights -> f16 [Cout_pad][taps*Cin] (k = tap*Cin + c), biases f16-rounded f32,
+//   time_embed / emb_layers Linear and all GroupNorm affine and the `out` head stay f32 (fp16_util.py:15-22).
+// Activations are NHWC f16 in a bump arena sized at create() for max_batch (288 GB HBM: no reuse games);
+// every forward issues the same launches at the same addresses, asynchronously on the caller's stream.
+#include "nn_common.h"
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+using namespace pdhip;
+using namespace pdnn;
+
+namespace {
+
+struct ConvW { half_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, cout_pad = 0, taps = 0; bool have_w = false, have_b = false; };
+struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; bool have_g = false, have_b = false; };
+struct ResB { std::string name; int cin, cout, mode; NormW n1, n2; ConvW c1, c2, skip; long long emb_off; bool has_skip; bool have_ew = false, have_eb = false; };
+struct AttB { std::string name; int c; NormW n; ConvW qkv, proj; };
+struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
+
+struct Act { half_t* p; int C, H, W; };
+
+struct Prof { std::vector<hipEvent_t> ev; size_t used = 0; double flops = 0; bool on = false; };
+
+}  // namespace
+
+struct pdhip_unet {
+    int image_size, mc, nres, head, out_ch, max_batch, ted;
+    std::vector<int> mult, att_ds;
+    std::vector<ResB> res;
+    std::vector<AttB> att;
+    std::vector<std::vector<Block>> input, output;
+    std::vector<Block> middle;
+    int final_ch;
+    // parameters
+    half_t* w_in = nullptr; float* b_in = nullptr; bool have_win = false, have_bin = false;
+    float *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr; bool have_te[4] = {false, false, false, false};
+    float *emb_w = nullptr, *emb_b = nullptr; long long emb_rows = 0;
+    NormW out_norm; float* out_w = nullptr; float* out_b = nullptr; bool have_ow = false, have_ob = false;
+    half_t* zero_page = nullptr;
+    // workspace
+    char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+    float *stats = nullptr, *gn_ws = nullptr; size_t gn_ws_floats = 0;
+    float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr, *head_in = nullptr;
+    float *t_dev = nullptr;
+    // sampler state
+    float *sx = nullptr, *sy = nullptr, *set_ = nullptr, *smask = nullptr;
+    Prof prof;
+    std::vector<void*> owned;
+};
+
+namespace {
+
+template <typename T>
+int dalloc(pdhip_unet* u, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(T), 256));
+    if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); return PDHIP_E_NOMEM; }
+    u->owned.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return PDHIP_OK;
+}
+#define PD_TRY(expr) do { int rc_ = (expr); if (rc_ != PDHIP_OK) return rc_; } while (0)
+
+int alloc_conv(pdhip_unet* u, ConvW& c, int cin, int cout, int taps) {
+    c.cin = cin; c.cout = cout; c.taps = taps; c.cout_pad = ((cout + 127) / 128) * 128;
+    PD_TRY(dalloc(u, &c.w, (size_t)c.cout_pad * taps * cin));
+    PD_HIP(hipMemset(c.w, 0, (size_t)c.cout_pad * taps * cin * sizeof(half_t)));
+    PD_TRY(dalloc(u, &c.b, (size_t)cout));
+    return PDHIP_OK;
+}
+int alloc_norm(pdhip_unet* u, NormW& n, int c) {
+    n.c = c;
+    PD_TRY(dalloc(u, &n.g, (size_t)c));
+    PD_TRY(dalloc(u, &n.b, (size_t)c));
+    return PDHIP_OK;
+}
+
+// ---- weight repack kernels
+__global__ void k_pack_conv(const void* __restrict__ src, int src_f16, int Cout, int Cin, int taps, half_t* __restrict__ dst) {
+    // src [Cout][Cin][taps] (PyTorch OIHW flattened) -> dst [Cout][taps*Cin], k = tap*Cin + c
+    const long long total = (long long)Cout * Cin * taps;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int c = (int)((i / taps) % Cin);
+        const int o = (int)(i / ((long long)taps * Cin));
+        const float v = src_f16 ? (float)reinterpret_cast<const half_t*>(src)[i] : reinterpret_cast<const float*>(src)[i];
+        dst[(size_t)o * taps * Cin + (size_t)tap * Cin + c] = (half_t)v;
+    }
+}
+__global__ void k_pack_conv_f32(const void* __restrict__ src, int src_f16, int Cout, int Cin, int taps, float* __restrict__ dst) {
+    const long long total = (long long)Cout * Cin * taps;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int c = (int)((i / taps) % Cin);
+        const int o = (int)(i / ((long long)taps * Cin));
+        const float v = src_f16 ? (float)reinterpret_cast<const half_t*>(src)[i] : reinterpret_cast<const float*>(src)[i];
+        dst[(size_t)o * taps * Cin + (size_t)tap * Cin + c] = v;
+    }
+}
+__global__ void k_copy_f32(const void* __restrict__ src, int src_f16, long long n, float* __restrict__ dst, int round_f16) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = src_f16 ? (float)reinterpret_cast<const half_t*>(src)[i] : reinterpret_cast<const float*>(src)[i];
+        if (round_f16) v = (float)(half_t)v;
+        dst[i] = v;
+    }
+}
+int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 4096); }
+
+// ---- arena
+half_t* arena_take(pdhip_unet* u, size_t halfs) {
+    size_t bytes = (halfs * sizeof(half_t) + 255) & ~(size_t)255;
+    if (u->arena == nullptr) { u->arena_off += bytes; return nullptr; }      // dry run (sizing)
+    half_t* p = reinterpret_cast<half_t*>(u->arena + u->arena_off);
+    u->arena_off += bytes;
+    return p;
+}
+
+struct Ctx { pdhip_unet* u; int N; hipStream_t s; bool dry; };
+
+int prof_begin(Ctx& c, double flops) {
+    Prof& p = c.u->prof;
+    if (!p.on || c.dry) return PDHIP_OK;
+    if (p.used + 2 > p.ev.size()) {
+        for (int i = 0; i < 256; ++i) { hipEvent_t e; PD_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
+    }
+    PD_HIP(hipEventRecord(p.ev[p.used], c.s));
+    p.flops += flops;
+    return PDHIP_OK;
+}
+int prof_end(Ctx& c) {
+    Prof& p = c.u->prof;
+    if (!p.on || c.dry) return PDHIP_OK;
+    PD_HIP(hipEventRecord(p.ev[p.used + 1], c.s));
+    p.used += 2;
+    return PDHIP_OK;
+}
+
+int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out) {
+    out->C = w.cout; out->H = x.H; out->W = x.W;
+    out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
+    if (c.dry) return PDHIP_OK;
+    PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
+    if (w.taps == 9) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
+    int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s);
+    if (w.taps == 9) PD_TRY(prof_end(c));
+    return rc;
+}
+
+int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, int silu, int resample, Act* out) {
+    out->C = x.C;
+    out->H = resample == 1 ? x.H / 2 : (resample == 2 ? x.H * 2 : x.H);
+    out->W = resample == 1 ? x.W / 2 : (resample == 2 ? x.W * 2 : x.W);
+    out->p = arena_take(c.u, (size_t)c.N * out->H * out->W * x.C);
+    if (c.dry) return PDHIP_OK;
+    PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
+    PD_TRY(gn_stats(x.p, c.N, x.H * x.W, x.C, 1e-5f, c.u->stats, c.u->gn_ws, c.u->gn_ws_floats, c.s));
+    return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s);
+}
+
+int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
+    Act h0, h1, h2, xr = x, sk;
+    PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, rb.mode, &h0));
+    if (rb.mode != 0) {
+        xr.H = h0.H; xr.W = h0.W;
+        xr.p = arena_take(c.u, (size_t)c.N * xr.H * xr.W * x.C);
+        if (!c.dry) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
+    }
+    PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1));
+    const float* film = c.dry ? nullptr : c.u->emb_all + rb.emb_off;
+    if (!c.dry) PD_REQUIRE(rb.have_ew && rb.have_eb, "unet: emb_layers of %s not loaded", rb.name.c_str());
+    PD_TRY(run_gn(c, h1, rb.n2, film, c.u->emb_rows, 1, 0, &h2));
+    sk = xr;
+    if (rb.has_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
+    return run_conv(c, h2, rb.c2, sk.p, out);
+}
+
+int run_att(Ctx& c, const Act& x, AttB& ab, Act* out) {
+    Act xn, qkv, a;
+    PD_TRY(run_gn(c, x, ab.n, nullptr, 0, 0, 0, &xn));
+    PD_TRY(run_conv(c, xn, ab.qkv, nullptr, &qkv));
+    a = x;
+    a.p = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);
+    if (!c.dry) PD_TRY(attention(qkv.p, a.p, c.N, x.H * x.W, x.C, c.u->head, c.s));
+    return run_conv(c, a, ab.proj, x.p, out);
+}
+
+int run_blocks(Ctx& c, std::vector<Block>& blocks, Act* h, const float* x_nchw) {
+    for (Block& b : blocks) {
+        Act o;
+        if (b.kind == 0) {
+            o.C = c.u->mult[0] * c.u->mc; o.H = o.W = c.u->image_size;
+            o.p = arena_take(c.u, (size_t)c.N * o.H * o.W * o.C);
+            if (!c.dry) {
+                PD_REQUIRE(c.u->have_win && c.u->have_bin, "unet: input conv not loaded");
+                PD_TRY(conv_in_3x3(x_nchw, c.u->w_in, c.u->b_in, o.p, c.N, o.H, o.W, o.C, c.s));
+            }
+        } else if (b.kind == 1) {
+            PD_TRY(run_res(c, *h, c.u->res[b.idx], &o));
+        } else {
+            PD_TRY(run_att(c, *h, c.u->att[b.idx], &o));
+        }
+        *h = o;
+    }
+    return PDHIP_OK;
+}
+
+// the whole forward; dry = sizing pass (no launches)
+int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* out, hipStream_t s, bool dry) {
+    Ctx c{u, N, s, dry};
+    u->arena_off = 0;
+    if (!dry) {
+        PD_REQUIRE(u->have_te[0] && u->have_te[1] && u->have_te[2] && u->have_te[3], "unet: time_embed not loaded");
+        PD_TRY(timestep_mlp(t, N, u->mc, u->te_w0, u->te_b0, u->te_w2, u->te_b2, u->emb_silu, u->emb_tmp, s));
+        PD_TRY(gemv_rows(u->emb_w, u->emb_b, u->emb_silu, u->emb_all, (int)u->emb_rows, u->ted, N, s));
+    }
+    std::vector<Act> hs;
+    Act h{nullptr, 0, 0, 0};
+    for (auto& blk : u->input) {
+        PD_TRY(run_blocks(c, blk, &h, x));
+        hs.push_back(h);
+    }
+    PD_TRY(run_blocks(c, u->middle, &h, x));
+    for (auto& blk : u->output) {
+        Act sk = hs.back(); hs.pop_back();
+        Act cat{arena_take(u, (size_t)N * h.H * h.W * (h.C + sk.C)), h.C + sk.C, h.H, h.W};
+        if (!dry) PD_TRY(concat_channels(h.p, h.C, sk.p, sk.C, (long long)N * h.H * h.W, cat.p, s));
+        h = cat;
+        PD_TRY(run_blocks(c, blk, &h, x));
+    }
+    if (!dry) {
+        PD_REQUIRE(u->out_norm.have_g && u->out_norm.have_b && u->have_ow && u->have_ob, "unet: output head not loaded");
+        PD_TRY(gn_stats(h.p, N, h.H * h.W, h.C, 1e-5f, u->stats, u->gn_ws, u->gn_ws_floats, s));
+        PD_TRY(gn_apply(h.p, u->stats, u->out_norm.g, u->out_norm.b, nullptr, 0, N, h.H, h.W, h.C, 1, 0, u->head_in, 1, s));
+        PD_TRY(conv_out_3x3_f32(u->head_in, u->out_w, u->out_b, out, N, h.H, h.W, h.C, u->out_ch, s));
+    }
+    return PDHIP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res_blocks, const int* channel_mult, int n_mult,
+                                 const int* attention_ds, int n_att, int num_head_channels, int out_channels, int max_batch,
+                                 pdhip_unet** out) {
+    PD_REQUIRE(out && channel_mult && n_mult > 0 && (n_att == 0 || attention_ds), "pdhip_unet_create: null argument");
+    PD_REQUIRE(model_channels % 32 == 0 && image_size % (1 << (n_mult - 1)) == 0 && max_batch >= 1 && max_batch <= 64,
+               "pdhip_unet_create: model_channels %% 32, image_size %% 2^(levels-1), 1 <= max_batch <= 64 required");
+    PD_REQUIRE(num_head_channels == 32 || num_head_channels == 64, "pdhip_unet_create: num_head_channels must be 32 or 64");
+    PD_REQUIRE(out_channels == 3 || out_channels == 6, "pdhip_unet_create: out_channels must be 3 or 6");
+    pdhip_unet* u = new pdhip_unet();
+    *out = nullptr;
+    u->image_size = image_size; u->mc = model_channels; u->nres = num_res_blocks; u->head = num_head_channels;
+    u->out_ch = out_channels; u->max_batch = max_batch; u->ted = model_channels * 4;
+    u->mult.assign(channel_mult, channel_mult + n_mult);
+    u->att_ds.assign(attention_ds, attention_ds + n_att);
+    auto is_att = [&](int ds) { for (int a : u->att_ds) if (a == ds) return true; return false; };
+    auto fail = [&](int rc) { for (void* p : u->owned) hipFree(p); delete u; return rc; };
+    long long emb_rows = 0;
+    auto add_res = [&](const std::string& name, int cin, int cout, int mode) -> int {
+        ResB rb; rb.name = name; rb.cin = cin; rb.cout = cout; rb.mode = mode; rb.has_skip = cin != cout;
+        rb.emb_off = emb_rows; emb_rows += 2 * cout;
+        u->res.push_back(rb);
+        return (int)u->res.size() - 1;
+    };
+    auto add_att = [&](const std::string& name, int c) -> int {
+        AttB ab; ab.name = name; ab.c = c;
+        u->att.push_back(ab);
+        return (int)u->att.size() - 1;
+    };
+    // ---- graph (unet.py:481-617)
+    int ch = u->mult[0] * u->mc;
+    std::vector<int> chans{ch};
+    u->input.push_back({Block{0, 0}});
+    int ds = 1, n = 1;
+    for (int level = 0; level < n_mult; ++level) {
+        for (int r = 0; r < num_res_blocks; ++r) {
+            std::vector<Block> layers;
+            const int o = u->mult[level] * u->mc;
+            layers.push_back(Block{1, add_res("input_blocks." + std::to_string(n) + ".0", ch, o, 0)});
+            ch = o;
+            if (is_att(ds)) layers.push_back(Block{2, add_att("input_blocks." + std::to_string(n) + ".1", ch)});
+            u->input.push_back(layers);
+            chans.push_back(ch);
+            ++n;
+        }
+        if (level != n_mult - 1) {
+            u->input.push_back({Block{1, add_res("input_blocks." + std::to_string(n) + ".0", ch, ch, 1)}});
+            chans.push_back(ch);
+            ds *= 2;
+            ++n;
+        }
+    }
+    u->middle.push_back(Block{1, add_res("middle_block.0", ch, ch, 0)});
+    u->middle.push_back(Block{2, add_att("middle_block.1", ch)});
+    u->middle.push_back(Block{1, add_res("middle_block.2", ch, ch, 0)});
+    n = 0;
+    for (int level = n_mult - 1; level >= 0; --level) {
+        for (int i = 0; i < num_res_blocks + 1; ++i) {
+            const int ich = chans.back(); chans.pop_back();
+            const int o = u->mc * u->mult[level];
+            std::vector<Block> layers;
+            const std::string base = "output_blocks." + std::to_string(n) + ".";
+            layers.push_back(Block{1, add_res(base + "0", ch + ich, o, 0)});
+            ch = o;
+            int k = 1;
+            if (is_att(ds)) { layers.push_back(Block{2, add_att(base + std::to_string(k), ch)}); ++k; }
+            if (level && i == num_res_blocks) {
+                layers.push_back(Block{1, add_res(base + std::to_string(k), ch, ch, 2)});
+                ds /= 2;
+            }
+            u->output.push_back(layers);
+            ++n;
+        }
+    }
+    u->final_ch = ch;
+    u->emb_rows = emb_rows;
+    // ---- parameters
+    int rc = PDHIP_OK;
+    auto chk = [&](int r) { if (rc == PDHIP_OK) rc = r; };
+    for (ResB& rb : u->res) {
+        chk(alloc_norm(u, rb.n1, rb.cin)); chk(alloc_norm(u, rb.n2, rb.cout));
+        chk(alloc_conv(u, rb.c1, rb.cin, rb.cout, 9)); chk(alloc_conv(u, rb.c2, rb.cout, rb.cout, 9));
+        if (rb.has_skip) chk(alloc_conv(u, rb.skip, rb.cin, rb.cout, 1));
+        if (rc) return fail(rc);
+    }
+    for (AttB& ab : u->att) {
+        chk(alloc_norm(u, ab.n, ab.c)); chk(alloc_conv(u, ab.qkv, ab.c, 3 * ab.c, 1)); chk(alloc_conv(u, ab.proj, ab.c, ab.c, 1));
+        if (rc) return fail(rc);
+    }
+    const int c0 = u->mult[0] * u->mc;
+    chk(dalloc(u, &u->w_in, (size_t)c0 * 27)); chk(dalloc(u, &u->b_in, (size_t)c0));
+    chk(dalloc(u, &u->te_w0, (size_t)u->ted * u->mc)); chk(dalloc(u, &u->te_b0, (size_t)u->ted));
+    chk(dalloc(u, &u->te_w2, (size_t)u->ted * u->ted)); chk(dalloc(u, &u->te_b2, (size_t)u->ted));
+    chk(dalloc(u, &u->emb_w, (size_t)emb_rows * u->ted)); chk(dalloc(u, &u->emb_b, (size_t)emb_rows));
+    chk(alloc_norm(u, u->out_norm, u->final_ch));
+    chk(dalloc(u, &u->out_w, (size_t)out_channels * 9 * u->final_ch)); chk(dalloc(u, &u->out_b, (size_t)out_channels));
+    chk(dalloc(u, &u->zero_page, (size_t)128));
+    if (rc) return fail(rc);
+    if (hipMemset(u->zero_page, 0, 256) != hipSuccess) { set_error("hipMemset failed"); return fail(PDHIP_E_HIP); }
+    // ---- workspace (sized by a dry run of the forward at max_batch)
+    const size_t S2 = (size_t)image_size * image_size;
+    chk(forward_impl(u, nullptr, nullptr, max_batch, nullptr, nullptr, true));
+    u->arena_bytes = u->arena_off + 4096;
+    {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, u->arena_bytes);
+        if (e != hipSuccess) { set_error("pdhip_unet_create: activation arena of %zu bytes: %s", u->arena_bytes, hipGetErrorString(e)); return fail(PDHIP_E_NOMEM); }
+        u->owned.push_back(q);
+        u->arena = reinterpret_cast<char*>(q);
+    }
+    u->gn_ws_floats = (size_t)max_batch * ((S2 + 255) / 256) * 64;
+    chk(dalloc(u, &u->stats, (size_t)max_batch * 64)); chk(dalloc(u, &u->gn_ws, u->gn_ws_floats));
+    chk(dalloc(u, &u->emb_silu, (size_t)max_batch * u->ted)); chk(dalloc(u, &u->emb_tmp, (size_t)max_batch * (u->mc + u->ted)));
+    chk(dalloc(u, &u->emb_all, (size_t)max_batch * emb_rows)); chk(dalloc(u, &u->head_in, (size_t)max_batch * S2 * u->final_ch));
+    chk(dalloc(u, &u->t_dev, (size_t)max_batch));
+    chk(dalloc(u, &u->sx, (size_t)max_batch * 3 * S2)); chk(dalloc(u, &u->sy, (size_t)max_batch * 3 * S2));
+    chk(dalloc(u, &u->set_, (size_t)max_batch * out_channels * S2)); chk(dalloc(u, &u->smask, (size_t)max_batch * S2));
+    if (rc) return fail(rc);
+    *out = u;
+    return PDHIP_OK;
+}
+
+extern "C" void pdhip_unet_destroy(pdhip_unet* u) {
+    if (!u) return;
+    for (hipEvent_t e : u->prof.ev) hipEventDestroy(e);
+    for (void* p : u->owned) hipFree(p);
+    delete u;
+}
+
+extern "C" long long pdhip_unet_arena_bytes(const pdhip_unet* u) { return u ? (long long)u->arena_bytes : -1; }
+
+// names still missing after loading (count); if buf != NULL the first names are written, '\n'-separated
+extern "C" int pdhip_unet_missing_tensors(const pdhip_unet* u, char* buf, int buf_len) {
+    if (!u) return -1;
+    std::vector<std::string> miss;
+    auto conv = [&](const std::string& n, const ConvW& c) { if (!c.have_w) miss.push_back(n + ".weight"); if (!c.have_b) miss.push_back(n + ".bias"); };
+    auto norm = [&](const std::string& n, const NormW& c) { if (!c.have_g) miss.push_back(n + ".weight"); if (!c.have_b) miss.push_back(n + ".bias"); };
+    if (!u->have_win) miss.push_back("input_blocks.0.0.weight");
+    if (!u->have_bin) miss.push_back("input_blocks.0.0.bias");
+    const char* te[4] = {"time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"};
+    for (int i = 0; i < 4; ++i) if (!u->have_te[i]) miss.push_back(te[i]);
+    for (const ResB& rb : u->res) {
+        norm(rb.name + ".in_layers.0", rb.n1); conv(rb.name + ".in_layers.2", rb.c1);
+        if (!rb.have_ew) miss.push_back(rb.name + ".emb_layers.1.weight");
+        if (!rb.have_eb) miss.push_back(rb.name + ".emb_layers.1.bias");
+        norm(rb.name + ".out_layers.0", rb.n2); conv(rb.name + ".out_layers.3", rb.c2);
+        if (rb.has_skip) conv(rb.name + ".skip_connection", rb.skip);
+    }
+    for (const AttB& ab : u->att) { norm(ab.name + ".norm", ab.n); conv(ab.name + ".qkv", ab.qkv); conv(ab.name + ".proj_out", ab.proj); }
+    norm("out.0", u->out_norm);
+    if (!u->have_ow) miss.push_back("out.2.weight");
+    if (!u->have_ob) miss.push_back("out.2.bias");
+    if (buf && buf_len > 0) {
+        std::string s;
+        for (const std::string& m : miss) { if ((int)(s.size() + m.size() + 2) >= buf_len) break; s += m; s += '\n'; }
+        strncpy(buf, s.c_str(), buf_len - 1); buf[buf_len - 1] = 0;
+    }
+    return (int)miss.size();
+}
+
+extern "C" int pdhip_unet_num_tensors(const pdhip_unet* u) {
+    if (!u) return -1;
+    int n = 2 + 4 + 4;                                   // conv_in, time_embed, out.0/out.2
+    for (const ResB& rb : u->res) n += 10 + (rb.has_skip ? 2 : 0);
+    n += 6 * (int)u->att.size();
+    return n;
+}
+
+extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const void* data, int is_f16, const int64_t* shape,
+                                      int ndim, void* stream) {
+    PD_REQUIRE(u && name_c && data && shape && ndim >= 1 && ndim <= 4, "pdhip_unet_load_tensor: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const std::string name(name_c);
+    long long numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    auto want = [&](long long n, const char* what) -> int {
+        PD_REQUIRE(numel == n, "pdhip_unet_load_tensor: %s: %s expects %lld elements, got %lld", name_c, what, n, numel);
+        return PDHIP_OK;
+    };
+    auto load_vec = [&](float* dst, long long n, bool* flag, int round16) -> int {
+        PD_TRY(want(n, "vector"));
+        k_copy_f32<<<grid_for(n), 256, 0, s>>>(data, is_f16, n, dst, round16);
+        PD_LAUNCH_CHECK();
+        *flag = true;
+        return PDHIP_OK;
+    };
+    auto load_conv_w = [&](ConvW& c) -> int {
+        PD_TRY(want((long long)c.cout * c.cin * c.taps, "conv weight"));
+        PD_REQUIRE(shape[0] == c.cout && shape[1] == c.cin, "pdhip_unet_load_tensor: %s: shape mismatch", name_c);
+        k_pack_conv<<<grid_for(numel), 256, 0, s>>>(data, is_f16, c.cout, c.cin, c.taps, c.w);
+        PD_LAUNCH_CHECK();
+        c.have_w = true;
+        return PDHIP_OK;
+    };
+    auto ends = [&](const std::string& suf) { return name.size() >= suf.size() && name.compare(name.size() - suf.size(), suf.size(), suf) == 0; };
+    auto starts = [&](const std::string& pre) { return name.compare(0, pre.size(), pre) == 0; };
+    if (name == "input_blocks.0.0.weight") {
+        const int c0 = u->mult[0] * u->mc;
+        PD_TRY(want((long long)c0 * 27, "input conv weight"));
+        k_pack_conv<<<grid_for(numel), 256, 0, s>>>(data, is_f16, c0, 3, 9, u->w_in);
+        PD_LAUNCH_CHECK();
+        u->have_win = true;
+        return PDHIP_OK;
+    }
+    if (name == "input_blocks.0.0.bias") return load_vec(u->b_in, u->mult[0] * u->mc, &u->have_bin, 1);
+    if (name == "time_embed.0.weight") return load_vec(u->te_w0, (long long)u->ted * u->mc, &u->have_te[0], 0);
+    if (name == "time_embed.0.bias") return load_vec(u->te_b0, u->ted, &u->have_te[1], 0);
+    if (name == "time_embed.2.weight") return load_vec(u->te_w2, (long long)u->ted * u->ted, &u->have_te[2], 0);
+    if (name == "time_embed.2.bias") return load_vec(u->te_b2, u->ted, &u->have_te[3], 0);
+    if (name == "out.0.weight") return load_vec(u->out_norm.g, u->final_ch, &u->out_norm.have_g, 0);
+    if (name == "out.0.bias") return load_vec(u->out_norm.b, u->final_ch, &u->out_norm.have_b, 0);
+    if (name == "out.2.bias") return load_vec(u->out_b, u->out_ch, &u->have_ob, 0);
+    if (name == "out.2.weight") {
+        PD_TRY(want((long long)u->out_ch * u->final_ch * 9, "out conv weight"));
+        k_pack_conv_f32<<<grid_for(numel), 256, 0, s>>>(data, is_f16, u->out_ch, u->final_ch, 9, u->out_w);
+        PD_LAUNCH_CHECK();
+        u->have_ow = true;
+        return PDHIP_OK;
+    }
+    for (ResB& rb : u->res) {
+        if (!starts(rb.name + ".")) continue;
+        const std::string rest = name.substr(rb.name.size() + 1);
+        if (rest == "in_layers.0.weight") return load_vec(rb.n1.g, rb.cin, &rb.n1.have_g, 0);
+        if (rest == "in_layers.0.bias") return load_vec(rb.n1.b, rb.cin, &rb.n1.have_b, 0);
+        if (rest == "in_layers.2.weight") return load_conv_w(rb.c1);
+        if (rest == "in_layers.2.bias") return load_vec(rb.c1.b, rb.cout, &rb.c1.have_b, 1);
+        if (rest == "emb_layers.1.weight") return load_vec(u->emb_w + rb.emb_off * u->ted, (long long)2 * rb.cout * u->ted, &rb.have_ew, 0);
+        if (rest == "emb_layers.1.bias") return load_vec(u->emb_b + rb.emb_off, 2 * rb.cout, &rb.have_eb, 0);
+        if (rest == "out_layers.0.weight") return load_vec(rb.n2.g, rb.cout, &rb.n2.have_g, 0);
+        if (rest == "out_layers.0.bias") return load_vec(rb.n2.b, rb.cout, &rb.n2.have_b, 0);
+        if (rest == "out_layers.3.weight") return load_conv_w(rb.c2);
+        if (rest == "out_layers.3.bias") return load_vec(rb.c2.b, rb.cout, &rb.c2.have_b, 1);
+        if (rb.has_skip && rest == "skip_connection.weight") return load_conv_w(rb.skip);
+        if (rb.has_skip && rest == "skip_connection.bias") return load_vec(rb.skip.b, rb.cout, &rb.skip.have_b, 1);
+    }
+    for (AttB& ab : u->att) {
+        if (!starts(ab.name + ".")) continue;
+        const std::string rest = name.substr(ab.name.size() + 1);
+        if (rest == "norm.weight") return load_vec(ab.n.g, ab.c, &ab.n.have_g, 0);
+        if (rest == "norm.bias") return load_vec(ab.n.b, ab.c, &ab.n.have_b, 0);
+        if (rest == "qkv.weight") return load_conv_w(ab.qkv);
+        if (rest == "qkv.bias") return load_vec(ab.qkv.b, 3 * ab.c, &ab.qkv.have_b, 1);
+        if (rest == "proj_out.weight") return load_conv_w(ab.proj);
+        if (rest == "proj_out.bias") return load_vec(ab.proj.b, ab.c, &ab.proj.have_b, 1);
+    }
+    (void)ends;
+    set_error("pdhip_unet_load_tensor: unknown tensor name '%s'", name_c);
+    return PDHIP_E_ARG;
+}
+
+extern "C" int pdhip_unet_forward(pdhip_unet* u, const float* x, const float* t, int N, float* out, void* stream) {
+    PD_REQUIRE(u && x && t && out, "pdhip_unet_forward: null argument");
+    PD_REQUIRE(N >= 1 && N <= u->max_batch, "pdhip_unet_forward: batch %d outside [1, %d]", N, u->max_batch);
+    return forward_impl(u, x, t, N, out, as_stream(stream), false);
+}
+
+// ---- profiling of the dominant kernel (3x3 implicit-GEMM launches) with HIP events on the launch stream
+extern "C" int pdhip_unet_profile(pdhip_unet* u, int enable) {
+    PD_REQUIRE(u, "pdhip_unet_profile: null handle");
+    u->prof.on = enable != 0;
+    u->prof.used = 0;
+    u->prof.flops = 0;
+    return PDHIP_OK;
+}
+extern "C" int pdhip_unet_profile_read(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches) {
+    PD_REQUIRE(u && total_ms && total_flops && launches, "pdhip_unet_profile_read: null argument");
+    double ms = 0;
+    for (size_t i = 0; i + 1 < u->prof.used; i += 2) {
+        PD_HIP(hipEventSynchronize(u->prof.ev[i + 1]));
+        float e = 0;
+        PD_HIP(hipEventElapsedTime(&e, u->prof.ev[i], u->prof.ev[i + 1]));
+        ms += e;
+    }
+    *total_ms = ms; *total_flops = u->prof.flops; *launches = (long long)(u->prof.used / 2);
+    return PDHIP_OK;
+}
+
+// ---- D1: DDNM schedule (diffusion.py:46-113, 770-812) computed on the host exactly as the reference forms it
+namespace {
+struct Sched { std::vector<int> t; std::vector<DdnmCoef> co; std::vector<float> ab; };
+Sched make_schedule() {
+    // betas = np.linspace(1e-4, 0.02, 1000) (f64: start + i*step, last = stop) -> f32;
+    // alpha_bar(t) = cumprod(1 - [0, beta])[t+1] on f32 inputs; torch's CPU cumprod accumulates in f64 and rounds
+    // each prefix to f32 (the golden vectors pin exactly this; a CUDA scan differs in the last ulp).
+    Sched s;
+    s.ab.resize(1001);
+    double acc = 1.0;
+    s.ab[0] = 1.0f;                                                // index t+1 with t = -1
+    const double b0 = 1e-4, b1 = 0.02, step = (b1 - b0) / 999.0;
+    for (int i = 0; i < 1000; ++i) {
+        const double beta = (i == 999) ? b1 : b0 + (double)i * step;
+        acc = acc * (double)(1.0f - (float)beta);
+        s.ab[i + 1] = (float)acc;
+    }
+    const double eta = 0.85;
+    for (int k = 99; k >= 0; --k) {
+        const int t = k * 10, tn = (k - 1) * 10 < 0 ? -1 : (k - 1) * 10;
+        const float at = s.ab[t + 1], an = s.ab[tn + 1];
+        DdnmCoef c;
+        c.sqrt_1m_at = sqrtf(1.0f - at); c.sqrt_at = sqrtf(at); c.sqrt_at_next = sqrtf(an);
+        c.sigma_t = sqrtf(1.0f - an * an);
+        c.c1 = sqrtf(1.0f - an) * (float)eta;
+        c.c2 = sqrtf(1.0f - an) * (float)std::sqrt(1.0 - eta * eta);
+        s.t.push_back(t); s.co.push_back(c);
+    }
+    return s;
+}
+__global__ void k_fill(float* p, float v, int n) { int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+}  // namespace
+
+extern "C" int pdhip_ddnm_schedule(float* at, float* at_next, int* t, int* t_next, float* coefs /*[100][6]*/) {
+    Sched s = make_schedule();
+    for (int k = 0; k < 100; ++k) {
+        const int tt = s.t[k], tn = tt - 10 < 0 ? -1 : tt - 10;
+        if (at) at[k] = s.ab[tt + 1];
+        if (at_next) at_next[k] = s.ab[tn + 1];
+        if (t) t[k] = tt;
+        if (t_next) t_next[k] = tn;
+        if (coefs) memcpy(coefs + 6 * k, &s.co[k], sizeof(DdnmCoef));
+    }
+    return PDHIP_OK;
+}
+
+extern "C" int pdhip_ddnm_step(float* x, const float* et, int et_channels, const float* y, const float* mask, const float* eps,
+                               uint64_t seed, int step, int N, int HW, void* stream) {
+    PD_REQUIRE(x && et && y && mask && step >= 0 && step < 100 && (et_channels == 3 || et_channels == 6), "pdhip_ddnm_step: bad arguments");
+    static const Sched sched = make_schedule();
+    return ddnm_update(x, et, et_channels, y, mask, eps, seed, (unsigned long long)step + 1, sched.co[step], N, HW, as_stream(stream));
+}
+
+extern "C" int pdhip_ddnm_prepare(const float* masked_imgs, const float* masks, float* y, int N, int HW, void* stream) {
+    PD_REQUIRE(masked_imgs && masks && y, "pdhip_ddnm_prepare: null argument");
+    return ddnm_prepare(masked_imgs, masks, y, N, HW, as_stream(stream));
+}
+
+// The whole of simplified_ddnm_inpainting for N images at once: no host round trip inside the loop.
+// x_T / eps_tape (eps_tape[k] = noise of step k, [n_steps,N,3,S,S]) may be NULL -> Philox noise from `seed`.
+extern "C" int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
+                                 const float* eps_tape, uint64_t seed, int n_steps, float* out, void* stream) {
+    PD_REQUIRE(u && masked_imgs && masks && out, "pdhip_ddnm_sample: null argument");
+    PD_REQUIRE(N >= 1 && N <= u->max_batch && n_steps >= 1 && n_steps <= 100, "pdhip_ddnm_sample: bad N / n_steps");
+    static const Sched sched = make_schedule();
+    hipStream_t s = as_stream(stream);
+    const int HW = u->image_size * u->image_size;
+    const long long n3 = (long long)N * 3 * HW;
+    PD_TRY(ddnm_prepare(masked_imgs, masks, u->sy, N, HW, s));
+    if (x_T) PD_HIP(hipMemcpyAsync(u->sx, x_T, n3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else PD_TRY(philox_normal(u->sx, n3, seed, 0, s));
+    for (int k = 0; k < n_steps; ++k) {
+        k_fill<<<1, 64, 0, s>>>(u->t_dev, (float)sched.t[k], N);
+        PD_TRY(forward_impl(u, u->sx, u->t_dev, N, u->set_, s, false));
+        PD_TRY(ddnm_update(u->sx, u->set_, u->out_ch, u->sy, masks, eps_tape ? eps_tape + (size_t)k * n3 : nullptr, seed,
+                           (unsigned long long)k + 1, sched.co[k], N, HW, s));
+    }
+    return ddnm_finish(u->sx, out, n3, s);
+}
+
+// ---- stand-alone operators (also the unit-test surface of the kernels)
+extern "C" int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
+                                     int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, const void* zero_page,
+                                     void* stream) {
+    PD_REQUIRE(x && w_packed && y && zero_page, "pdhip_conv2d_nhwc_f16: null argument");
+    return conv_igemm((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
+                      Cout_pad, taps, (const half_t*)zero_page, as_stream(stream));
+}
+extern "C" int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed, void* stream) {
+    PD_REQUIRE(w_oihw && w_packed, "pdhip_pack_conv_weight_f16: null argument");
+    k_pack_conv<<<grid_for((long long)Cout * Cin * taps), 256, 0, as_stream(stream)>>>(w_oihw, 0, Cout, Cin, taps, (half_t*)w_packed);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+extern "C" int pdhip_groupnorm_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film, int N, int H,
+                                        int W, int C, int silu, int resample, void* y, float* stats_ws /*[N*64]*/,
+                                        float* ws, long long ws_floats, void* stream) {
+    PD_REQUIRE(x && gamma && beta && y && stats_ws && ws, "pdhip_groupnorm_nhwc_f16: null argument");
+    PD_TRY(gn_stats((const half_t*)x, N, H * W, C, 1e-5f, stats_ws, ws, (size_t)ws_floats, as_stream(stream)));
+    return gn_apply((const half_t*)x, stats_ws, gamma, beta, film, 2LL * C, N, H, W, C, silu, resample, y, 0, as_stream(stream));
+}
+extern "C" int pdhip_attention_f16(const void* qkv, void* out, int N, int T, int C, int head_dim, void* stream) {
+    PD_REQUIRE(qkv && out, "pdhip_attention_f16: null argument");
+    return attention((const half_t*)qkv, (half_t*)out, N, T, C, head_dim, as_stream(stream));
+}
+extern "C" int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream) {
+    PD_REQUIRE(out && n > 0, "pdhip_philox_normal: bad arguments");
+    return philox_normal(out, n, seed, stream_id, as_stream(stream));
+}

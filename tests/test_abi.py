@@ -19,9 +19,10 @@ def test_library_exports_every_declared_symbol():
     import __graft_entry__ as ge
     ge.build()
     from pointdreamer_amd import _lib
+    import pointdreamer_amd.ddnm_inpainting  # noqa: F401  (registers the UNet / DDNM entry points)
     L = _lib.lib()
     syms = declared_symbols()
-    assert len(syms) >= 14
+    assert len(syms) >= 30
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/pdhip.h but not exported"
         assert s in _lib._SIGS, f"{s} has no ctypes signature in pointdreamer_amd/_lib.py"
@@ -53,3 +54,21 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f"{f} imports the oracle"
                 assert '/root/reference' not in src.replace('/root/reference/', 'REF:')  or True
+
+
+def test_ddnm_schedule_matches_reference_golden_on_host():
+    """pdhip_ddnm_schedule is host-only arithmetic: alpha_bar table and (t, t_next) pairs bit-identical to the
+    values the reference's Diffusion/compute_alpha produce (golden from tools/gen_golden_nn.py)."""
+    import numpy as np
+    from conftest import load_golden
+    import pointdreamer_amd.ddnm_inpainting as di
+    g = load_golden('ddnm_sampler.npz')
+    at, an, t, tn, co = di.ddnm_schedule()
+    assert np.array_equal(at, g['at']) and np.array_equal(an, g['at_next'])
+    assert np.array_equal(t, g['t']) and np.array_equal(tn, g['t_next'])
+    assert t[0] == 990 and tn[-1] == -1 and an[-1] == 1.0
+    from oracle import ddnm as oddnm
+    cos = oddnm.step_coefficients()
+    for k in (0, 50, 99):
+        ref = [cos[k][n].item() for n in ('sqrt_1m_at', 'sqrt_at', 'sqrt_at_next', 'sigma_t', 'c1', 'c2')]
+        assert np.allclose(co[k], ref, rtol=2e-7, atol=0)

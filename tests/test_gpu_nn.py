@@ -1,0 +1,255 @@
+"""GPU parity tests for rows U1 (UNet) and D1 (DDNM): HIP kernels through the C ABI vs a plain torch fp32
+reference of the same op, vs the oracle (oracle/unet.py, oracle/ddnm.py) and vs golden vectors produced by the
+imported reference (tools/gen_golden_nn.py).
+
+Tolerances: the engine computes in f16 with f32 accumulation like the reference's fp16 torso, the
+oracle is fp32 => per-forward relative L-inf <= 2e-2 and relative L2 <= 5e-3 on random weights; single kernels
+are compared against an fp32 reference fed the same f16-rounded inputs (<= 2e-3 of the output scale);
+the DDNM update with injected noise is f32 elementwise => 1e-5."""
+import ctypes as C
+import math
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import unet as ounet, ddnm as oddnm
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope="module")
+def nn():
+    assert torch.cuda.is_available()
+    from pointdreamer_amd import _lib
+    import pointdreamer_amd.ddnm_inpainting as di
+    return dict(L=_lib.lib(), lib=_lib, di=di)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def hip_conv(nn, x_nchw, w, b, res_nchw=None):
+    """x [N,Cin,H,W] f32 (already f16-representable), w [Cout,Cin,k,k]; returns [N,Cout,H,W] f32."""
+    L = nn['L']
+    N, Cin, H, W = x_nchw.shape
+    Cout, taps = w.shape[0], w.shape[2] * w.shape[3]
+    pad = ((Cout + 127) // 128) * 128
+    x = x_nchw.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    wp = torch.zeros((pad, taps * Cin), dtype=torch.float16, device=DEV)
+    wd = w.contiguous().float().to(DEV)
+    assert L.pdhip_pack_conv_weight_f16(_ptr(wd), Cout, Cin, taps, _ptr(wp), _stream()) == 0
+    bd = b.float().to(DEV)
+    y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=DEV)
+    zp = torch.zeros((128,), dtype=torch.float16, device=DEV)
+    r = None if res_nchw is None else res_nchw.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    rc = L.pdhip_conv2d_nhwc_f16(_ptr(x), _ptr(wp), _ptr(bd), _ptr(r) if r is not None else None, _ptr(y), N, H, W, Cin, Cout,
+                                 pad, taps, _ptr(zp), _stream())
+    assert rc == 0, L.pdhip_last_error()
+    torch.cuda.synchronize()
+    return y.float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,res", [
+    (1, 16, 16, 32, 64, 3, False),      # small
+    (1, 8, 8, 64, 96, 3, True),         # M = 64 < tile, Cout not a multiple of 128, fused residual
+    (2, 32, 32, 256, 256, 3, True),     # the dominant layer shape at reduced size
+    (3, 8, 8, 160, 128, 1, False),      # 1x1 (skip connection / qkv / proj), M = 192 (ragged tile)
+    (1, 64, 64, 96, 32, 3, False),      # wide image, narrow output
+    (1, 16, 16, 1024, 512, 1, True),    # deep K
+])
+def test_conv_igemm_vs_torch_fp32(nn, N, H, W, Cin, Cout, k, res):
+    g = torch.Generator().manual_seed(N * 1000 + Cin + Cout + k)
+    x = (torch.randn((N, Cin, H, W), generator=g)).half().float()
+    # asymmetric, transpose-detecting weights
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(Cin * k * k)).half().float()
+    b = (torch.randn((Cout,), generator=g) * 0.1).half().float()
+    r = (torch.randn((N, Cout, H, W), generator=g)).half().float() if res else None
+    ref = F.conv2d(x, w, b, padding=k // 2)
+    ref = ref.half().float()
+    if res:
+        ref = (ref + r).half().float()
+    out = hip_conv(nn, x, w, b, r)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() <= 2e-3 * scale + 1e-3
+    # the zero-padding border must be exact zeros' contribution: compare a border pixel separately
+    assert torch.allclose(out[:, :, 0, 0], ref[:, :, 0, 0], atol=2e-3 * scale + 1e-3)
+
+
+@pytest.mark.parametrize("N,H,W,Cc,film,silu,resample", [
+    (2, 16, 16, 64, False, True, 0), (1, 8, 8, 96, True, True, 0), (2, 16, 16, 256, False, True, 1),
+    (1, 8, 8, 512, False, True, 2), (3, 4, 4, 32, True, False, 0), (1, 32, 32, 2048, False, False, 0),
+])
+def test_groupnorm_silu_film_resample_vs_torch(nn, N, H, W, Cc, film, silu, resample):
+    L = nn['L']
+    g = torch.Generator().manual_seed(Cc + H)
+    x = (torch.randn((N, Cc, H, W), generator=g) * 1.7 + 0.3).half().float()
+    gamma = 1 + 0.1 * torch.randn((Cc,), generator=g)
+    beta = 0.1 * torch.randn((Cc,), generator=g)
+    fl = 0.3 * torch.randn((N, 2 * Cc), generator=g) if film else None
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if film:
+        ref = ref * (1 + fl[:, :Cc, None, None]) + fl[:, Cc:, None, None]
+    if silu:
+        ref = F.silu(ref)
+    if resample == 1:
+        ref = F.avg_pool2d(ref, 2)
+    elif resample == 2:
+        ref = F.interpolate(ref, scale_factor=2, mode='nearest')
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    Ho, Wo = ref.shape[2:]
+    y = torch.empty((N, Ho, Wo, Cc), dtype=torch.float16, device=DEV)
+    stats = torch.empty((N * 64,), device=DEV)
+    ws = torch.empty((N * 64 * ((H * W + 255) // 256),), device=DEV)
+    fd = fl.to(DEV) if film else None
+    rc = L.pdhip_groupnorm_nhwc_f16(_ptr(xd), _ptr(gamma.to(DEV)), _ptr(beta.to(DEV)), _ptr(fd) if film else None, N, H, W, Cc,
+                                    1 if silu else 0, resample, _ptr(y), _ptr(stats), _ptr(ws), ws.numel(), _stream())
+    assert rc == 0, L.pdhip_last_error()
+    out = y.float().cpu().permute(0, 3, 1, 2)
+    assert (out - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("N,T,Cc,D", [(1, 64, 128, 64), (2, 256, 128, 32), (1, 1024, 512, 64), (2, 64, 1024, 64)])
+def test_attention_vs_torch(nn, N, T, Cc, D):
+    L = nn['L']
+    g = torch.Generator().manual_seed(T + Cc)
+    qkv = (torch.randn((N, 3 * Cc, T), generator=g) * 1.5).half().float()
+    heads = Cc // D
+    q, k, v = qkv.reshape(N * heads, 3 * D, T).split(D, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(D))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", w, v).reshape(N, Cc, T)
+    # a spiked key row forces a large running-max jump in the online softmax (rare-branch test)
+    qd = qkv.permute(0, 2, 1).contiguous().half().to(DEV)
+    out = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
+    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _stream()) == 0, L.pdhip_last_error()
+    o = out.float().cpu().permute(0, 2, 1)
+    assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_attention_online_softmax_rescale_branch(nn):
+    L = nn['L']
+    N, T, Cc, D = 1, 256, 64, 64
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn((N, 3 * Cc, T), generator=g) * 0.5)
+    qkv[0, D:2 * D, 200] = qkv[0, 0:D, 17] * 6.0        # key 200 (4th chunk) matches query 17 strongly -> max jumps late
+    qkv = qkv.half().float()
+    q, k, v = qkv.reshape(1, 3 * D, T).split(D, dim=1)
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q, k) / math.sqrt(D), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", w, v)
+    qd = qkv.permute(0, 2, 1).contiguous().half().to(DEV)
+    out = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
+    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _stream()) == 0
+    o = out.float().cpu().permute(0, 2, 1)
+    assert w[0, 17, 200] > 0.5
+    assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).norm() / b.norm()).item()
+
+
+def test_unet_small_vs_oracle_and_reference_golden(nn):
+    g = load_golden('unet_small.npz')
+    cfg = ounet.make_config(int(g['cfg_image_size']), int(g['cfg_channels']), 2, "32,16,8", int(g['cfg_head']), True)
+    w = ounet.random_weights(cfg, int(g['seed']))
+    assert len(w) == int(g['n_tensors'])
+    m = nn['di'].UNetModel(image_size=cfg['image_size'], num_channels=cfg['model_channels'], num_head_channels=cfg['num_head_channels'],
+                           max_batch=2, device=DEV)
+    assert m.load_state_dict(w, strict=True) == len(w)
+    x, t = torch.from_numpy(g['x']), torch.from_numpy(g['t'])
+    out = m(x.to(DEV), t.to(DEV)).cpu()
+    ref = torch.from_numpy(g['ref_out'])                            # the imported reference's fp32 output
+    linf, l2 = _rel(out, ref)
+    assert linf <= 2e-2 and l2 <= 5e-3, (linf, l2)
+    taps = {}
+    oo = ounet.forward(cfg, w, x, t, taps=taps)
+    assert _rel(out, oo)[0] <= 2e-2
+    # batch independence / ragged batch: one image alone gives the same answer
+    out1 = m(x[1:2].to(DEV), t[1:2].to(DEV)).cpu()
+    assert torch.allclose(out1, out[1:2], atol=2e-3, rtol=0)
+    with pytest.raises(nn['lib'].PdhipError):
+        m(torch.zeros((3, 3, 64, 64), device=DEV), torch.zeros((3,), device=DEV))      # > max_batch
+    with pytest.raises(nn['lib'].PdhipError):
+        nn['di'].UNetModel(image_size=64, num_channels=32, num_head_channels=32, max_batch=1, device=DEV).forward(
+            x[:1].to(DEV), t[:1].to(DEV))                           # weights never loaded -> loud failure
+
+
+def test_unet_full_256_vs_reference_golden(nn):
+    g = load_golden('unet_full.npz')
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, int(g['seed']))
+    assert len(w) == 566 and int(g['n_params']) == 552814086
+    m = nn['di'].UNetModel(max_batch=1, device=DEV, **nn['di'].IMAGENET_256)
+    m.load_state_dict(w, strict=True)
+    del w
+    out = m(torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV)).cpu()
+    st = int(g['stride'])
+    linf, l2 = _rel(out[:, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+    assert linf <= 2e-2 and l2 <= 5e-3, (linf, l2)
+
+
+def test_ddnm_schedule_and_step_vs_reference_sampler_golden(nn):
+    L = nn['L']
+    g = load_golden('ddnm_sampler.npz')
+    at, an, t, tn, co = nn['di'].ddnm_schedule()
+    assert np.array_equal(at, g['at']) and np.array_equal(an, g['at_next'])
+    assert np.array_equal(t, g['t']) and np.array_equal(tn, g['t_next'])
+    masked, mask, tape = torch.from_numpy(g['masked']).to(DEV), torch.from_numpy(g['mask']).to(DEV), torch.from_numpy(g['tape']).to(DEV)
+    wk = torch.from_numpy(g['toy_w']).to(DEV)
+    HW = masked.shape[-1] ** 2
+    y = torch.empty_like(masked)
+    assert L.pdhip_ddnm_prepare(_ptr(masked), _ptr(mask), _ptr(y), 1, HW, _stream()) == 0
+    x = tape[0].clone().contiguous()
+    for k in range(100):
+        tt = torch.ones(1, device=DEV) * float(t[k])
+        et = (F.conv2d(x, wk, padding=1) * (0.5 + tt.view(-1, 1, 1, 1) / 1000.0)).contiguous()     # the fixture's toy denoiser
+        assert L.pdhip_ddnm_step(_ptr(x), _ptr(et), 6, _ptr(y), _ptr(mask), _ptr(tape[k + 1].contiguous()), 0, k, 1, HW, _stream()) == 0
+    out = torch.clamp((x + 1) / 2, 0, 1).cpu()
+    assert (out - torch.from_numpy(g['ref_out'])).abs().max().item() <= 1e-5     # vs the reference's own sampler
+
+
+def test_ddnm_sampler_with_unet_vs_oracle(nn):
+    g = load_golden('unet_small.npz')
+    cfg = ounet.make_config(64, 32, 2, "32,16,8", 32, True)
+    w = ounet.random_weights(cfg, 21)
+    inp = nn['di'].Inpainter(DEV, ckpt_path=None, model_kwargs=dict(image_size=64, num_channels=32, num_head_channels=32),
+                             max_batch=2, state_dict=w)
+    gen = torch.Generator().manual_seed(3)
+    V, S, steps = 3, 64, 3                                            # V > max_batch exercises chunking
+    imgs = torch.rand((V, 3, S, S), generator=gen)
+    masks = (torch.rand((V, S, S), generator=gen) > 0.7).float()
+    imgs = imgs * masks[:, None]
+    xT = torch.randn((V, 3, S, S), generator=gen)
+    tape = torch.randn((steps, V, 3, S, S), generator=gen)
+    out = inp.inpaint_views(imgs.to(DEV), masks.to(DEV), x_T=xT.to(DEV), eps_tape=tape.to(DEV), n_steps=steps).cpu()
+    ref = oddnm.sample(lambda x, t: ounet.forward(cfg, w, x, t), imgs, masks, xT, list(tape), n_steps=steps)
+    assert (out - ref).abs().max().item() <= 3e-2
+    # known pixels are reproduced by the masked projection up to the remaining noise level only after many steps;
+    # what must hold exactly is determinism and the reference-signature wrapper
+    out2 = inp.inpaint_views(imgs.to(DEV), masks.to(DEV), x_T=xT.to(DEV), eps_tape=tape.to(DEV), n_steps=steps).cpu()
+    assert torch.equal(out, out2)
+    one = inp.inpaint(imgs[:1].permute(0, 2, 3, 1).to(DEV), masks[:1, :, :, None].repeat(1, 1, 1, 3).to(DEV))
+    assert one.shape == (1, 3, S, S) and float(one.min()) >= 0 and float(one.max()) <= 1
+
+
+def test_philox_normal_stream(nn):
+    L = nn['L']
+    n = 1 << 20
+    a = torch.empty((n,), device=DEV)
+    b = torch.empty((n,), device=DEV)
+    assert L.pdhip_philox_normal(_ptr(a), n, 1234, 1, _stream()) == 0
+    assert L.pdhip_philox_normal(_ptr(b), n, 1234, 1, _stream()) == 0
+    assert torch.equal(a, b)
+    assert L.pdhip_philox_normal(_ptr(b), n, 1234, 2, _stream()) == 0
+    assert not torch.equal(a, b)
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a * b).mean().item()) < 5e-3
+    assert abs((a ** 4).mean().item() - 3.0) < 0.1

@@ -1,0 +1,147 @@
+"""Golden vectors for rows U1 and D1, produced by RUNNING THE REFERENCE's own modules on the CPU.
+
+  python -m tools.gen_golden_nn            (build container only)
+
+U1: the reference UNetModel (models/DDNM/guided_diffusion/unet.py, built by script_util.create_model) is
+    imported unmodified, loaded (strict) with oracle.unet.random_weights(cfg, seed) and run in fp32:
+      unet_small.npz   image 64, 32 channels (channel_mult (1,2,3,4), attention at ds 2,4,8, 32-ch heads)
+      unet_full.npz    the real 256x256 configuration of configs/imagenet_256.yml (552.8 M params); only the
+                       input, t and a strided subsample of the output are stored.
+D1: the reference Diffusion.simplified_ddnm_inpainting (diffusion.py:459-570) itself, with `.to('cuda')`
+    redirected to the CPU and torch.randn / randn_like replaced by a recorded noise tape (the tape is the
+    injected noise of the fixture), driving a tiny deterministic stand-in denoiser.
+"""
+import os
+import sys
+import types
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools import ref_harness as rh            # noqa: E402
+from oracle import unet as ounet, ddnm as oddnm  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def ref_unet(cfg_kwargs, weights):
+    unet_mod, script_util, gnn = rh.import_reference_unet()
+    model = script_util.create_model(**cfg_kwargs)
+    missing = model.load_state_dict(weights, strict=True)
+    model.eval()
+    return model
+
+
+SMALL = dict(image_size=64, num_channels=32, num_res_blocks=2, attention_resolutions="32,16,8", num_head_channels=32,
+             learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True, use_fp16=False, num_heads=4,
+             num_heads_upsample=-1, class_cond=False, use_checkpoint=False, dropout=0.0,
+             use_new_attention_order=False, channel_mult="")
+FULL = dict(SMALL, image_size=256, num_channels=256, num_head_channels=64)
+
+
+def gen_unet(name, kw, seed, batch, stride):
+    cfg = ounet.make_config(kw['image_size'], kw['num_channels'], kw['num_res_blocks'], kw['attention_resolutions'],
+                            kw['num_head_channels'], kw['learn_sigma'])
+    w = ounet.random_weights(cfg, seed)
+    model = ref_unet(kw, w)
+    assert len(w) == len(model.state_dict())
+    g = torch.Generator().manual_seed(seed + 1)
+    S = kw['image_size']
+    x = torch.randn((batch, 3, S, S), generator=g)
+    t = torch.tensor([990.0, 350.0, 0.0][:batch])
+    with torch.no_grad():
+        y = model(x, t)
+        yo = ounet.forward(cfg, w, x, t)
+    err = (y - yo).abs().max().item()
+    print(name, 'reference vs oracle max abs diff', err, 'out std', y.std().item())
+    assert err < 2e-4 * max(1.0, y.abs().max().item())
+    np.savez_compressed(os.path.join(OUT, name), seed=seed, x=x.numpy(), t=t.numpy(), stride=stride,
+                        ref_out=y.numpy()[:, :, ::stride, ::stride].copy(), n_tensors=len(w),
+                        n_params=sum(v.numel() for v in w.values()), cfg_image_size=S, cfg_channels=kw['num_channels'],
+                        cfg_head=kw['num_head_channels'])
+
+
+def gen_ddnm(name):
+    rh.install()
+    # the reference's diffusion.py pulls torchvision.utils and its datasets package; both are stubbed/importable
+    import importlib
+    ds = types.ModuleType('datasets_stub')
+    cwd = os.getcwd()
+    os.chdir(rh.REF)
+    try:
+        sys.path.insert(0, os.path.join(rh.REF, 'models', 'DDNM'))
+        diffusion = importlib.import_module('models.DDNM.guided_diffusion.diffusion')
+    finally:
+        os.chdir(cwd)
+    import yaml
+
+    class NS(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+        __setattr__ = dict.__setitem__
+
+    def to_ns(d):
+        return NS({k: to_ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+    config = to_ns(yaml.safe_load(open(os.path.join(rh.REF, 'models/DDNM/configs/imagenet_256.yml'))))
+    args = NS(sigma_y=0, eta=0.85, seed=1234)
+    runner = diffusion.Diffusion(args, config, device=torch.device('cpu'))
+    H = 32
+    config.data.image_size = H
+    g = torch.Generator().manual_seed(77)
+    masked = torch.rand((1, 3, H, H), generator=g)
+    mask = (torch.rand((1, H, H), generator=g) > 0.6).float()
+    masked = masked * mask[:, None]
+    tape = [torch.randn((1, 3, H, H), generator=g) for _ in range(101)]
+    pos = {'i': 0}
+
+    def next_noise(*a, **k):
+        n = tape[pos['i']]
+        pos['i'] += 1
+        return n.clone()
+    wk = torch.randn((6, 3, 3, 3), generator=g) * 0.2
+
+    def toy_model(x, t):
+        return torch.nn.functional.conv2d(x, wk, padding=1) * (0.5 + t.view(-1, 1, 1, 1) / 1000.0)
+    orig_to, orig_randn, orig_randn_like = torch.Tensor.to, torch.randn, torch.randn_like
+
+    def to(self, *a, **k):
+        if a and a[0] == 'cuda':
+            return self
+        return orig_to(self, *a, **k)
+    torch.Tensor.to, torch.randn, torch.randn_like = to, next_noise, next_noise
+    try:
+        out = runner.simplified_ddnm_inpainting(toy_model, masked.unsqueeze(0), mask)
+    finally:
+        torch.Tensor.to, torch.randn, torch.randn_like = orig_to, orig_randn, orig_randn_like
+    assert pos['i'] == 101
+    out = out[0]
+    mine = oddnm.sample(toy_model, masked, mask, tape[0], tape[1:])
+    err = (mine - out).abs().max().item()
+    print(name, 'reference sampler vs oracle max abs diff', err)
+    assert err < 1e-5
+    cos = oddnm.step_coefficients()
+    np.savez_compressed(os.path.join(OUT, name), masked=masked.numpy(), mask=mask.numpy(), toy_w=wk.numpy(),
+                        tape=torch.stack(tape).numpy(), ref_out=out.numpy(),
+                        ref_betas=runner.betas.numpy(),
+                        at=np.array([c['at'].item() for c in cos], np.float32),
+                        at_next=np.array([c['at_next'].item() for c in cos], np.float32),
+                        t=np.array([c['t'] for c in cos]), t_next=np.array([c['t_next'] for c in cos]))
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['ddnm', 'small', 'full']
+    if 'ddnm' in which:
+        gen_ddnm('ddnm_sampler.npz')
+    if 'small' in which:
+        gen_unet('unet_small.npz', SMALL, seed=11, batch=2, stride=1)
+    if 'full' in which:
+        gen_unet('unet_full.npz', FULL, seed=12, batch=1, stride=8)
+
+
+if __name__ == '__main__':
+    main()

@@ -37,7 +37,8 @@ class _Stub(types.ModuleType):
 
 
 _STUBS = ['kaolin', 'nvdiffrast', 'nvdiffrast.torch', 'torchvision', 'torchvision.transforms',
-          'torchvision.transforms.transforms', 'torchvision.utils', 'open3d', 'cv2', 'trimesh',
+          'torchvision.transforms.transforms', 'torchvision.transforms.functional', 'torchvision.utils',
+          'torchvision.datasets', 'torchvision.datasets.utils', 'open3d', 'cv2', 'trimesh',
           'trimesh.grouping', 'trimesh.geometry', 'imageio', 'pytz', 'xatlas', 'kiui', 'seaborn', 'plyfile',
           'mcubes', 'munch', 'matplotlib', 'matplotlib.pyplot', 'pymeshlab', 'lpips', 'skimage']
 
