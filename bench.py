@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Headline benchmark: shapes/hour of the project -> inpaint -> unproject texturing path
+(BASELINE.json: 30k-point cloud, 8 x 256^2 views, DDNM 100 steps, 1024^2 atlas) on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one whole shape through the hot path with its inputs already resident in HBM:
+P1-P6 project/sparse -> D1/U1 DDNM inpainting of all 8 views (100 UNet steps, views batched) -> N1-N3 NBF ->
+Uq1-Uq5 unproject + dilate.  Shapes are independent, so ranks shard SHAPES with no data-path collective
+(weak scaling: one shape per rank per step); `--parallel views` instead splits the 8 views of one shape across
+ranks and assembles them with a single RCCL all_gather (strong scaling).
+Random-init UNet weights of the reference architecture (the checkpoint cannot be fetched offline), synthetic shape.
+Rank 0 prints ONE JSON line (contract in the task statement) incl. `roofline` (dominant kernel: the 3x3
+implicit-GEMM conv, timed with HIP events on its launch stream inside the timed region) and `cpu_baseline`
+(the oracle's CPU restatement of the reference's 'nearest' path on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+UNET_FLOP_PER_FORWARD = 2.0 * 1119832768512            # 1 119 832 768 512 MAC per 256^2 forward (N=1)
+PEAK_FP16_TFLOPS = 2500.0                              # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sample_views=2):
+    """Reference CPU 'nearest' path, restated by the oracle (kind = "port"), on a bounded sample:
+    `sample_views` of the 8 views for the per-view stages (project/raster/sparse/nearest/texel visibility scale
+    linearly in views) plus the full NBF + unproject + dilate at A=1024; extrapolated to one 8-view shape."""
+    from pointdreamer_amd import synthetic
+    from oracle import camera as ocam, project as oproj, sparse as osparse, inpaint as oinp, unproject as ounp
+    torch.set_num_threads(1)
+    sh = synthetic.make_shape(30000, 1024)
+    V = 8
+    cams, base_dirs, eyes, ups = ocam.create_cameras(V, 1.6, 512)
+    t0 = time.time()
+    sub = cams[:sample_views]
+    pr = oproj.project_batch(sub, sh['vertices'], sh['points'], True, 0.05)
+    hard, fid, depth = oproj.rasterize(pr['pos'], sh['faces'], 512)
+    hard_r = oproj.downsample_masks(hard, 256)
+    vis, _ = oproj.point_validation_by_depth(512, pr['point_uvs'], pr['point_depths'], depth, 0.0001)
+    pp = oproj.point_pixels_for_res(pr['point_uvs'], 256)
+    sp, m0, m2, sf = osparse.get_sparse_images(pp, sh['colors'], vis, hard_r, sample_views, 256, 1, 1, 0.82)
+    inp = np.stack([oinp.reference_nearest_inpaint_scipy(sp[i], m2[i]) for i in range(sample_views)]).astype(np.float32)
+    t_views = time.time() - t0
+    t1 = time.time()
+    o = ounp.unproject(inp, sh['f_normals'], 256, sub, 512, base_dirs[:sample_views], sh['gb_pos'], sh['mask'],
+                       sh['per_atlas_pixel_face_id'], pr['uv_centers'], pr['uv_scales'], 0.05, sf, depth, [21], True)
+    oinp.reference_nearest_inpaint_scipy(o['atlas_img'].transpose(2, 0, 1), sh['mask'][..., 0])
+    t_unproj = time.time() - t1
+    per_shape = t_views * (V / sample_views) + t_unproj * (0.5 + 0.5 * V / sample_views)
+    return dict(value=3600.0 / per_shape, unit="shapes/hour", cores=1, kind="port",
+                sample=f"oracle CPU restatement, texture_gen_method='nearest' (scipy griddata), {sample_views}/8 views measured "
+                       f"({t_views:.1f}s per-view stages + {t_unproj:.1f}s NBF/unproject/dilate at A=1024) extrapolated to 8 views "
+                       f"= {per_shape:.1f} s/shape; no DDNM on the CPU (a CPU fp32 UNet forward is ~8 s, x800 per shape)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='ddnm', choices=['ddnm', 'nearest'])
+    ap.add_argument('--parallel', default='shapes', choices=['shapes', 'views'])
+    ap.add_argument('--ddnm-steps', type=int, default=100)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from pointdreamer_amd import synthetic, pipeline, _lib
+    import pointdreamer_amd.camera_utils as cu
+    import pointdreamer_amd.ddnm_inpainting as di
+    from pointdreamer_amd import dist as pdist
+    _lib.lib()
+
+    V, RES, CAM_RES, A = 8, 256, 512, 1024
+    sh = synthetic.make_shape(30000, A, seed=rank if args.parallel == 'shapes' else 0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    g = {k: T(v) for k, v in sh.items()}
+    cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, CAM_RES, device=dev)
+    camera_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    xatlas = dict(gb_pos=g['gb_pos'], mask=g['mask'], per_atlas_pixel_face_id=g['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
+    inpainter = None
+    views_here = V if args.parallel == 'shapes' else len(pdist.shard_range(V, rank, world))
+    if args.workload == 'ddnm':
+        inpainter = di.Inpainter(dev, ckpt_path=None, allow_random_weights=True, max_batch=views_here)
+        inpainter.n_steps = args.ddnm_steps
+    method = 'DDNM_inpaint' if args.workload == 'ddnm' else 'nearest'
+    cfg = dict(view_num=V, res=RES, cam_res=CAM_RES, point_validation_by_o3d=False, texture_gen_method=method, point_size=1,
+               edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None,
+               edge_dilate_kernels=[21], complete_unseen_by='unproject', inpainter=inpainter)
+
+    def step():
+        if args.parallel == 'views' and world > 1:
+            return pdist.colorize_one_mesh_view_parallel(g['points'], g['colors'], g['vertices'], g['faces'], g['f_normals'],
+                                                         xatlas, camera_info, rank=rank, world=world, **cfg)
+        return pipeline.colorize_one_mesh(g['points'], g['colors'], g['vertices'], g['faces'], g['f_normals'], xatlas,
+                                          camera_info, **cfg)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if inpainter is not None:
+        inpainter.model.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    shapes = args.steps * (world if args.parallel == 'shapes' else 1)
+    value = shapes / dt * 3600.0
+
+    roofline = None
+    if inpainter is not None:
+        ms, flops, launches = inpainter.model.profile_read()
+        inpainter.model.profile(False)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = dict(bound="mfma", kernel="k_conv_igemm<9> (3x3 implicit-GEMM conv, f16 in / f32 acc)", achieved=achieved,
+                        peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=None,
+                        launches=int(launches), avg_launch_ms=ms / max(launches, 1),
+                        flops_per_launch=flops / max(launches, 1),
+                        unet_forward_tflops_effective=(UNET_FLOP_PER_FORWARD * views_here * args.ddnm_steps * args.steps) / dt / 1e12)
+    else:
+        roofline = dict(bound="hbm", kernel="n/a (nearest workload: sub-millisecond HBM-bound kernels)", achieved=None, peak=8000.0,
+                        unit="GB/s", frac=None, traffic=None)
+    if rank == 0:
+        out = dict(metric="shapes/hour (30k-pt cloud, 8x256^2 views, DDNM) on MI355X", value=value, unit="shapes/hour",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+                   higher_is_better=True, scaling="weak" if args.parallel == 'shapes' else "strong", vs_baseline=None,
+                   dtype="f16 (f32 accumulate; f32 GroupNorm/softmax statistics, f32 geometry)", data="synthetic",
+                   config=dict(workload=f"configs[2]: synthetic 30k-point sphere shape, 8x256^2 views, texture_gen_method="
+                                        f"'{method}' ({args.ddnm_steps} DDNM steps, 552.8M-param guided-diffusion UNet, random-init weights), "
+                                        f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, HPR off",
+                               parallelism=f"{args.parallel}-parallel x{world}", views_per_unet_batch=views_here,
+                               shapes_per_step=world if args.parallel == 'shapes' else 1),
+                   roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

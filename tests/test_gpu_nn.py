@@ -109,7 +109,8 @@ def test_groupnorm_silu_film_resample_vs_torch(nn, N, H, W, Cc, film, silu, resa
     stats = torch.empty((N * 64,), device=DEV)
     ws = torch.empty((N * 64 * ((H * W + 255) // 256),), device=DEV)
     fd = fl.to(DEV) if film else None
-    rc = L.pdhip_groupnorm_nhwc_f16(_ptr(xd), _ptr(gamma.to(DEV)), _ptr(beta.to(DEV)), _ptr(fd) if film else None, N, H, W, Cc,
+    gd, bd = gamma.to(DEV), beta.to(DEV)                   # keep the device copies alive across the async launch
+    rc = L.pdhip_groupnorm_nhwc_f16(_ptr(xd), _ptr(gd), _ptr(bd), _ptr(fd) if film else None, N, H, W, Cc,
                                     1 if silu else 0, resample, _ptr(y), _ptr(stats), _ptr(ws), ws.numel(), _stream())
     assert rc == 0, L.pdhip_last_error()
     out = y.float().cpu().permute(0, 3, 1, 2)
