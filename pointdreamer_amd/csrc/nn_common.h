@@ -15,7 +15,8 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 // bias f32 [Cout] (may be null), residual [N,H,W,Cout] f16 (may be null), Y [N,H,W,Cout] f16.
 // taps: 1 (1x1 conv / linear over pixels) or 9 (3x3, pad 1).  Cin % 32 == 0.
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
-               int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s);
+               int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
+               float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
 
 // ---- normalisation / elementwise (nn_norm.hip)
 // GroupNorm(32) statistics of X [N,HW,C] f16 -> stats [N][32][2] (mean, rstd) f32.  ws: N*chunks*32*2 floats.
@@ -31,8 +32,8 @@ int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long 
 int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStream_t s);
 
 // ---- small dense ops (nn_misc.hip)
-int conv_in_3x3(const float* x_nchw, const half_t* Wt /*[Cout][27] k=(ky*3+kx)*3+c*/, const float* bias, half_t* Y, int N,
-                int H, int W, int Cout, hipStream_t s);
+int conv_in_3x3(const float* x_nchw, const half_t* Wt /*[Cout_pad][32] k=(ky*3+kx)*3+c, k>=27 zero*/, const float* bias, half_t* Y,
+                int N, int H, int W, int Cout, int Cout_pad, half_t* im2col_ws /*[N*H*W][32]*/, const half_t* zero_page, hipStream_t s);
 int conv_out_3x3_f32(const float* X_nhwc, const float* Wt /*[Cout][9*Cin]*/, const float* bias, float* y_nchw, int N, int H,
                      int W, int Cin, int Cout, hipStream_t s);
 int timestep_mlp(const float* t, int N, int mc, const float* w0, const float* b0, const float* w2, const float* b2,

@@ -40,7 +40,8 @@ template <int TAPS>
 __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
                                                     const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                     half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
-                                                    int n_tiles, int total_tiles, const half_t* __restrict__ zero_page) {
+                                                    int n_tiles, int total_tiles, const half_t* __restrict__ zero_page,
+                                                    int splits, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -91,8 +92,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
         }
     };
     char* const wave_dst = smem + (wave * 2) * 1024;
-    int ntap = 0, nc = 0;
-    set_tap(0);
+    // split-K: this workgroup reduces K-steps [it0, it1) (blockIdx.y = split); splits == 1 -> the whole K range
+    const int it0 = (int)((long long)KI * blockIdx.y / splits), it1 = (int)((long long)KI * (blockIdx.y + 1) / splits);
+    int ntap = it0 / kc, nc = it0 - (it0 / kc) * kc;
+    set_tap(ntap);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ap[i] += astep[i] * nc; bp[i] += (size_t)it0 * BK; }
     auto issue = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -117,10 +122,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
 
     issue(0);
     int cur = 0;
-    for (int it = 0; it < KI; ++it) {
+    for (int it = it0; it < it1; ++it) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // stage `cur` landed; everyone is done reading stage cur^1
-        if (it + 1 < KI) issue(cur ^ 1);
+        if (it + 1 < it1) issue(cur ^ 1);
         const char* As = smem + cur * STAGE_BYTES + (wm * 64) * 64 + frag_off;
         const char* Bs = smem + cur * STAGE_BYTES + TILE_BYTES + (wn * 64) * 64 + frag_off;
         half8 a[4], b[4];
@@ -136,6 +141,21 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     }
     __syncthreads();                                       // all fragment reads done before the tile is reused
 
+    if (partial != nullptr) {                              // split-K: raw f32 partial tile, reduced by k_splitk_reduce
+        float* P = partial + (size_t)blockIdx.y * (size_t)M * Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long m = (long long)m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    if (m < M && n < Cout) P[(size_t)m * Cout + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue: acc (+bias) -> f16 -> LDS [128][CS_LD] -> coalesced 16-byte rows (+residual)
     half_t* Cs = reinterpret_cast<half_t*>(smem);
 #pragma unroll
@@ -168,18 +188,61 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     }
 }
 
+// sum of split-K partials (fixed order) + bias -> f16 (+ residual) -> Y
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int splits, long long M, int Cout,
+                                                       const float* __restrict__ bias, const half_t* __restrict__ residual,
+                                                       half_t* __restrict__ Y) {
+    const long long total = M * (Cout >> 3);
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const size_t o = (size_t)idx * 8;
+        const int n = (int)(o % Cout);
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+        for (int sp = 0; sp < splits; ++sp) {
+            const float4 v0 = *reinterpret_cast<const float4*>(partial + (size_t)sp * M * Cout + o);
+            const float4 v1 = *reinterpret_cast<const float4*>(partial + (size_t)sp * M * Cout + o + 4);
+            a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+        }
+        half8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)(a[e] + (bias ? bias[n + e] : 0.f));
+        if (residual != nullptr) {
+            const half8 rv = *reinterpret_cast<const half8*>(residual + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+        }
+        *reinterpret_cast<half8*>(Y + o) = v;
+    }
+}
+
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
-               int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s) {
+               int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
+               size_t splitk_ws_floats) {
     PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
     PD_REQUIRE(Cin % BK == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
     const long long M = (long long)N * H * W;
     const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = Cout_pad / BN;
     const int total = m_tiles * n_tiles;
+    // small-M layers (16x16 / 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups
+    const int KI = taps * (Cin / BK);
+    int splits = 1;
+    if (splitk_ws != nullptr && total < 384) {
+        splits = std::min(std::min((640 + total - 1) / total, KI / 4), 16);
+        while (splits > 1 && (size_t)splits * M * Cout > splitk_ws_floats) --splits;
+        if (splits < 1) splits = 1;
+    }
+    float* partial = splits > 1 ? splitk_ws : nullptr;
+    dim3 grid(total, splits);
     if (taps == 9)
-        k_conv_igemm<9><<<total, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page);
+        k_conv_igemm<9><<<grid, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial);
     else
-        k_conv_igemm<1><<<total, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page);
+        k_conv_igemm<1><<<grid, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial);
+    if (splits > 1) {
+        const long long tot = M * (Cout >> 3);
+        k_splitk_reduce<<<(int)std::min<long long>((tot + 255) / 256, 2048), 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y);
+    }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

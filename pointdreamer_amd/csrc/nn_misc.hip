@@ -10,22 +10,17 @@ using namespace pdhip;
 namespace pdnn {
 
 // ------------------------------------------------------------------------------------------------
-// conv_in: x f32 NCHW [N,3,H,W] -> (x.half()) conv3x3 -> Y f16 NHWC [N,H,W,Cout].  K = 27, weights in LDS.
-__global__ __launch_bounds__(256) void k_conv_in(const float* __restrict__ x, const half_t* __restrict__ Wt,
-                                                 const float* __restrict__ bias, half_t* __restrict__ Y, int H, int W,
-                                                 int Cout) {
-    extern __shared__ float s_w[];                 // [Cout][27] + bias [Cout]
-    for (int i = threadIdx.x; i < Cout * 27; i += blockDim.x) s_w[i] = (float)Wt[i];
-    for (int i = threadIdx.x; i < Cout; i += blockDim.x) s_w[Cout * 27 + i] = bias[i];
-    __syncthreads();
-    const int n = blockIdx.y;
-    const int opp = Cout >> 3;
-    const long long total = (long long)H * W * opp;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int oc = (int)(idx % opp);
-        const int p = (int)(idx / opp);
-        const int y = p / W, xx = p - y * W;
-        float in[27];
+// conv_in: x f32 NCHW [N,3,H,W] -> (x.half()) conv3x3 -> Y f16 NHWC [N,H,W,Cout].
+// K = 27 is far too short for its own kernel to matter: gather the 3x3x3 patch of every pixel into a 32-wide
+// f16 row (k = tap*3 + c, k >= 27 zero) and run the MFMA GEMM as a 1x1 convolution with Cin = 32.
+__global__ __launch_bounds__(256) void k_im2col_in(const float* __restrict__ x, half_t* __restrict__ A, int H, int W,
+                                                   long long pixels) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < pixels; p += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(p % W), y = (int)((p / W) % H);
+        const long long n = p / ((long long)W * H);
+        half_t row[32];
+#pragma unroll
+        for (int k = 27; k < 32; ++k) row[k] = (half_t)0.f;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -34,28 +29,25 @@ __global__ __launch_bounds__(256) void k_conv_in(const float* __restrict__ x, co
                 const bool ok = yy >= 0 && yy < H && xc >= 0 && xc < W;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    in[(ky * 3 + kx) * 3 + c] = ok ? (float)(half_t)x[(((size_t)n * 3 + c) * H + yy) * W + xc] : 0.f;
+                    row[(ky * 3 + kx) * 3 + c] = ok ? (half_t)x[(((size_t)n * 3 + c) * H + yy) * W + xc] : (half_t)0.f;
             }
-        half8 o;
+        half8* dst = reinterpret_cast<half8*>(A + (size_t)p * 32);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int co = oc * 8 + e;
-            float a = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            half8 v;
 #pragma unroll
-            for (int k = 0; k < 27; ++k) a += in[k] * s_w[co * 27 + k];
-            o[e] = (half_t)(a + s_w[Cout * 27 + co]);
+            for (int e = 0; e < 8; ++e) v[e] = row[q * 8 + e];
+            dst[q] = v;
         }
-        *reinterpret_cast<half8*>(Y + ((size_t)n * H * W + p) * Cout + oc * 8) = o;
     }
 }
 
-int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t* Y, int N, int H, int W, int Cout,
-                hipStream_t s) {
-    PD_REQUIRE(Cout % 8 == 0 && Cout <= 1024, "conv_in_3x3: bad Cout %d", Cout);
-    dim3 g((unsigned)std::min<long long>(((long long)H * W * (Cout / 8) + 255) / 256, 4096), N);
-    k_conv_in<<<g, 256, (size_t)Cout * 28 * sizeof(float), s>>>(x_nchw, Wt, bias, Y, H, W, Cout);
+int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t* Y, int N, int H, int W, int Cout, int Cout_pad,
+                half_t* im2col_ws, const half_t* zero_page, hipStream_t s) {
+    const long long pixels = (long long)N * H * W;
+    k_im2col_in<<<(int)std::min<long long>((pixels + 255) / 256, 8192), 256, 0, s>>>(x_nchw, im2col_ws, H, W, pixels);
     PD_LAUNCH_CHECK();
-    return PDHIP_OK;
+    return conv_igemm(im2col_ws, Wt, bias, nullptr, Y, N, H, W, 32, Cout, Cout_pad, 1, zero_page, s);
 }
 
 // ------------------------------------------------------------------------------------------------

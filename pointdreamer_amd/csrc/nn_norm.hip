@@ -52,20 +52,27 @@ __global__ __launch_bounds__(256) void k_gn_partial(const half_t* __restrict__ X
     }
 }
 
-__global__ void k_gn_finalize(const float* __restrict__ part, int chunks, int HW, int C, float eps, float* __restrict__ stats) {
-    const int n = blockIdx.x, g = threadIdx.x;
-    if (g >= 32) return;
+// one block per image: thread (slice j = tid>>5, group g = tid&31) sums chunks j, j+8, ...; fixed-order combine.
+__global__ __launch_bounds__(256) void k_gn_finalize(const float* __restrict__ part, int chunks, int HW, int C, float eps,
+                                                     float* __restrict__ stats) {
+    __shared__ double s_s[8][32], s_q[8][32];
+    const int n = blockIdx.x, g = threadIdx.x & 31, j = threadIdx.x >> 5;
     double ds = 0.0, dq = 0.0;
-    for (int c = 0; c < chunks; ++c) {
+    for (int c = j; c < chunks; c += 8) {
         ds += (double)part[(((size_t)n * chunks + c) * 32 + g) * 2];
         dq += (double)part[(((size_t)n * chunks + c) * 32 + g) * 2 + 1];
     }
-    const double cnt = (double)HW * (C / 32);
-    const double mean = ds / cnt;
-    double var = dq / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((size_t)n * 32 + g) * 2] = (float)mean;
-    stats[((size_t)n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    s_s[j][g] = ds; s_q[j][g] = dq;
+    __syncthreads();
+    if (j == 0) {
+        for (int k = 1; k < 8; ++k) { ds += s_s[k][g]; dq += s_q[k][g]; }
+        const double cnt = (double)HW * (C / 32);
+        const double mean = ds / cnt;
+        double var = dq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((size_t)n * 32 + g) * 2] = (float)mean;
+        stats[((size_t)n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, float* ws, size_t ws_floats, hipStream_t s) {
@@ -78,73 +85,94 @@ int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, flo
     PD_REQUIRE(smem <= 64 * 1024, "gn_stats: C too large (%d)", C);
     dim3 g(chunks, N);
     k_gn_partial<<<g, 256, smem, s>>>(X, HW, C, ws);
-    k_gn_finalize<<<N, 32, 0, s>>>(ws, chunks, HW, C, eps, stats);
+    k_gn_finalize<<<N, 256, 0, s>>>(ws, chunks, HW, C, eps, stats);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// one thread = one output pixel's channel octet.  RES: 0 none, 1 avgpool2 (of activated values), 2 nearest-up2.
-template <int RES, bool OUT_F32>
+// grid (pixel chunks, N).  thread -> (pixel sub-slot, channel octet): the octet's affine constants live in
+// registers for the whole chunk; consecutive threads touch consecutive 16-byte octets (full 128-B lines).
+// RES: 0 none, 1 avgpool2 (of activated values), 2 nearest-up2.
+#define GNA_ITERS 32
+template <int RES, bool OUT_F32, bool FILM>
 __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ film, long long film_stride, int H, int W,
-                                                  int C, int silu, void* __restrict__ Yv, long long total_oct) {
+                                                  int C, int silu, void* __restrict__ Yv) {
     const int opp = C >> 3, cg = C / 32;
+    const int pps = max(1, 256 / opp);
     const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_oct; idx += (long long)gridDim.x * blockDim.x) {
-        const int oc = (int)(idx % opp);
-        const long long pix = idx / opp;
-        const int xo = (int)(pix % Wo);
-        const int yo = (int)((pix / Wo) % Ho);
-        const int n = (int)(pix / ((long long)Wo * Ho));
+    const int n = blockIdx.y;
+    const int sub = threadIdx.x / opp;
+    if (sub >= pps) return;
+    const int p_begin = blockIdx.x * (pps * GNA_ITERS), p_end = min(Ho * Wo, p_begin + pps * GNA_ITERS);
+    for (int oc = threadIdx.x - sub * opp; oc < opp; oc += 256) {
         const int c0 = oc * 8;
-        float g8[8], b8[8], mean[8], rstd[8], sc[8], sh[8];
+        float ga[8], gb[8], t1[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e, grp = c / cg;
-            g8[e] = gamma[c]; b8[e] = beta[c];
-            mean[e] = stats[((size_t)n * 32 + grp) * 2];
-            rstd[e] = stats[((size_t)n * 32 + grp) * 2 + 1];
-            if (film) { sc[e] = film[(size_t)n * film_stride + c]; sh[e] = film[(size_t)n * film_stride + C + c]; }
+            const float mean = stats[((size_t)n * 32 + grp) * 2], rstd = stats[((size_t)n * 32 + grp) * 2 + 1];
+            ga[e] = rstd * gamma[c];
+            gb[e] = beta[c] - mean * ga[e];
+            if (FILM) {
+                t1[e] = (float)(half_t)(1.0f + (float)(half_t)film[(size_t)n * film_stride + c]);
+                sh[e] = (float)(half_t)film[(size_t)n * film_stride + C + c];
+            }
         }
         auto act = [&](int yi, int xi, float* o) {
             const half8 v = *reinterpret_cast<const half8*>(X + (((size_t)n * H + yi) * W + xi) * C + c0);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = ((float)v[e] - mean[e]) * rstd[e] * g8[e] + b8[e];
+                float f = (float)v[e] * ga[e] + gb[e];
                 if (!OUT_F32) f = (float)(half_t)f;                          // GroupNorm32 returns x.dtype (f16)
-                if (film) {
-                    const float t1 = (float)(half_t)(1.0f + (float)(half_t)sc[e]);
-                    f = (float)(half_t)(f * t1);
-                    f = (float)(half_t)(f + (float)(half_t)sh[e]);
+                if (FILM) {
+                    f = (float)(half_t)(f * t1[e]);
+                    f = (float)(half_t)(f + sh[e]);
                 }
                 if (silu) { f = silu_f(f); if (!OUT_F32) f = (float)(half_t)f; }
                 o[e] = f;
             }
         };
-        float r[8];
-        if (RES == 1) {
-            float a[8], b[8], c[8], d[8];
-            act(2 * yo, 2 * xo, a); act(2 * yo, 2 * xo + 1, b); act(2 * yo + 1, 2 * xo, c); act(2 * yo + 1, 2 * xo + 1, d);
+        for (int p = p_begin + sub; p < p_end; p += pps) {
+            float r[8];
+            if (RES == 0) {
+                const half8 v = *reinterpret_cast<const half8*>(X + ((size_t)n * H * W + p) * C + c0);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = (a[e] + b[e] + c[e] + d[e]) * 0.25f;
-        } else if (RES == 2) {
-            act(yo >> 1, xo >> 1, r);
-        } else {
-            act(yo, xo, r);
-        }
-        const size_t o = (((size_t)n * Ho + yo) * Wo + xo) * C + c0;
-        if (OUT_F32) {
-            float* Y = reinterpret_cast<float*>(Yv);
-            *reinterpret_cast<float4*>(Y + o) = make_float4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<float4*>(Y + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
-        } else {
-            half8 hv;
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[e] * ga[e] + gb[e];
+                    if (!OUT_F32) f = (float)(half_t)f;
+                    if (FILM) {
+                        f = (float)(half_t)(f * t1[e]);
+                        f = (float)(half_t)(f + sh[e]);
+                    }
+                    if (silu) { f = silu_f(f); if (!OUT_F32) f = (float)(half_t)f; }
+                    r[e] = f;
+                }
+            } else {
+                const int yo = p / Wo, xo = p - yo * Wo;
+                if (RES == 1) {
+                    float a[8], b[8], c[8], d[8];
+                    act(2 * yo, 2 * xo, a); act(2 * yo, 2 * xo + 1, b); act(2 * yo + 1, 2 * xo, c); act(2 * yo + 1, 2 * xo + 1, d);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (half_t)r[e];
-            *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(Yv) + o) = hv;
+                    for (int e = 0; e < 8; ++e) r[e] = (a[e] + b[e] + c[e] + d[e]) * 0.25f;
+                } else {
+                    act(yo >> 1, xo >> 1, r);
+                }
+            }
+            const size_t o = ((size_t)n * Ho * Wo + p) * C + c0;
+            if (OUT_F32) {
+                float* Y = reinterpret_cast<float*>(Yv);
+                *reinterpret_cast<float4*>(Y + o) = make_float4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<float4*>(Y + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            } else {
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)r[e];
+                *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(Yv) + o) = hv;
+            }
         }
     }
 }
@@ -153,14 +181,16 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s) {
     PD_REQUIRE(C % 32 == 0 && resample >= 0 && resample <= 2, "gn_apply: bad arguments");
     PD_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avgpool needs even H, W");
-    PD_REQUIRE(!out_f32 || resample == 0, "gn_apply: f32 output only without resampling");
+    PD_REQUIRE(!out_f32 || (resample == 0 && film == nullptr), "gn_apply: f32 output only without resampling / FiLM");
+    PD_REQUIRE(film == nullptr || resample == 0, "gn_apply: FiLM only without resampling");
     const int Ho = resample == 1 ? H / 2 : (resample == 2 ? H * 2 : H), Wo = resample == 1 ? W / 2 : (resample == 2 ? W * 2 : W);
-    const long long total = (long long)N * Ho * Wo * (C / 8);
-    const int grid = (int)std::min<long long>((total + 255) / 256, 65536);
-    if (out_f32) k_gn_apply<0, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
-    else if (resample == 0) k_gn_apply<0, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
-    else if (resample == 1) k_gn_apply<1, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
-    else k_gn_apply<2, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, total);
+    const int opp = C >> 3, pps = max(1, 256 / opp);
+    dim3 grid(cdiv((long long)Ho * Wo, pps * GNA_ITERS), N);
+    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
+    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
+    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
+    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
+    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -48,6 +48,7 @@ struct pdhip_unet {
     float *stats = nullptr, *gn_ws = nullptr; size_t gn_ws_floats = 0;
     float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr, *head_in = nullptr;
     float *t_dev = nullptr;
+    float* splitk_ws = nullptr; size_t splitk_floats = 0;
     // sampler state
     float *sx = nullptr, *sy = nullptr, *set_ = nullptr, *smask = nullptr;
     Prof prof;
@@ -91,6 +92,15 @@ __global__ void k_pack_conv(const void* __restrict__ src, int src_f16, int Cout,
         const int o = (int)(i / ((long long)taps * Cin));
         const float v = src_f16 ? (float)reinterpret_cast<const half_t*>(src)[i] : reinterpret_cast<const float*>(src)[i];
         dst[(size_t)o * taps * Cin + (size_t)tap * Cin + c] = (half_t)v;
+    }
+}
+__global__ void k_pack_conv_in(const void* __restrict__ src, int src_f16, int Cout, half_t* __restrict__ dst) {
+    // src [Cout][3][3][3] (OIHW) -> dst [Cout][32], k = (ky*3+kx)*3 + c  (columns 27..31 stay zero)
+    const int total = Cout * 27;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int tap = i % 9, c = (i / 9) % 3, o = i / 27;
+        const float v = src_f16 ? (float)reinterpret_cast<const half_t*>(src)[i] : reinterpret_cast<const float*>(src)[i];
+        dst[(size_t)o * 32 + tap * 3 + c] = (half_t)v;
     }
 }
 __global__ void k_pack_conv_f32(const void* __restrict__ src, int src_f16, int Cout, int Cin, int taps, float* __restrict__ dst) {
@@ -147,7 +157,8 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
     if (w.taps == 9) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
-    int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s);
+    int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
+                        c.u->splitk_ws, c.u->splitk_floats);
     if (w.taps == 9) PD_TRY(prof_end(c));
     return rc;
 }
@@ -196,9 +207,11 @@ int run_blocks(Ctx& c, std::vector<Block>& blocks, Act* h, const float* x_nchw) 
         if (b.kind == 0) {
             o.C = c.u->mult[0] * c.u->mc; o.H = o.W = c.u->image_size;
             o.p = arena_take(c.u, (size_t)c.N * o.H * o.W * o.C);
+            half_t* col = arena_take(c.u, (size_t)c.N * o.H * o.W * 32);
             if (!c.dry) {
                 PD_REQUIRE(c.u->have_win && c.u->have_bin, "unet: input conv not loaded");
-                PD_TRY(conv_in_3x3(x_nchw, c.u->w_in, c.u->b_in, o.p, c.N, o.H, o.W, o.C, c.s));
+                PD_TRY(conv_in_3x3(x_nchw, c.u->w_in, c.u->b_in, o.p, c.N, o.H, o.W, o.C, ((o.C + 127) / 128) * 128, col,
+                                   c.u->zero_page, c.s));
             }
         } else if (b.kind == 1) {
             PD_TRY(run_res(c, *h, c.u->res[b.idx], &o));
@@ -334,7 +347,8 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
         if (rc) return fail(rc);
     }
     const int c0 = u->mult[0] * u->mc;
-    chk(dalloc(u, &u->w_in, (size_t)c0 * 27)); chk(dalloc(u, &u->b_in, (size_t)c0));
+    chk(dalloc(u, &u->w_in, (size_t)(((c0 + 127) / 128) * 128) * 32)); chk(dalloc(u, &u->b_in, (size_t)c0));
+    if (rc == PDHIP_OK && hipMemset(u->w_in, 0, (size_t)(((c0 + 127) / 128) * 128) * 32 * sizeof(half_t)) != hipSuccess) rc = PDHIP_E_HIP;
     chk(dalloc(u, &u->te_w0, (size_t)u->ted * u->mc)); chk(dalloc(u, &u->te_b0, (size_t)u->ted));
     chk(dalloc(u, &u->te_w2, (size_t)u->ted * u->ted)); chk(dalloc(u, &u->te_b2, (size_t)u->ted));
     chk(dalloc(u, &u->emb_w, (size_t)emb_rows * u->ted)); chk(dalloc(u, &u->emb_b, (size_t)emb_rows));
@@ -359,6 +373,8 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     chk(dalloc(u, &u->emb_silu, (size_t)max_batch * u->ted)); chk(dalloc(u, &u->emb_tmp, (size_t)max_batch * (u->mc + u->ted)));
     chk(dalloc(u, &u->emb_all, (size_t)max_batch * emb_rows)); chk(dalloc(u, &u->head_in, (size_t)max_batch * S2 * u->final_ch));
     chk(dalloc(u, &u->t_dev, (size_t)max_batch));
+    u->splitk_floats = (size_t)16 * 384 * 128 * 128;               // 16 splits x (< 384 tiles of 128x128) f32
+    chk(dalloc(u, &u->splitk_ws, u->splitk_floats));
     chk(dalloc(u, &u->sx, (size_t)max_batch * 3 * S2)); chk(dalloc(u, &u->sy, (size_t)max_batch * 3 * S2));
     chk(dalloc(u, &u->set_, (size_t)max_batch * out_channels * S2)); chk(dalloc(u, &u->smask, (size_t)max_batch * S2));
     if (rc) return fail(rc);
@@ -443,7 +459,7 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
     if (name == "input_blocks.0.0.weight") {
         const int c0 = u->mult[0] * u->mc;
         PD_TRY(want((long long)c0 * 27, "input conv weight"));
-        k_pack_conv<<<grid_for(numel), 256, 0, s>>>(data, is_f16, c0, 3, 9, u->w_in);
+        k_pack_conv_in<<<grid_for(numel), 256, 0, s>>>(data, is_f16, c0, u->w_in);
         PD_LAUNCH_CHECK();
         u->have_win = true;
         return PDHIP_OK;
