@@ -1,0 +1,176 @@
+"""demo.py-compatible driver for the texturing path: same CLI (`--config`, `--pc_file` file-or-directory),
+same YAML keys (configs/*.yaml of the reference) and the same output tree as /root/reference/demo.py:311-497:
+
+  <output_path>/<ply stem>_<config stem>/config.yaml, input_pc.ply,
+      models/model_normalized.{obj,mtl,png}, others/{k}_{sparse,mask0,mask2,inpainted}.png, others/atlas_wo_background.png
+
+Geometry and UV unwrapping are UPSTREAM of this build (POCO / SPR / xatlas are out of scope):
+the driver uses the reference's own drop-in hooks -- `<pc>_untextured_mesh.obj` next to the PLY (demo.py:391-399)
+and the cached `geo/xatlas_<res>.pth` dict (demo.py:428-448); if no mesh is supplied it falls back to the build's
+stand-in UV sphere fitted to the cloud (clearly logged), so that the texturing path can be exercised end to end.
+
+  python -m pointdreamer_amd.demo --config configs/nearest.yaml --pc_file dataset/demo_data/clock.ply
+"""
+import argparse
+import datetime
+import logging
+import os
+import shutil
+import time
+
+import numpy as np
+import PIL.Image
+import torch
+import yaml
+
+from . import io_utils, pipeline, synthetic
+from .camera_utils import create_cameras
+
+SUPPORTED_KEYS = ('texture_gen_method', 'camera_distribution', 'cam_res', 'view_num', 'res', 'point_size', 'edge_point_size',
+                  'point_validation_by_o3d', 'hidden_point_removal_radius', 'refine_point_validation_by_remove_abnormal_depth',
+                  'crop_img', 'crop_padding', 'mask_ratio_thresh', 'edge_dilate_kernels', 'optimize_from',
+                  'xatlas_texture_res', 'complete_unseen_by', 'output_path')
+
+
+class Cfg(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def get_logger(path):
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    logger = logging.getLogger('pointdreamer_amd')
+    logger.setLevel(logging.INFO)
+    if not logger.handlers:
+        fmt = logging.Formatter('%(asctime)s %(levelname)s %(message)s')
+        for h in (logging.FileHandler(path), logging.StreamHandler()):
+            h.setFormatter(fmt)
+            logger.addHandler(h)
+    return logger
+
+
+def prepare(cfg_file, device, ckpt_path=None, allow_random_weights=False, overrides=None):
+    """demo.py:311-356 without the POCO network."""
+    cfg = Cfg(yaml.safe_load(open(cfg_file)))
+    cfg.update(overrides or {})
+    logger = get_logger(os.path.join(cfg.output_path, f'{datetime.datetime.now().strftime("%Y.%m.%d.%H.%M.%S")}_log.log'))
+    inpainter = None
+    if cfg.texture_gen_method == 'DDNM_inpaint':
+        logger.info('Loading inpainter...')
+        from .ddnm_inpainting import Inpainter, DEFAULT_CKPT
+        inpainter = Inpainter(device, ckpt_path=ckpt_path or DEFAULT_CKPT, allow_random_weights=allow_random_weights,
+                              max_batch=cfg.view_num)
+        logger.info('inpainter loaded')
+    cams, base_dirs, eye_positions, up_dirs = create_cameras(num_views=cfg.view_num, distribution=cfg.camera_distribution,
+                                                             distance=1.6, res=cfg.cam_res, device=device)
+    camera_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eye_positions, up_dirs=up_dirs)
+    return cfg, inpainter, camera_info, logger
+
+
+def standin_geometry(xyz, atlas_res, device, logger):
+    """No mesh next to the PLY and no POCO here: UV sphere (radius 0.5 = the normalised cloud's half extent) + analytic atlas."""
+    logger.warning('no <pc>_untextured_mesh.obj supplied: using the stand-in UV sphere geometry (POCO/SPR/xatlas are upstream)')
+    verts, faces, lut = synthetic.uv_sphere(50, 100)
+    gb_pos, mask, fid = synthetic.latlong_atlas(atlas_res, 50, 100, lut=lut)
+    # per-corner UVs of the lat-long parametrisation (one vt per face corner, like xatlas' unshared output)
+    v = verts.astype(np.float64)
+    lat = np.arccos(np.clip(v[:, 1] / 0.5, -1, 1)) / np.pi
+    lon = (np.arctan2(v[:, 2], v[:, 0]) % (2 * np.pi)) / (2 * np.pi)
+    corner_uv = np.stack([lon[faces], lat[faces]], -1)                          # [F,3,2]
+    wrap = (corner_uv[..., 0].max(1) - corner_uv[..., 0].min(1)) > 0.5           # faces crossing the seam
+    cu = corner_uv[..., 0]
+    cu[wrap] = np.where(cu[wrap] < 0.5, cu[wrap] + 1.0, cu[wrap])
+    span, g = atlas_res - 4, 2
+    uvs = np.stack([(np.clip(cu, 0, 1) * span + g) / atlas_res, (corner_uv[..., 1] * span + g) / atlas_res], -1).reshape(-1, 2)
+    tex_idx = np.arange(faces.shape[0] * 3, dtype=np.int64).reshape(-1, 3)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return T(verts), T(faces), dict(uvs=T(uvs.astype(np.float32)), mesh_tex_idx=T(tex_idx), gb_pos=T(gb_pos), mask=T(mask),
+                                    per_atlas_pixel_face_id=T(fid))
+
+
+def save_textured_mesh(vertices, uvs, faces, mesh_tex_idx, atlas_img, mask, output_root_path):
+    """demo.py:264-307."""
+    io_utils.savemeshtes2(vertices.cpu().numpy(), uvs.cpu().numpy(), faces.cpu().numpy(), mesh_tex_idx.cpu().numpy(),
+                          os.path.join(output_root_path, 'models', 'model_normalized.obj'))
+    img = np.asarray(atlas_img.cpu().numpy(), dtype=np.float32) * 255.0
+    img = img.clip(0, 255).astype(np.uint8)
+    PIL.Image.fromarray(np.ascontiguousarray(img[::-1, :, :]), 'RGB').save(os.path.join(output_root_path, 'models', 'model_normalized.png'))
+    cat_mask = (mask[0].long() * 255).cpu().numpy().astype(np.uint8)
+    rgba = np.concatenate([img, cat_mask], axis=-1)
+    PIL.Image.fromarray(np.ascontiguousarray(rgba[::-1, :, :]), 'RGBA').save(os.path.join(output_root_path, 'others', 'atlas_wo_background.png'))
+
+
+def recon_one_textured_mesh(cfg, inpainter, camera_info, pc_file, name, device, logger):
+    """demo.py:359-466 (texturing part)."""
+    out = os.path.join(cfg.output_path, name)
+    for d in ('geo', 'models', 'others'):
+        os.makedirs(os.path.join(out, d), exist_ok=True)
+    xyz, rgb = io_utils.read_ply_xyzrgb(pc_file)
+    if len(xyz) > 30000:
+        print(f"Point number > 30000! ({len(xyz)} points)({pc_file}) \n Please try uniformly subsampling the input point cloud first")
+        raise NotImplementedError
+    xyz = torch.tensor(np.asarray(xyz, np.float32)).to(device)
+    rgb = torch.tensor(np.asarray(rgb)).float().to(device) / 255.0
+    vmin, vmax = xyz.min(0)[0], xyz.max(0)[0]
+    xyz -= (vmax + vmin) / 2.
+    xyz /= (vmax - vmin).max()
+    io_utils.save_colored_pc_ply(xyz.cpu().numpy(), rgb.cpu().numpy(), os.path.join(out, 'input_pc.ply'))
+    all_start = time.time()
+    geo_path = pc_file.replace('.ply', '_untextured_mesh.obj')
+    xatlas_file = os.path.join(out, 'geo', f'xatlas_{cfg.xatlas_texture_res}.pth')
+    if os.path.exists(geo_path):
+        v, f = io_utils.load_obj_mesh(geo_path)
+        vertices = torch.from_numpy(v).to(device)
+        faces = torch.from_numpy(f).to(device)
+        vertices -= (vmax + vmin) / 2.
+        vertices /= (vmax - vmin).max()
+        if not os.path.exists(xatlas_file):
+            raise FileNotFoundError(f"{xatlas_file} not found: UV unwrapping (xatlas + UV rasterisation, "
+                                    "models/get3d/extract_texture_map.py:42-64) is upstream of this build; provide the cached dict")
+        xatlas_dict = {k: (t.to(device) if torch.is_tensor(t) else t) for k, t in torch.load(xatlas_file).items()}
+        logger.info('Existing geometry + xatlas data loaded')
+    else:
+        vertices, faces, xatlas_dict = standin_geometry(xyz, cfg.xatlas_texture_res, device, logger)
+    f_normals = torch.from_numpy(synthetic.face_normals(vertices.cpu().numpy(), faces.cpu().numpy())).to(device)
+    logger.info('Generate texture by PointDreamer...')
+    start = time.time()
+    kw = {k: cfg[k] for k in SUPPORTED_KEYS if k in cfg and k != 'output_path'}
+    kw.pop('camera_distribution', None)
+    vertices, uvs, faces, mesh_tex_idx, atlas_img, mask = pipeline.colorize_one_mesh(
+        xyz, rgb, vertices, faces, f_normals, xatlas_dict, camera_info, inpainter=inpainter,
+        save_img_path=os.path.join(out, 'others'), device=device, logger=None, **kw)
+    torch.cuda.synchronize()
+    logger.info(f'generate texture time: {time.time() - start} s')
+    save_textured_mesh(vertices, uvs, faces, mesh_tex_idx, atlas_img, mask, out)
+    logger.info(f'total time: {time.time() - all_start} s')
+    return out
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser("PointDreamer (MI355X texturing path)")
+    p.add_argument("--config", type=str, default='configs/default.yaml', help="path to config file")
+    p.add_argument("--pc_file", type=str, default='dataset/demo_data/clock.ply', help="path to input point cloud file or directory")
+    p.add_argument("--ckpt", type=str, default=None, help="256x256_diffusion_uncond.pt (reference key names)")
+    p.add_argument("--allow_random_weights", action='store_true', help="run DDNM with random-init weights if the checkpoint is absent")
+    p.add_argument("--set", nargs='*', default=[], help="YAML overrides key=value (e.g. complete_unseen_by=unproject optimize_from=None)")
+    args = p.parse_args(argv)
+    device = torch.device('cuda')
+    overrides = {k: yaml.safe_load(v) for k, v in (kv.split('=', 1) for kv in args.set)}
+    cfg, inpainter, camera_info, logger = prepare(args.config, device, args.ckpt, args.allow_random_weights, overrides)
+    pc_files = [args.pc_file] if args.pc_file.endswith('.ply') else \
+        [os.path.join(args.pc_file, i) for i in sorted(os.listdir(args.pc_file)) if i.endswith('.ply')]
+    outs = []
+    for pc_file in pc_files:
+        name = os.path.basename(pc_file).split('.ply')[0] + '_' + os.path.basename(args.config).split('.')[0]
+        os.makedirs(os.path.join(cfg.output_path, name), exist_ok=True)
+        shutil.copy(args.config, os.path.join(cfg.output_path, name, 'config.yaml'))
+        logger.info(f'Start Recon {pc_file}...')
+        outs.append(recon_one_textured_mesh(cfg, inpainter, camera_info, pc_file, name, device, logger))
+    return outs
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,48 @@
+"""End-to-end demo driver on the GPU: reference CLI/config surface in, reference output tree out."""
+import os
+import numpy as np
+import PIL.Image
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_cloud(path, n=20000):
+    from pointdreamer_amd import synthetic, io_utils
+    xyz, rgb = synthetic.sphere_points(n, seed=3)
+    io_utils.save_colored_pc_ply(xyz * 1.7 + 0.3, rgb, path)          # off-centre / scaled: the driver normalises it
+
+
+@pytest.mark.parametrize("config,extra", [("nearest.yaml", []), ("default.yaml", ["--allow_random_weights"])])
+def test_demo_cli_outputs(tmp_path, config, extra):
+    from pointdreamer_amd import demo
+    pc = str(tmp_path / 'ball.ply')
+    _write_cloud(pc)
+    over = ["--set", f"output_path={tmp_path / 'out'}", "xatlas_texture_res=512", "point_validation_by_o3d=False"]
+    if config == "default.yaml":
+        import pointdreamer_amd.ddnm_inpainting as di
+        orig = di.Inpainter.inpaint_views
+        di.Inpainter.inpaint_views = lambda self, a, b, **k: orig(self, a, b, n_steps=2)      # 2 DDNM steps keep the test short
+    try:
+        outs = demo.main(["--config", os.path.join(ROOT, "configs", config), "--pc_file", pc] + extra + over)
+    finally:
+        if config == "default.yaml":
+            di.Inpainter.inpaint_views = orig
+    out = outs[0]
+    assert os.path.basename(out) == "ball_" + config.split('.')[0]
+    for f in ["config.yaml", "input_pc.ply", "models/model_normalized.obj", "models/model_normalized.mtl",
+              "models/model_normalized.png", "others/atlas_wo_background.png"] + \
+             [f"others/{k}_{s}.png" for k in range(8) for s in ("sparse", "mask0", "mask2", "inpainted")]:
+        assert os.path.exists(os.path.join(out, f)), f
+    atlas = np.array(PIL.Image.open(os.path.join(out, "models/model_normalized.png")))
+    assert atlas.shape == (512, 512, 3) and atlas.std() > 5
+    rgba = np.array(PIL.Image.open(os.path.join(out, "others/atlas_wo_background.png")))
+    assert rgba.shape[2] == 4 and set(np.unique(rgba[..., 3])) <= {0, 255}
+    mode = PIL.Image.open(os.path.join(out, "others/0_inpainted.png")).mode
+    assert mode == ("RGBA" if config == "default.yaml" else "RGB")          # ours_utils.py:924-928 vs :939-941
+    if config == "nearest.yaml":
+        # colours come from the cloud: the nearest atlas must correlate with the analytic colour field
+        sp = np.array(PIL.Image.open(os.path.join(out, "others/0_sparse.png")))
+        assert sp.shape == (256, 256, 4) and (sp[..., 3] > 0).mean() > 0.05
