@@ -7,23 +7,21 @@
 //   NHWC f16 activation with zero padding -- no im2col buffer.
 //
 // Structure (MI355X-first): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 each =
-// 4x4 v_mfma_f32_16x16x32_f16 accumulators), K-step 32, both operand tiles staged HBM->LDS by LDS-DMA
-// (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction), double-buffered; the LDS image
-// is lane-linear so the bank swizzle is applied on the per-lane SOURCE address and mirrored on the
+// 4x4 v_mfma_f32_16x16x32_f16 accumulators), K-step BKT = 64 (32 when Cin % 64 != 0), both operand tiles staged
+// HBM->LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 1 KiB per wave-instruction), double-buffered;
+// the LDS image is lane-linear so the bank swizzle is applied on the per-lane SOURCE address and mirrored on the
 // ds_read_b128 side (cdna guide rule 21).  Out-of-image taps read a 16-byte zero page instead of branching.
 // Workgroup ids are remapped so that the n-tiles sharing one activation tile run back-to-back on one XCD (L2 reuse).
 // Epilogue: accumulators -> LDS transpose -> 16-byte coalesced NHWC stores with bias and residual fused.
+// Small-M layers: split-K over blockIdx.y with f32 partial tiles + a fixed-order reduce kernel.
 #include "nn_common.h"
 using namespace pdhip;
 namespace pdnn {
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define TILE_BYTES (BM * BK * 2)           // 8 KiB per operand tile
-#define STAGE_BYTES (2 * TILE_BYTES)
 #define CS_LD 136                          // epilogue tile leading dimension (halfs)
-#define SMEM_BYTES (BM * CS_LD * 2)        // 34 816 B >= 2 stages (32 768 B)
+#define EPI_BYTES (BM * CS_LD * 2)         // 34 816 B
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -32,16 +30,28 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-// 16-byte slot permutation inside a 64-byte tile row: slot = chunk ^ swz(row); conflict-free for the
-// ds_read_b128 lane groups (derivation in DESIGN.md "conv kernel": s = [0,2,3,1][(row >> 2) & 3]).
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+// 16-byte slot permutation inside a tile row: slot = chunk ^ swz(row).  Chosen so that every ds_read_b128
+// 16-lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) touches 16 distinct 16-B slots of the 256-B bank row:
+//   64-B rows  (BKT 32): s = [0,2,3,1][(row >> 2) & 3]      128-B rows (BKT 64): s = (row >> 1) & 7
+template <int BKT>
+__device__ __forceinline__ int swz(int row) {
+    if (BKT == 32) return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+    return (row >> 1) & 7;
+}
 
-template <int TAPS>
+template <int TAPS, int BKT>
 __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
                                                     const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                     half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
                                                     int n_tiles, int total_tiles, const half_t* __restrict__ zero_page,
                                                     int splits, float* __restrict__ partial) {
+    constexpr int ROWB = BKT * 2;                 // bytes per tile row
+    constexpr int CPR = BKT / 8;                  // 16-byte chunks per row
+    constexpr int RPI = 1024 / ROWB;              // rows per wave-instruction (1 KiB)
+    constexpr int LPO = 32 / RPI;                 // loads per operand per lane per K-step (each wave stages 32 rows)
+    constexpr int TILE_BYTES = BM * ROWB;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int KSTEPS = BKT / 32;              // MFMA k-steps per K-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -54,22 +64,22 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
     const long long M = (long long)N * H * W;
     const int K = TAPS * Cin;
-    const int kc = Cin / BK;                 // K-steps per tap
+    const int kc = Cin / BKT;                // K-steps per tap
     const int KI = TAPS * kc;
 
-    // ---- loader role: this lane stages rows {wave*32 + i*16 + (lane>>2)}, 16-byte slot (lane&3) of each tile.
-    // Running source pointers: advanced by BK halfs per K-step, re-derived once per filter tap (uniform branch).
-    const int lrow = lane >> 2, lpos = lane & 3;
-    int py[2], pxx[2];
-    long long pbase[2];                      // element offset of (pixel, channel-chunk), or -1 for rows beyond M
-    const half_t* bp[2];
-    const half_t* ap[2];
-    int astep[2];
+    // ---- loader role: this lane stages rows {wave*32 + i*RPI + lane/CPR}, 16-byte slot (lane % CPR) of each tile.
+    // Running source pointers: advanced by BKT halfs per K-step, re-derived once per filter tap (uniform branch).
+    const int lrow = lane / CPR, lpos = lane % CPR;
+    int py[LPO], pxx[LPO];
+    long long pbase[LPO];
+    const half_t* bp[LPO];
+    const half_t* ap[LPO];
+    int astep[LPO];
     const long long zoff = zero_page - X;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = wave * 32 + i * 16 + lrow;
-        const int c = lpos ^ swz(r);
+    for (int i = 0; i < LPO; ++i) {
+        const int r = wave * 32 + i * RPI + lrow;
+        const int c = lpos ^ swz<BKT>(r);
         const long long m = (long long)m0 + r;
         const bool inm = m < M;
         const long long mm = inm ? m : 0;
@@ -83,28 +93,28 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     auto set_tap = [&](int tap) {
         const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < LPO; ++i) {
             const int yy = py[i] + dy, xx = pxx[i] + dx;
             const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
             const long long off = pbase[i] + ((long long)dy * W + dx) * Cin;
             ap[i] = X + (ok ? off : zoff);
-            astep[i] = ok ? BK : 0;
+            astep[i] = ok ? BKT : 0;
         }
     };
-    char* const wave_dst = smem + (wave * 2) * 1024;
+    char* const wave_dst = smem + wave * (32 * ROWB);
     // split-K: this workgroup reduces K-steps [it0, it1) (blockIdx.y = split); splits == 1 -> the whole K range
     const int it0 = (int)((long long)KI * blockIdx.y / splits), it1 = (int)((long long)KI * (blockIdx.y + 1) / splits);
     int ntap = it0 / kc, nc = it0 - (it0 / kc) * kc;
     set_tap(ntap);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { ap[i] += astep[i] * nc; bp[i] += (size_t)it0 * BK; }
+    for (int i = 0; i < LPO; ++i) { ap[i] += astep[i] * nc; bp[i] += (size_t)it0 * BKT; }
     auto issue = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < LPO; ++i) {
             glds16(ap[i], wave_dst + stage * STAGE_BYTES + i * 1024);
             glds16(bp[i], wave_dst + stage * STAGE_BYTES + TILE_BYTES + i * 1024);
             ap[i] += astep[i];
-            bp[i] += BK;
+            bp[i] += BKT;
         }
         if (++nc == kc) {
             nc = 0;
@@ -112,8 +122,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
         }
     };
 
-    // ---- consumer role: fragment byte offset inside a 16-row group (row = lane&15, k-chunk = lane>>4)
-    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz(lane & 15)) << 4);
+    // ---- consumer role: fragment byte offset inside a 16-row group (row = lane&15, k-chunk = lane>>4 (+4 per k-step))
+    int frag_off[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk)
+        frag_off[kk] = (lane & 15) * ROWB + ((((lane >> 4) + 4 * kk) ^ swz<BKT>(lane & 15)) << 4);
     float4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -126,17 +139,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // stage `cur` landed; everyone is done reading stage cur^1
         if (it + 1 < it1) issue(cur ^ 1);
-        const char* As = smem + cur * STAGE_BYTES + (wm * 64) * 64 + frag_off;
-        const char* Bs = smem + cur * STAGE_BYTES + TILE_BYTES + (wn * 64) * 64 + frag_off;
-        half8 a[4], b[4];
+        const char* As = smem + cur * STAGE_BYTES + (wm * 64) * ROWB;
+        const char* Bs = smem + cur * STAGE_BYTES + TILE_BYTES + (wn * 64) * ROWB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * 64);
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            half8 a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * 64);
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * ROWB + frag_off[kk]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         cur ^= 1;
     }
     __syncthreads();                                       // all fragment reads done before the tile is reused
@@ -216,29 +232,33 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     }
 }
 
+int g_force_bk = 0;   // test hook: 32 / 64 forces the K-step, 0 = automatic
+
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
                size_t splitk_ws_floats) {
     PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
-    PD_REQUIRE(Cin % BK == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
+    PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
     const long long M = (long long)N * H * W;
     const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = Cout_pad / BN;
     const int total = m_tiles * n_tiles;
+    const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
     // small-M layers (16x16 / 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups
-    const int KI = taps * (Cin / BK);
+    const int KI = taps * (Cin / bk);
     int splits = 1;
     if (splitk_ws != nullptr && total < 384) {
-        splits = std::min(std::min((640 + total - 1) / total, KI / 4), 16);
+        splits = std::min(std::min((640 + total - 1) / total, KI / 2), 16);
         while (splits > 1 && (size_t)splits * M * Cout > splitk_ws_floats) --splits;
         if (splits < 1) splits = 1;
     }
     float* partial = splits > 1 ? splitk_ws : nullptr;
     dim3 grid(total, splits);
-    if (taps == 9)
-        k_conv_igemm<9><<<grid, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial);
-    else
-        k_conv_igemm<1><<<grid, 256, SMEM_BYTES, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial);
+    const size_t smem = bk == 64 ? (size_t)65536 : (size_t)EPI_BYTES;
+#define LAUNCH(T, B) k_conv_igemm<T, B><<<grid, 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial)
+    if (taps == 9) { if (bk == 64) LAUNCH(9, 64); else LAUNCH(9, 32); }
+    else { if (bk == 64) LAUNCH(1, 64); else LAUNCH(1, 32); }
+#undef LAUNCH
     if (splits > 1) {
         const long long tot = M * (Cout >> 3);
         k_splitk_reduce<<<(int)std::min<long long>((tot + 255) / 256, 2048), 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y);

@@ -625,6 +625,9 @@ extern "C" int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed, const 
     return conv_igemm((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
                       Cout_pad, taps, (const half_t*)zero_page, as_stream(stream));
 }
+namespace pdnn { extern int g_force_bk; }
+/* tuning / test hook: force the conv K-step (32 or 64; 0 = automatic). Returns the previous value. */
+extern "C" int pdhip_debug_set_conv_bk(int bk) { int old = pdnn::g_force_bk; pdnn::g_force_bk = bk; return old; }
 extern "C" int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed, void* stream) {
     PD_REQUIRE(w_oihw && w_packed, "pdhip_pack_conv_weight_f16: null argument");
     k_pack_conv<<<grid_for((long long)Cout * Cin * taps), 256, 0, as_stream(stream)>>>(w_oihw, 0, Cout, Cin, taps, (half_t*)w_packed);
