@@ -39,8 +39,8 @@ __device__ __forceinline__ int swz(int row) {
     return (row >> 1) & 7;
 }
 
-template <int TAPS, int BKT>
-__global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
+template <int TAPS, int BKT, int NSTAGE, int WMW>
+__global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
                                                     const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                     half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
                                                     int n_tiles, int total_tiles, const half_t* __restrict__ zero_page,
@@ -48,9 +48,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     constexpr int ROWB = BKT * 2;                 // bytes per tile row
     constexpr int CPR = BKT / 8;                  // 16-byte chunks per row
     constexpr int RPI = 1024 / ROWB;              // rows per wave-instruction (1 KiB)
-    constexpr int LPO = 32 / RPI;                 // loads per operand per lane per K-step (each wave stages 32 rows)
-    constexpr int TILE_BYTES = BM * ROWB;
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int BMT = 64 * WMW;                 // output rows per workgroup: 128 (4 waves) or 256 (8 waves)
+    constexpr int NWAVES = 2 * WMW;
+    constexpr int LPO = 32 / RPI;                 // A loads per lane per K-step (each wave stages BMT/NWAVES = 32 rows)
+    constexpr int BROWS = BN / NWAVES;            // B rows staged per wave: 32 or 16
+    constexpr int LPB = BROWS / RPI;              // B loads per lane per K-step
+    constexpr int A_BYTES = BMT * ROWB;
+    constexpr int TILE_BYTES = A_BYTES;           // offset of the B tile inside a stage
+    constexpr int STAGE_BYTES = A_BYTES + BN * ROWB;
     constexpr int KSTEPS = BKT / 32;              // MFMA k-steps per K-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
         const int b = blockIdx.x, q = total_tiles >> 3, r = total_tiles & 7, xcd = b & 7, i = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
-    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    const int m0 = (tile / n_tiles) * BMT, n0 = (tile % n_tiles) * BN;
     const long long M = (long long)N * H * W;
     const int K = TAPS * Cin;
     const int kc = Cin / BKT;                // K-steps per tap
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     const int lrow = lane / CPR, lpos = lane % CPR;
     int py[LPO], pxx[LPO];
     long long pbase[LPO];
-    const half_t* bp[LPO];
+    const half_t* bp[LPB];
     const half_t* ap[LPO];
     int astep[LPO];
     const long long zoff = zero_page - X;
@@ -88,7 +93,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
         py[i] = inm ? rem / W : -100000;
         pxx[i] = rem - (rem / W) * W;
         pbase[i] = (((long long)img * H + rem / W) * W + pxx[i]) * Cin + c * 8;
-        bp[i] = Wt + (size_t)(n0 + r) * K + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < LPB; ++i) {
+        const int r = wave * BROWS + i * RPI + lrow;
+        bp[i] = Wt + (size_t)(n0 + r) * K + (lpos ^ swz<BKT>(r)) * 8;
     }
     auto set_tap = [&](int tap) {
         const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
@@ -102,18 +111,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
         }
     };
     char* const wave_dst = smem + wave * (32 * ROWB);
+    char* const wave_dst_b = smem + TILE_BYTES + wave * (BROWS * ROWB);
     // split-K: this workgroup reduces K-steps [it0, it1) (blockIdx.y = split); splits == 1 -> the whole K range
     const int it0 = (int)((long long)KI * blockIdx.y / splits), it1 = (int)((long long)KI * (blockIdx.y + 1) / splits);
     int ntap = it0 / kc, nc = it0 - (it0 / kc) * kc;
     set_tap(ntap);
 #pragma unroll
-    for (int i = 0; i < LPO; ++i) { ap[i] += astep[i] * nc; bp[i] += (size_t)it0 * BKT; }
+    for (int i = 0; i < LPO; ++i) ap[i] += astep[i] * nc;
+#pragma unroll
+    for (int i = 0; i < LPB; ++i) bp[i] += (size_t)it0 * BKT;
     auto issue = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < LPO; ++i) {
             glds16(ap[i], wave_dst + stage * STAGE_BYTES + i * 1024);
-            glds16(bp[i], wave_dst + stage * STAGE_BYTES + TILE_BYTES + i * 1024);
             ap[i] += astep[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LPB; ++i) {
+            glds16(bp[i], wave_dst_b + stage * STAGE_BYTES + i * 1024);
             bp[i] += BKT;
         }
         if (++nc == kc) {
@@ -133,12 +148,31 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
-    int cur = 0;
+    // Software pipeline: NSTAGE LDS stages, loads run NSTAGE-1 K-steps ahead and stay in flight ACROSS the barrier
+    // (counted s_waitcnt vmcnt + raw s_barrier; __syncthreads() would drain the LDS-DMA queue -- cdna guide T3/T4).
+    constexpr int D = NSTAGE - 1;                          // prefetch distance
+    constexpr int OPS = LPO + LPB;                         // VMEM ops per lane per stage
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (it0 + d < it1) issue(d);
+    int cur = 0, nxt = D % NSTAGE;
     for (int it = it0; it < it1; ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // stage `cur` landed; everyone is done reading stage cur^1
-        if (it + 1 < it1) issue(cur ^ 1);
+        const int inflight = min(D, it1 - it);             // stages issued and not yet consumed (incl. this one)
+        static_assert(OPS == 3 || OPS == 4 || OPS == 6 || OPS == 8, "unexpected loads per stage");
+        if (D >= 3 && inflight >= 3) {
+            if (OPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (OPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (OPS == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else if (D >= 2 && inflight == 2) {
+            if (OPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (OPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (OPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // stage `cur` landed for every wave; stage `nxt` is free again
+        asm volatile("" ::: "memory");
+        if (it + D < it1) issue(nxt);
         const char* As = smem + cur * STAGE_BYTES + (wm * 64) * ROWB;
         const char* Bs = smem + cur * STAGE_BYTES + TILE_BYTES + (wn * 64) * ROWB;
 #pragma unroll
@@ -153,7 +187,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        cur ^= 1;
+        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
     }
     __syncthreads();                                       // all fragment reads done before the tile is reused
 
@@ -187,9 +222,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(const half_t* __restrict__ X
     }
     __syncthreads();
     const int col8 = (tid & 15) * 8;
+    constexpr int RPP = NWAVES * 4;                        // rows per pass (threads / 16)
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = p * 16 + (tid >> 4);
+    for (int p = 0; p < BMT / RPP; ++p) {
+        const int row = p * RPP + (tid >> 4);
         const long long m = (long long)m0 + row;
         if (m < M && n0 + col8 < Cout) {
             half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
@@ -232,7 +268,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     }
 }
 
-int g_force_bk = 0;   // test hook: 32 / 64 forces the K-step, 0 = automatic
+int g_force_bk = 0;       // tuning hook: 32 / 64 forces the K-step, 0 = automatic
+int g_force_stages = 0;   // tuning hook: 2 / 3 / 4 LDS stages, 0 = automatic
+int g_force_wmw = 0;      // tuning hook: 2 (128-row tile, 4 waves) / 4 (256-row tile, 8 waves), 0 = automatic
 
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
@@ -241,9 +279,12 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
     const long long M = (long long)N * H * W;
-    const int m_tiles = (int)((M + BM - 1) / BM), n_tiles = Cout_pad / BN;
-    const int total = m_tiles * n_tiles;
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
+    int wmw = g_force_wmw ? g_force_wmw : 2;
+    if (wmw != 2 && wmw != 4) wmw = 2;
+    const int bmt = 64 * wmw;
+    const int m_tiles = (int)((M + bmt - 1) / bmt), n_tiles = Cout_pad / BN;
+    const int total = m_tiles * n_tiles;
     // small-M layers (16x16 / 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups
     const int KI = taps * (Cin / bk);
     int splits = 1;
@@ -254,10 +295,25 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     }
     float* partial = splits > 1 ? splitk_ws : nullptr;
     dim3 grid(total, splits);
-    const size_t smem = bk == 64 ? (size_t)65536 : (size_t)EPI_BYTES;
-#define LAUNCH(T, B) k_conv_igemm<T, B><<<grid, 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial)
-    if (taps == 9) { if (bk == 64) LAUNCH(9, 64); else LAUNCH(9, 32); }
-    else { if (bk == 64) LAUNCH(1, 64); else LAUNCH(1, 32); }
+    int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);
+    if (stages < 2) stages = 2;
+    if (stages > 4) stages = 4;
+    const size_t stage_bytes = (size_t)(bmt + BN) * bk * 2;
+    while (stages > 2 && stages * stage_bytes > 160 * 1024) --stages;
+    const size_t smem = std::max<size_t>((size_t)stages * stage_bytes, (size_t)bmt * CS_LD * 2);
+#define LAUNCH(T, B, S, W_)                                                                                               \
+    do {                                                                                                                  \
+        auto kern = k_conv_igemm<T, B, S, W_>;                                                                            \
+        if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        kern<<<grid, W_ * 128, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial); \
+    } while (0)
+#define LAUNCH_S(T, B, W_)                                                                                                \
+    do { if (stages == 2) LAUNCH(T, B, 2, W_); else if (stages == 3) LAUNCH(T, B, 3, W_); else LAUNCH(T, B, 4, W_); } while (0)
+#define LAUNCH_W(T, B) do { if (wmw == 2) LAUNCH_S(T, B, 2); else LAUNCH_S(T, B, 4); } while (0)
+    if (taps == 9) { if (bk == 64) LAUNCH_W(9, 64); else LAUNCH_W(9, 32); }
+    else { if (bk == 64) LAUNCH_W(1, 64); else LAUNCH_W(1, 32); }
+#undef LAUNCH_W
+#undef LAUNCH_S
 #undef LAUNCH
     if (splits > 1) {
         const long long tot = M * (Cout >> 3);

@@ -625,7 +625,9 @@ extern "C" int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed, const 
     return conv_igemm((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
                       Cout_pad, taps, (const half_t*)zero_page, as_stream(stream));
 }
-namespace pdnn { extern int g_force_bk; }
+namespace pdnn { extern int g_force_bk; extern int g_force_stages; extern int g_force_wmw; }
+extern "C" int pdhip_debug_set_conv_tile(int wmw) { int old = pdnn::g_force_wmw; pdnn::g_force_wmw = wmw; return old; }
+extern "C" int pdhip_debug_set_conv_stages(int st) { int old = pdnn::g_force_stages; pdnn::g_force_stages = st; return old; }
 /* tuning / test hook: force the conv K-step (32 or 64; 0 = automatic). Returns the previous value. */
 extern "C" int pdhip_debug_set_conv_bk(int bk) { int old = pdnn::g_force_bk; pdnn::g_force_bk = bk; return old; }
 extern "C" int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed, void* stream) {

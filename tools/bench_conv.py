@@ -11,11 +11,13 @@ SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (8, 256, 256, 256, 256, 9), (8, 256, 256, 512, 256, 9), (8, 128, 128, 256, 256, 9), (8, 64, 64, 512, 512, 9),
     (8, 64, 64, 1024, 512, 9), (8, 32, 32, 512, 512, 9), (8, 128, 128, 512, 256, 9), (8, 256, 256, 512, 256, 1),
     (8, 32, 32, 512, 1536, 1)]
-ap = argparse.ArgumentParser(); ap.add_argument('--bk', type=int, nargs='*', default=[32, 0]); ap.add_argument('--iters', type=int, default=20)
+ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64x2x2', '64x2x4', '64x3x4', '32x3x4', '32x4x4']); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--shapes', type=int, nargs='*', default=None)
 a = ap.parse_args()
 dev = 'cuda:0'
 zp = torch.zeros(128, dtype=torch.float16, device=dev)
-for (N, H, W, Cin, Cout, taps) in SHAPES:
+for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
+    if a.shapes is not None and si not in a.shapes:
+        continue
     x = torch.randn((N, H, W, Cin), device=dev).half()
     pad = (Cout + 127) // 128 * 128
     w = (torch.randn((pad, taps * Cin), device=dev) * 0.05).half()
@@ -23,8 +25,9 @@ for (N, H, W, Cin, Cout, taps) in SHAPES:
     y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev)
     fl = 2.0 * N * H * W * Cout * taps * Cin
     res = []
-    for bk in a.bk:
-        L.pdhip_debug_set_conv_bk(bk)
+    for cfg in a.cfg:
+        bk, st, wm = (int(v) for v in cfg.split('x'))
+        L.pdhip_debug_set_conv_bk(bk); L.pdhip_debug_set_conv_stages(st); L.pdhip_debug_set_conv_tile(wm)
         for _ in range(3):
             L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), None, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), None)
         torch.cuda.synchronize()
@@ -34,6 +37,6 @@ for (N, H, W, Cin, Cout, taps) in SHAPES:
             L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), None, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        res.append(f"bk={bk or 'auto'}: {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF")
+        res.append(f"{cfg}: {fl/ms/1e9:6.0f}")
     print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} taps{taps} ({fl/1e9:7.1f} GFLOP)  " + " | ".join(res))
-L.pdhip_debug_set_conv_bk(0)
+L.pdhip_debug_set_conv_bk(0); L.pdhip_debug_set_conv_stages(0); L.pdhip_debug_set_conv_tile(0)
