@@ -16,7 +16,11 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 // taps: 1 (1x1 conv / linear over pixels) or 9 (3x3, pad 1).  Cin % 32 == 0.
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
-               float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+               float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr);
+// combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
+// the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).
+int gn_finalize_oct(const float* partA, int Ca, const float* partB, int Cb, int chunks, int N, int HW, float eps, float* stats,
+                    hipStream_t s);
 
 // ---- normalisation / elementwise (nn_norm.hip)
 // GroupNorm(32) statistics of X [N,HW,C] f16 -> stats [N][32][2] (mean, rstd) f32.  ws: N*chunks*32*2 floats.

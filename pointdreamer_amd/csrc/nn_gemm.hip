@@ -44,7 +44,7 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
                                                     const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                     half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
                                                     int n_tiles, int total_tiles, const half_t* __restrict__ zero_page,
-                                                    int splits, float* __restrict__ partial) {
+                                                    int splits, float* __restrict__ partial, float* __restrict__ gn_part) {
     constexpr int ROWB = BKT * 2;                 // bytes per tile row
     constexpr int CPR = BKT / 8;                  // 16-byte chunks per row
     constexpr int RPI = 1024 / ROWB;              // rows per wave-instruction (1 KiB)
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
     __syncthreads();
     const int col8 = (tid & 15) * 8;
     constexpr int RPP = NWAVES * 4;                        // rows per pass (threads / 16)
+    float gs = 0.f, gq = 0.f;                              // fused GroupNorm partial statistics of this thread's 8 channels
 #pragma unroll
     for (int p = 0; p < BMT / RPP; ++p) {
         const int row = p * RPP + (tid >> 4);
@@ -236,6 +237,26 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
             *reinterpret_cast<half8*>(Y + o) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
+        }
+    }
+    if (gn_part != nullptr) {
+        // Fused GroupNorm statistics: per-(image, row-chunk, channel octet) sum / sum of squares of the tile just written,
+        // layout [img][chunk][Cout/8][2].  Any GroupNorm(32) whose group size is a multiple of 8 channels -- also over a
+        // channel concat of two such tensors -- is assembled from these by gn_finalize_oct without re-reading the tensor.
+        // Host guarantees the whole tile lies inside one image.
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid * 2] = gs; red[tid * 2 + 1] = gq;
+        __syncthreads();
+        if (tid < 16 && n0 + tid * 8 < Cout) {
+            float s1 = 0.f, q1 = 0.f;
+            for (int r = 0; r < RPP; ++r) { s1 += red[(r * 16 + tid) * 2]; q1 += red[(r * 16 + tid) * 2 + 1]; }
+            const int hw = H * W, chunks = hw / BMT;
+            const int img = m0 / hw, chunk = (m0 - img * hw) / BMT;
+            float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + tid) * 2;
+            dst[0] = s1; dst[1] = q1;
         }
     }
 }
@@ -274,7 +295,7 @@ int g_force_wmw = 0;      // tuning hook: 2 (128-row tile, 4 waves) / 4 (256-row
 
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
-               size_t splitk_ws_floats) {
+               size_t splitk_ws_floats, float* gn_part, int* gn_fused) {
     PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
     PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
@@ -295,6 +316,10 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     }
     float* partial = splits > 1 ? splitk_ws : nullptr;
     dim3 grid(total, splits);
+    // fused GroupNorm partial statistics: only when a tile never straddles two images and maps to whole groups
+    const bool fuse = gn_part != nullptr && splits == 1 && ((long long)H * W) % bmt == 0;
+    if (gn_fused) *gn_fused = fuse ? (int)(((long long)H * W) / bmt) : 0;     // number of partial chunks per image
+    float* gnp = fuse ? gn_part : nullptr;
     int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);
     if (stages < 2) stages = 2;
     if (stages > 4) stages = 4;
@@ -305,7 +330,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     do {                                                                                                                  \
         auto kern = k_conv_igemm<T, B, S, W_>;                                                                            \
         if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, W_ * 128, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial); \
+        kern<<<grid, W_ * 128, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp); \
     } while (0)
 #define LAUNCH_S(T, B, W_)                                                                                                \
     do { if (stages == 2) LAUNCH(T, B, 2, W_); else if (stages == 3) LAUNCH(T, B, 3, W_); else LAUNCH(T, B, 4, W_); } while (0)

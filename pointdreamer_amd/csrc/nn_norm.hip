@@ -90,6 +90,42 @@ int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, flo
     return PDHIP_OK;
 }
 
+// stats from the conv epilogue's octet partials; thread (slice j = tid>>5, group g = tid&31), fixed-order combine
+__global__ __launch_bounds__(256) void k_gn_finalize_oct(const float* __restrict__ partA, int Ca, const float* __restrict__ partB,
+                                                         int Cb, int chunks, int HW, float eps, float* __restrict__ stats) {
+    __shared__ double s_s[8][32], s_q[8][32];
+    const int n = blockIdx.x, g = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int C = Ca + Cb, opg = (C / 32) >> 3;           // octets per group
+    const int oa = Ca >> 3, ob = Cb >> 3;
+    double ds = 0.0, dq = 0.0;
+    for (int c = j; c < chunks; c += 8)
+        for (int k = 0; k < opg; ++k) {
+            const int o = g * opg + k;
+            const float* src = (o < oa) ? partA + (((size_t)n * chunks + c) * oa + o) * 2
+                                        : partB + (((size_t)n * chunks + c) * ob + (o - oa)) * 2;
+            ds += (double)src[0]; dq += (double)src[1];
+        }
+    s_s[j][g] = ds; s_q[j][g] = dq;
+    __syncthreads();
+    if (j == 0) {
+        for (int k = 1; k < 8; ++k) { ds += s_s[k][g]; dq += s_q[k][g]; }
+        const double cnt = (double)HW * (C / 32);
+        const double mean = ds / cnt;
+        double var = dq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((size_t)n * 32 + g) * 2] = (float)mean;
+        stats[((size_t)n * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+int gn_finalize_oct(const float* partA, int Ca, const float* partB, int Cb, int chunks, int N, int HW, float eps, float* stats,
+                    hipStream_t s) {
+    PD_REQUIRE(((Ca + Cb) / 32) % 8 == 0 && Ca % 8 == 0 && Cb % 8 == 0 && (Ca + Cb) % 32 == 0, "gn_finalize_oct: group size must be a multiple of 8");
+    k_gn_finalize_oct<<<N, 256, 0, s>>>(partA, Ca, partB, Cb, chunks, HW, eps, stats);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
 // grid (pixel chunks, N).  thread -> (pixel sub-slot, channel octet): the octet's affine constants live in

@@ -23,7 +23,9 @@ struct ResB { std::string name; int cin, cout, mode; NormW n1, n2; ConvW c1, c2,
 struct AttB { std::string name; int c; NormW n; ConvW qkv, proj; };
 struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 
-struct Act { half_t* p; int C, H, W; };
+// gn_part: octet partial sums fused into the producing conv's epilogue ([N][chunks][C/8][2]); for a channel concat the
+// second source's partials are gn_partB (first Ca channels come from gn_part)
+struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chunks = 0; const float* gn_partB = nullptr; int Ca = 0; };
 
 struct Prof { std::vector<hipEvent_t> ev; size_t used = 0; double flops = 0; bool on = false; };
 
@@ -151,16 +153,26 @@ int prof_end(Ctx& c) {
     return PDHIP_OK;
 }
 
-int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out) {
-    out->C = w.cout; out->H = x.H; out->W = x.W;
+int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false) {
+    out->C = w.cout; out->H = x.H; out->W = x.W; out->gn_part = nullptr; out->gn_chunks = 0; out->gn_partB = nullptr; out->Ca = 0;
     out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
+    float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 127) / 128) * (w.cout / 8) * 2 * 2)) : nullptr;
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
     if (w.taps == 9) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
+    int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
-                        c.u->splitk_ws, c.u->splitk_floats);
+                        c.u->splitk_ws, c.u->splitk_floats, part, &fused);
+    if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = w.cout; }
     if (w.taps == 9) PD_TRY(prof_end(c));
     return rc;
+}
+
+// GroupNorm statistics of x: from the fused conv-epilogue partials when available, else a pass over the tensor
+int run_gn_stats(Ctx& c, const Act& x) {
+    if (x.gn_part != nullptr && ((x.C / 32) % 8) == 0)
+        return gn_finalize_oct(x.gn_part, x.Ca, x.gn_partB, x.C - x.Ca, x.gn_chunks, c.N, x.H * x.W, 1e-5f, c.u->stats, c.s);
+    return gn_stats(x.p, c.N, x.H * x.W, x.C, 1e-5f, c.u->stats, c.u->gn_ws, c.u->gn_ws_floats, c.s);
 }
 
 int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, int silu, int resample, Act* out) {
@@ -170,7 +182,7 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
     out->p = arena_take(c.u, (size_t)c.N * out->H * out->W * x.C);
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
-    PD_TRY(gn_stats(x.p, c.N, x.H * x.W, x.C, 1e-5f, c.u->stats, c.u->gn_ws, c.u->gn_ws_floats, c.s));
+    PD_TRY(run_gn_stats(c, x));
     return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s);
 }
 
@@ -182,13 +194,13 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
         xr.p = arena_take(c.u, (size_t)c.N * xr.H * xr.W * x.C);
         if (!c.dry) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
     }
-    PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1));
+    PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
     const float* film = c.dry ? nullptr : c.u->emb_all + rb.emb_off;
     if (!c.dry) PD_REQUIRE(rb.have_ew && rb.have_eb, "unet: emb_layers of %s not loaded", rb.name.c_str());
     PD_TRY(run_gn(c, h1, rb.n2, film, c.u->emb_rows, 1, 0, &h2));
     sk = xr;
     if (rb.has_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
-    return run_conv(c, h2, rb.c2, sk.p, out);
+    return run_conv(c, h2, rb.c2, sk.p, out, true);
 }
 
 int run_att(Ctx& c, const Act& x, AttB& ab, Act* out) {
@@ -198,7 +210,7 @@ int run_att(Ctx& c, const Act& x, AttB& ab, Act* out) {
     a = x;
     a.p = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);
     if (!c.dry) PD_TRY(attention(qkv.p, a.p, c.N, x.H * x.W, x.C, c.u->head, c.s));
-    return run_conv(c, a, ab.proj, x.p, out);
+    return run_conv(c, a, ab.proj, x.p, out, true);
 }
 
 int run_blocks(Ctx& c, std::vector<Block>& blocks, Act* h, const float* x_nchw) {
@@ -242,13 +254,16 @@ int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* ou
     for (auto& blk : u->output) {
         Act sk = hs.back(); hs.pop_back();
         Act cat{arena_take(u, (size_t)N * h.H * h.W * (h.C + sk.C)), h.C + sk.C, h.H, h.W};
+        if (h.gn_part && sk.gn_part && !h.gn_partB && !sk.gn_partB && h.gn_chunks == sk.gn_chunks) {
+            cat.gn_part = h.gn_part; cat.gn_partB = sk.gn_part; cat.Ca = h.C; cat.gn_chunks = h.gn_chunks;
+        }
         if (!dry) PD_TRY(concat_channels(h.p, h.C, sk.p, sk.C, (long long)N * h.H * h.W, cat.p, s));
         h = cat;
         PD_TRY(run_blocks(c, blk, &h, x));
     }
     if (!dry) {
         PD_REQUIRE(u->out_norm.have_g && u->out_norm.have_b && u->have_ow && u->have_ob, "unet: output head not loaded");
-        PD_TRY(gn_stats(h.p, N, h.H * h.W, h.C, 1e-5f, u->stats, u->gn_ws, u->gn_ws_floats, s));
+        PD_TRY(run_gn_stats(c, h));
         PD_TRY(gn_apply(h.p, u->stats, u->out_norm.g, u->out_norm.b, nullptr, 0, N, h.H, h.W, h.C, 1, 0, u->head_in, 1, s));
         PD_TRY(conv_out_3x3_f32(u->head_in, u->out_w, u->out_b, out, N, h.H, h.W, h.C, u->out_ch, s));
     }
