@@ -104,7 +104,7 @@ def main():
         inpainter = di.Inpainter(dev, ckpt_path=None, allow_random_weights=True, max_batch=views_here)
         inpainter.n_steps = args.ddnm_steps
     method = 'DDNM_inpaint' if args.workload == 'ddnm' else 'nearest'
-    cfg = dict(view_num=V, res=RES, cam_res=CAM_RES, point_validation_by_o3d=False, texture_gen_method=method, point_size=1,
+    cfg = dict(view_num=V, res=RES, cam_res=CAM_RES, point_validation_by_o3d=True, texture_gen_method=method, point_size=1,
                edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None,
                edge_dilate_kernels=[21], complete_unseen_by='unproject', inpainter=inpainter)
 
@@ -157,7 +157,7 @@ def main():
                    dtype="f16 (f32 accumulate; f32 GroupNorm/softmax statistics, f32 geometry)", data="synthetic",
                    config=dict(workload=f"configs[2]: synthetic 30k-point sphere shape, 8x256^2 views, texture_gen_method="
                                         f"'{method}' ({args.ddnm_steps} DDNM steps, 552.8M-param guided-diffusion UNet, random-init weights), "
-                                        f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, HPR off",
+                                        f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, hidden-point removal on (device)",
                                parallelism=f"{args.parallel}-parallel x{world}", views_per_unet_batch=views_here,
                                shapes_per_step=world if args.parallel == 'shapes' else 1),
                    roofline=roofline)

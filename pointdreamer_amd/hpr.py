@@ -1,23 +1,25 @@
 """Row P3b: hidden-point removal (Katz et al.), the reference's Open3D call at ours_utils.py:204-225.
 
-The reference runs this stage on the HOST (open3d -> qhull, float64, points copied to the CPU per view);
-this module keeps it a host stage and drives the same qhull library through scipy.spatial.ConvexHull:
-visible set = vertices of the convex hull of {spherical flip of the points} U {eye}.  It is not on the
-measured hot path (SURVEY 8d reports it separately) and a device kernel is listed as "next" in DESIGN.md.
-"""
+The reference copies the cloud to the host and runs qhull once per view; here all views are answered on the device by
+`pdhip_hidden_point_removal` (csrc/hpr.hip): spherical flip in float64, then one boolean-GJK containment query per
+point whose support function is a streaming argmax over the flipped cloud."""
 import numpy as np
 import torch
 
+from . import _lib
+from ._lib import ptr, as_u8, stream, check
+
 
 def hidden_point_removal(points, eye_positions, radius):
-    from scipy.spatial import ConvexHull
-    pts = points.detach().double().cpu().numpy()
-    out = np.zeros((len(eye_positions), pts.shape[0]), bool)
-    for i, eye in enumerate(eye_positions):
-        q = pts - np.asarray(eye, np.float64)[None]
-        n = np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-300)
-        flipped = q + 2 * (radius - n) * q / n
-        hull = ConvexHull(np.concatenate([flipped, np.zeros((1, 3))], 0))
-        vid = hull.vertices
-        out[i, vid[vid < pts.shape[0]]] = True
-    return torch.from_numpy(out).to(points.device)
+    """points [N,3] (GPU), eye_positions [V,3] (numpy / list, as create_cameras returns them) -> [V,N] bool."""
+    L = _lib.lib()
+    pts = points.detach().float().contiguous()
+    if not pts.is_cuda:
+        raise _lib.PdhipError("hidden_point_removal needs a GPU tensor; there is no CPU path")
+    eyes = torch.as_tensor(np.asarray(eye_positions, np.float64), dtype=torch.float64).reshape(-1, 3).to(pts.device).contiguous()
+    V, N = eyes.shape[0], pts.shape[0]
+    vis = torch.zeros((V, N), dtype=torch.bool, device=pts.device)
+    ws = torch.empty((L.pdhip_hpr_ws_bytes(V, N),), dtype=torch.uint8, device=pts.device)
+    check(L.pdhip_hidden_point_removal(ptr(pts), N, ptr(eyes), V, float(radius), ptr(as_u8(vis)), ptr(ws), stream()),
+          'pdhip_hidden_point_removal')
+    return vis

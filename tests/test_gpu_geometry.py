@@ -261,3 +261,31 @@ def test_full_size_shape_properties(pd):
     assert np.array_equal(N_(shr), o['shrinked'])
     assert np.array_equal(vid[m], o['point_view_ids'])
     assert np.array_equal(N_(atlas), o['atlas_img'])
+
+
+@pytest.mark.parametrize("n,shape", [(3000, 'sphere'), (30000, 'sphere'), (4000, 'blob')])
+def test_p3b_hidden_point_removal_vs_qhull(pd, n, shape):
+    """Device HPR (per-point GJK hull-vertex test) vs the oracle (same spherical flip + qhull through scipy).
+    open3d itself is absent (parity unpinned); agreement with qhull is required up to facet-tolerance cases."""
+    from pointdreamer_amd import hpr
+    rng = np.random.default_rng(n)
+    if shape == 'sphere':
+        pts, _ = pd['syn'].sphere_points(n, seed=n)
+    else:                                                  # a solid blob: most points are interior, hence hidden
+        pts = (rng.standard_normal((n, 3)) * 0.15).astype(np.float32)
+    _, _, eyes, _ = pd['cu'].create_cameras(8, 1.6, 512, device=DEV)
+    got = N_(hpr.hidden_point_removal(T(pts), eyes, 100))
+    want = oproj.point_validation_by_hpr(pts, eyes, 100)
+    assert got.shape == want.shape == (8, n)
+    mism = (got != want).mean()
+    assert mism < 2e-3, mism
+    frac = want.mean()
+    assert 0.05 < frac < 0.8
+    if shape == 'sphere':
+        # sanity: points facing the eye are kept, points on the far side are removed
+        for v in range(8):
+            facing = (pts @ eyes[v]) / (np.linalg.norm(pts, axis=1) * np.linalg.norm(eyes[v]))
+            assert got[v][facing > 0.6].mean() > 0.98 and got[v][facing < -0.3].mean() < 0.02
+    # through the reference-signature entry point
+    got2 = pd['ou'].get_point_validation_by_o3d(T(pts), eyes, 100)
+    assert np.array_equal(N_(got2), got)
