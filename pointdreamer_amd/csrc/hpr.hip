@@ -37,17 +37,41 @@ __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* _
     }
 }
 
-__global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flipped, int N, uint8_t* __restrict__ vis) {
+// queries that still need the hull test: all points, or only those a cheaper test (`skip`) has not already accepted
+__global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __restrict__ count, int* __restrict__ list,
+                              uint8_t* __restrict__ vis) {
+    const int v = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const bool sk = skip != nullptr && skip[(size_t)v * N + i];
+        const unsigned long long bal = __ballot(!sk);
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&count[v], __popcll(bal));
+        base = __shfl(base, 0);
+        if (!sk) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        else vis[(size_t)v * N + i] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+                                                 const int* __restrict__ list, uint8_t* __restrict__ vis) {
     __shared__ double s_dir[4][QPW][3];
+    __shared__ int s_q[4][QPW];
     const int v = blockIdx.y;
     const double* fx = flipped + (size_t)v * 3 * N;
     const double* fy = fx + N;
     const double* fz = fy + N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * 4 + wave) * QPW;
-    if (q0 >= N) return;
-    const int q = q0 + lane;
-    const bool owner = lane < QPW && q < N;
+    const int nq = count[v];
+    if (q0 >= nq) return;
+    const bool owner = lane < QPW && q0 + lane < nq;
+    const int q = owner ? list[(size_t)v * N + q0 + lane] : -1;
+    if (lane < QPW) s_q[wave][lane] = q;
+    __builtin_amdgcn_wave_barrier();
+    int qk[QPW];
+#pragma unroll
+    for (int k = 0; k < QPW; ++k) qk[k] = s_q[wave][k];
     // ---- per-query GJK state (meaningful in lanes < QPW)
     d3 pi = {0, 0, 0}, sa = {0, 0, 0}, sb = {0, 0, 0}, sc = {0, 0, 0}, sd = {0, 0, 0}, dir = {0, 0, 1};
     int dim = 0;                   // simplex size; phases: 0 -> fetch c, 1 -> fetch b, >= 2 -> main loop
@@ -73,7 +97,7 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
 #pragma unroll
             for (int k = 0; k < QPW; ++k) {
                 double val = dx[k] * x + dy[k] * y + dz[k] * z;
-                if (j == q0 + k) val = -1.0e300;                    // S_i excludes the point itself
+                if (j == qk[k]) val = -1.0e300;                     // S_i excludes the point itself
                 if (val > best[k]) { best[k] = val; bi[k] = j; }
             }
         }
@@ -136,10 +160,11 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
     if (owner) vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
 }
 
-extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) { return (size_t)V * 3 * (size_t)(N > 0 ? N : 1) * sizeof(double); }
+static size_t flipped_bytes(int V, int N) { return (((size_t)V * 3 * (size_t)(N > 0 ? N : 1) * sizeof(double)) + 255) & ~(size_t)255; }
+extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) { return flipped_bytes(V, N) + (size_t)V * ((size_t)N + 64) * sizeof(int); }
 
 extern "C" int pdhip_hidden_point_removal(const float* points, int N, const double* eyes_dev, int V, double radius,
-                                          uint8_t* visibility, void* ws, void* stream) {
+                                          const uint8_t* skip, uint8_t* visibility, void* ws, void* stream) {
     PD_REQUIRE(V > 0 && N >= 0, "pdhip_hidden_point_removal: bad sizes");
     if (N == 0) return PDHIP_OK;
     PD_REQUIRE(points && eyes_dev && visibility && ws, "pdhip_hidden_point_removal: null pointer");
@@ -147,8 +172,13 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     double* flipped = reinterpret_cast<double*>(ws);
     dim3 gf(min(cdiv(N, 256), 256), V);
     k_hpr_flip<<<gf, 256, 0, s>>>(points, N, eyes_dev, radius, flipped);
+    int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + flipped_bytes(V, N));
+    int* list = count + 64;
+    PD_HIP(hipMemsetAsync(count, 0, 64 * sizeof(int), s));
+    PD_REQUIRE(V <= 64, "pdhip_hidden_point_removal: at most 64 views");
+    k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);
     dim3 gg(cdiv(N, 4 * QPW), V);
-    k_hpr_gjk<<<gg, 256, 0, s>>>(flipped, N, visibility);
+    k_hpr_gjk<<<gg, 256, 0, s>>>(flipped, N, count, list, visibility);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -69,7 +69,8 @@ def _project_stage(coords, colors, vertices, faces, camera_info, view_num, res, 
     hard_r = ou.resize_masks(hard, res) if cam_res != res else hard
     pv, _ = ou.get_point_validation_by_depth(cam_res, puv, pdep, depth, offset=0.0001)
     if point_validation_by_o3d:
-        pv = torch.logical_or(pv, ou.get_point_validation_by_o3d(coords, camera_info['eye_positions'], hpr_radius))
+        from .hpr import hidden_point_removal
+        pv = hidden_point_removal(coords, camera_info['eye_positions'], hpr_radius, already_valid=pv)
     pp = ou.get_point_pixels(puv, res)
     sparse, m0, m2, sf = ou.get_sparse_images(pp, colors, pv, hard_r, None, view_num, res, point_size, edge_point_size,
                                               mask_ratio_thresh)

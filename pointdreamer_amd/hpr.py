@@ -10,8 +10,9 @@ from . import _lib
 from ._lib import ptr, as_u8, stream, check
 
 
-def hidden_point_removal(points, eye_positions, radius):
-    """points [N,3] (GPU), eye_positions [V,3] (numpy / list, as create_cameras returns them) -> [V,N] bool."""
+def hidden_point_removal(points, eye_positions, radius, already_valid=None):
+    """points [N,3] (GPU), eye_positions [V,3] (numpy / list, as create_cameras returns them) -> [V,N] bool.
+    already_valid [V,N] bool (optional): points another test accepted; they are not queried and the result is the OR."""
     L = _lib.lib()
     pts = points.detach().float().contiguous()
     if not pts.is_cuda:
@@ -20,6 +21,8 @@ def hidden_point_removal(points, eye_positions, radius):
     V, N = eyes.shape[0], pts.shape[0]
     vis = torch.zeros((V, N), dtype=torch.bool, device=pts.device)
     ws = torch.empty((L.pdhip_hpr_ws_bytes(V, N),), dtype=torch.uint8, device=pts.device)
-    check(L.pdhip_hidden_point_removal(ptr(pts), N, ptr(eyes), V, float(radius), ptr(as_u8(vis)), ptr(ws), stream()),
+    skip = None if already_valid is None else as_u8(already_valid.contiguous())
+    check(L.pdhip_hidden_point_removal(ptr(pts), N, ptr(eyes), V, float(radius), ptr(skip, allow_none=True), ptr(as_u8(vis)), ptr(ws),
+                                       stream()),
           'pdhip_hidden_point_removal')
     return vis

@@ -289,3 +289,15 @@ def test_p3b_hidden_point_removal_vs_qhull(pd, n, shape):
     # through the reference-signature entry point
     got2 = pd['ou'].get_point_validation_by_o3d(T(pts), eyes, 100)
     assert np.array_equal(N_(got2), got)
+
+
+def test_p3b_skip_mask_gives_the_or(pd):
+    from pointdreamer_amd import hpr
+    pts, _ = pd['syn'].sphere_points(5000, seed=77)
+    _, _, eyes, _ = pd['cu'].create_cameras(4, 1.6, 512, device=DEV)
+    full = hpr.hidden_point_removal(T(pts), eyes, 100)
+    pre = torch.from_numpy(np.random.default_rng(1).uniform(0, 1, (4, 5000)) > 0.5).to(DEV)
+    ored = hpr.hidden_point_removal(T(pts), eyes, 100, already_valid=pre)
+    assert torch.equal(ored, torch.logical_or(full, pre))
+    allv = hpr.hidden_point_removal(T(pts), eyes, 100, already_valid=torch.ones_like(pre))
+    assert bool(allv.all())
