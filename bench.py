@@ -30,7 +30,7 @@ UNET_FLOP_PER_FORWARD = 2.0 * 1119832768512            # 1 119 832 76
 PEAK_FP16_TFLOPS = 2500.0                              # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(sample_views=2):
+def cpu_baseline(sample_views=8):
     """Reference CPU 'nearest' path, restated by the oracle (kind = "port"), on a bounded sample:
     `sample_views` of the 8 views for the per-view stages (project/raster/sparse/nearest/texel visibility scale
     linearly in views) plus the full NBF + unproject + dilate at A=1024; extrapolated to one 8-view shape."""

@@ -18,10 +18,6 @@
 using namespace pdhip;
 namespace pdnn {
 
-#define BM 128
-#define BN 128
-#define CS_LD 136                          // epilogue tile leading dimension (halfs)
-#define EPI_BYTES (BM * CS_LD * 2)         // 34 816 B
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -39,8 +35,10 @@ __device__ __forceinline__ int swz(int row) {
     return (row >> 1) & 7;
 }
 
-template <int TAPS, int BKT, int NSTAGE, int WMW>
-__global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
+// Tile geometry: WM x WN waves, each wave owns TM x 4 accumulator tiles of 16x16 (wave tile TM*16 rows x 64 columns).
+//   <2,2,4> 128x128 / 4 waves      <4,2,4> 256x128 / 8 waves      <2,4,8> 256x256 / 8 waves (wave tile 128x64)
+template <int TAPS, int BKT, int NSTAGE, int WM, int WN, int TM>
+__global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
                                                     const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                     half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
                                                     int n_tiles, int total_tiles, const half_t* __restrict__ zero_page,
@@ -48,25 +46,29 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
     constexpr int ROWB = BKT * 2;                 // bytes per tile row
     constexpr int CPR = BKT / 8;                  // 16-byte chunks per row
     constexpr int RPI = 1024 / ROWB;              // rows per wave-instruction (1 KiB)
-    constexpr int BMT = 64 * WMW;                 // output rows per workgroup: 128 (4 waves) or 256 (8 waves)
-    constexpr int NWAVES = 2 * WMW;
-    constexpr int LPO = 32 / RPI;                 // A loads per lane per K-step (each wave stages BMT/NWAVES = 32 rows)
-    constexpr int BROWS = BN / NWAVES;            // B rows staged per wave: 32 or 16
+    constexpr int NWAVES = WM * WN;
+    constexpr int BMT = WM * TM * 16;             // output rows per workgroup
+    constexpr int BNT = WN * 64;                  // output columns per workgroup
+    constexpr int AROWS = BMT / NWAVES;           // A rows staged per wave
+    constexpr int BROWS = BNT / NWAVES;           // B rows staged per wave
+    constexpr int LPO = AROWS / RPI;              // A loads per lane per K-step
     constexpr int LPB = BROWS / RPI;              // B loads per lane per K-step
+    static_assert(AROWS % RPI == 0 && BROWS % RPI == 0 && LPO >= 1 && LPB >= 1, "tile rows must split into 1 KiB wave-instructions");
     constexpr int A_BYTES = BMT * ROWB;
     constexpr int TILE_BYTES = A_BYTES;           // offset of the B tile inside a stage
-    constexpr int STAGE_BYTES = A_BYTES + BN * ROWB;
+    constexpr int STAGE_BYTES = A_BYTES + BNT * ROWB;
+    constexpr int CS_LD = BNT + 8;                // epilogue tile leading dimension (halfs)
     constexpr int KSTEPS = BKT / 32;              // MFMA k-steps per K-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile id: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tile ids
     int tile;
     {
         const int b = blockIdx.x, q = total_tiles >> 3, r = total_tiles & 7, xcd = b & 7, i = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
-    const int m0 = (tile / n_tiles) * BMT, n0 = (tile % n_tiles) * BN;
+    const int m0 = (tile / n_tiles) * BMT, n0 = (tile % n_tiles) * BNT;
     const long long M = (long long)N * H * W;
     const int K = TAPS * Cin;
     const int kc = Cin / BKT;                // K-steps per tap
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
     const long long zoff = zero_page - X;
 #pragma unroll
     for (int i = 0; i < LPO; ++i) {
-        const int r = wave * 32 + i * RPI + lrow;
+        const int r = wave * AROWS + i * RPI + lrow;
         const int c = lpos ^ swz<BKT>(r);
         const long long m = (long long)m0 + r;
         const bool inm = m < M;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
             astep[i] = ok ? BKT : 0;
         }
     };
-    char* const wave_dst = smem + wave * (32 * ROWB);
+    char* const wave_dst = smem + wave * (AROWS * ROWB);
     char* const wave_dst_b = smem + TILE_BYTES + wave * (BROWS * ROWB);
     // split-K: this workgroup reduces K-steps [it0, it1) (blockIdx.y = split); splits == 1 -> the whole K range
     const int it0 = (int)((long long)KI * blockIdx.y / splits), it1 = (int)((long long)KI * (blockIdx.y + 1) / splits);
@@ -142,9 +144,9 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk)
         frag_off[kk] = (lane & 15) * ROWB + ((((lane >> 4) + 4 * kk) ^ swz<BKT>(lane & 15)) << 4);
-    float4_t acc[4][4];
+    float4_t acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -158,32 +160,34 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
     int cur = 0, nxt = D % NSTAGE;
     for (int it = it0; it < it1; ++it) {
         const int inflight = min(D, it1 - it);             // stages issued and not yet consumed (incl. this one)
-        static_assert(OPS == 3 || OPS == 4 || OPS == 6 || OPS == 8, "unexpected loads per stage");
+        static_assert(OPS == 3 || OPS == 4 || OPS == 6 || OPS == 8 || OPS == 12, "unexpected loads per stage");
         if (D >= 3 && inflight >= 3) {
             if (OPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (OPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (OPS == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (OPS == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         } else if (D >= 2 && inflight == 2) {
             if (OPS == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (OPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (OPS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (OPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // stage `cur` landed for every wave; stage `nxt` is free again
         asm volatile("" ::: "memory");
         if (it + D < it1) issue(nxt);
-        const char* As = smem + cur * STAGE_BYTES + (wm * 64) * ROWB;
+        const char* As = smem + cur * STAGE_BYTES + (wm * TM * 16) * ROWB;
         const char* Bs = smem + cur * STAGE_BYTES + TILE_BYTES + (wn * 64) * ROWB;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            half8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
+            half8 a[TM], b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * ROWB + frag_off[kk]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
@@ -198,10 +202,10 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + (lane & 15);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const long long m = (long long)m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                    const long long m = (long long)m0 + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + r;
                     if (m < M && n < Cout) P[(size_t)m * Cout + n] = acc[i][j][r];
                 }
         }
@@ -214,19 +218,20 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
         const int nl = wn * 64 + j * 16 + (lane & 15);
         const float bv = (bias != nullptr && n0 + nl < Cout) ? bias[n0 + nl] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = wm * 64 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * TM * 16 + i * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cs[(ml + r) * CS_LD + nl] = (half_t)(acc[i][j][r] + bv);
         }
     }
     __syncthreads();
-    const int col8 = (tid & 15) * 8;
-    constexpr int RPP = NWAVES * 4;                        // rows per pass (threads / 16)
+    constexpr int CT = BNT / 8;                            // column threads (one channel octet each)
+    constexpr int RPP = NWAVES * 64 / CT;                  // rows per pass
+    const int col8 = (tid % CT) * 8;
     float gs = 0.f, gq = 0.f;                              // fused GroupNorm partial statistics of this thread's 8 channels
 #pragma unroll
     for (int p = 0; p < BMT / RPP; ++p) {
-        const int row = p * RPP + (tid >> 4);
+        const int row = p * RPP + tid / CT;
         const long long m = (long long)m0 + row;
         if (m < M && n0 + col8 < Cout) {
             half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
@@ -250,9 +255,9 @@ __global__ __launch_bounds__(WMW * 128) void k_conv_igemm(const half_t* __restri
         float* red = reinterpret_cast<float*>(smem);
         red[tid * 2] = gs; red[tid * 2 + 1] = gq;
         __syncthreads();
-        if (tid < 16 && n0 + tid * 8 < Cout) {
+        if (tid < CT && n0 + tid * 8 < Cout) {
             float s1 = 0.f, q1 = 0.f;
-            for (int r = 0; r < RPP; ++r) { s1 += red[(r * 16 + tid) * 2]; q1 += red[(r * 16 + tid) * 2 + 1]; }
+            for (int r = 0; r < RPP; ++r) { s1 += red[(r * CT + tid) * 2]; q1 += red[(r * CT + tid) * 2 + 1]; }
             const int hw = H * W, chunks = hw / BMT;
             const int img = m0 / hw, chunk = (m0 - img * hw) / BMT;
             float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + tid) * 2;
@@ -291,20 +296,34 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 
 int g_force_bk = 0;       // tuning hook: 32 / 64 forces the K-step, 0 = automatic
 int g_force_stages = 0;   // tuning hook: 2 / 3 / 4 LDS stages, 0 = automatic
-int g_force_wmw = 0;      // tuning hook: 2 (128-row tile, 4 waves) / 4 (256-row tile, 8 waves), 0 = automatic
+int g_force_wmw = 0;      // tuning hook, tile geometry: 2 = 128x128/4 waves, 4 = 256x128/8 waves, 8 = 256x256/8 waves, 0 = automatic
+
+template <int TAPS, int BKT, int NSTAGE, int WM, int WN, int TM>
+static int launch_conv(dim3 grid, size_t smem, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias,
+                       const half_t* residual, half_t* Y, int N, int H, int W, int Cin, int Cout, int n_tiles, int total,
+                       const half_t* zero_page, int splits, float* partial, float* gnp) {
+    auto kern = k_conv_igemm<TAPS, BKT, NSTAGE, WM, WN, TM>;
+    if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    kern<<<grid, WM * WN * 64, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp);
+    return PDHIP_OK;
+}
 
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
                size_t splitk_ws_floats, float* gn_part, int* gn_fused) {
     PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
-    PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % BN == 0 && Cout_pad >= Cout,
+    PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
     const long long M = (long long)N * H * W;
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
-    int wmw = g_force_wmw ? g_force_wmw : 2;
-    if (wmw != 2 && wmw != 4) wmw = 2;
-    const int bmt = 64 * wmw;
-    const int m_tiles = (int)((M + bmt - 1) / bmt), n_tiles = Cout_pad / BN;
+    // tile geometry: 256x256 (wave tile 128x64: 25 % fewer LDS reads per MFMA, half the L2 traffic) once it still yields
+    // at least one workgroup per CU; 128x128 otherwise
+    int geo = g_force_wmw;
+    if (geo != 2 && geo != 4 && geo != 8)
+        geo = (Cout_pad % 256 == 0 && ((M + 255) / 256) * (Cout_pad / 256) >= 256) ? 8 : 2;
+    if (geo == 8 && Cout_pad % 256 != 0) geo = 2;
+    const int bmt = geo == 2 ? 128 : 256, bnt = geo == 8 ? 256 : 128;
+    const int m_tiles = (int)((M + bmt - 1) / bmt), n_tiles = Cout_pad / bnt;
     const int total = m_tiles * n_tiles;
     // small-M layers (16x16 / 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups
     const int KI = taps * (Cin / bk);
@@ -316,30 +335,28 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     }
     float* partial = splits > 1 ? splitk_ws : nullptr;
     dim3 grid(total, splits);
-    // fused GroupNorm partial statistics: only when a tile never straddles two images and maps to whole groups
+    // fused GroupNorm partial statistics: only when a tile never straddles two images
     const bool fuse = gn_part != nullptr && splits == 1 && ((long long)H * W) % bmt == 0;
     if (gn_fused) *gn_fused = fuse ? (int)(((long long)H * W) / bmt) : 0;     // number of partial chunks per image
     float* gnp = fuse ? gn_part : nullptr;
     int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);
     if (stages < 2) stages = 2;
     if (stages > 4) stages = 4;
-    const size_t stage_bytes = (size_t)(bmt + BN) * bk * 2;
+    const size_t stage_bytes = (size_t)(bmt + bnt) * bk * 2;
     while (stages > 2 && stages * stage_bytes > 160 * 1024) --stages;
-    const size_t smem = std::max<size_t>((size_t)stages * stage_bytes, (size_t)bmt * CS_LD * 2);
-#define LAUNCH(T, B, S, W_)                                                                                               \
-    do {                                                                                                                  \
-        auto kern = k_conv_igemm<T, B, S, W_>;                                                                            \
-        if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        kern<<<grid, W_ * 128, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp); \
-    } while (0)
-#define LAUNCH_S(T, B, W_)                                                                                                \
-    do { if (stages == 2) LAUNCH(T, B, 2, W_); else if (stages == 3) LAUNCH(T, B, 3, W_); else LAUNCH(T, B, 4, W_); } while (0)
-#define LAUNCH_W(T, B) do { if (wmw == 2) LAUNCH_S(T, B, 2); else LAUNCH_S(T, B, 4); } while (0)
-    if (taps == 9) { if (bk == 64) LAUNCH_W(9, 64); else LAUNCH_W(9, 32); }
-    else { if (bk == 64) LAUNCH_W(1, 64); else LAUNCH_W(1, 32); }
-#undef LAUNCH_W
-#undef LAUNCH_S
-#undef LAUNCH
+    const size_t smem = std::max<size_t>((size_t)stages * stage_bytes, (size_t)bmt * (bnt + 8) * 2);
+#define ARGS grid, smem, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp
+#define BY_STAGE(T, B, WM_, WN_, TM_)                                                   \
+    (stages == 2 ? launch_conv<T, B, 2, WM_, WN_, TM_>(ARGS) : stages == 3 ? launch_conv<T, B, 3, WM_, WN_, TM_>(ARGS) \
+                                                              : launch_conv<T, B, 4, WM_, WN_, TM_>(ARGS))
+#define BY_GEO(T, B) (geo == 2 ? BY_STAGE(T, B, 2, 2, 4) : geo == 4 ? BY_STAGE(T, B, 4, 2, 4) : BY_STAGE(T, B, 2, 4, 8))
+    int rc;
+    if (taps == 9) rc = (bk == 64) ? BY_GEO(9, 64) : BY_GEO(9, 32);
+    else rc = (bk == 64) ? BY_GEO(1, 64) : BY_GEO(1, 32);
+#undef BY_GEO
+#undef BY_STAGE
+#undef ARGS
+    if (rc) return rc;
     if (splits > 1) {
         const long long tot = M * (Cout >> 3);
         k_splitk_reduce<<<(int)std::min<long long>((tot + 255) / 256, 2048), 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y);

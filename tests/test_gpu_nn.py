@@ -256,13 +256,15 @@ def test_philox_normal_stream(nn):
     assert abs((a ** 4).mean().item() - 3.0) < 0.1
 
 
-@pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4)])
+@pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4),
+                                           (64, 2, 8)])
 def test_conv_igemm_all_kernel_variants(nn, bk, stages, wmw):
     """Every (K-step, pipeline depth, tile height) instantiation of the conv kernel computes the same convolution."""
     L = nn['L']
     old = (L.pdhip_debug_set_conv_bk(bk), L.pdhip_debug_set_conv_stages(stages), L.pdhip_debug_set_conv_tile(wmw))
     try:
-        for (N, H, W, Cin, Cout, k, res) in [(2, 16, 16, 128, 192, 3, True), (1, 24, 24, 64, 128, 1, False), (3, 8, 8, 256, 64, 3, False)]:
+        for (N, H, W, Cin, Cout, k, res) in [(2, 16, 16, 128, 192, 3, True), (1, 24, 24, 64, 128, 1, False), (3, 8, 8, 256, 64, 3, False),
+                                             (2, 16, 16, 128, 256, 3, True), (1, 20, 20, 64, 512, 1, False)]:
             g = torch.Generator().manual_seed(bk + stages + wmw + Cin)
             x = torch.randn((N, Cin, H, W), generator=g).half().float()
             w = (torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(Cin * k * k)).half().float()
