@@ -30,36 +30,38 @@ UNET_FLOP_PER_FORWARD = 2.0 * 1119832768512            # 1 119 832 76
 PEAK_FP16_TFLOPS = 2500.0                              # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(sample_views=8):
-    """Reference CPU 'nearest' path, restated by the oracle (kind = "port"), on a bounded sample:
-    `sample_views` of the 8 views for the per-view stages (project/raster/sparse/nearest/texel visibility scale
-    linearly in views) plus the full NBF + unproject + dilate at A=1024; extrapolated to one 8-view shape."""
+def cpu_baseline(repeats=2):
+    """Reference CPU 'nearest' path, restated by the oracle (kind = "port": the reference itself has no runnable CPU
+    pipeline -- demo.py:12,19 hard-code CUDA): one full 8-view shape at BASELINE sizes (project, raster, depth test +
+    hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF unproject, atlas dilate),
+    timed `repeats` times on the host (about 15 s of CPU work); median reported."""
     from pointdreamer_amd import synthetic
     from oracle import camera as ocam, project as oproj, sparse as osparse, inpaint as oinp, unproject as ounp
     torch.set_num_threads(1)
     sh = synthetic.make_shape(30000, 1024)
     V = 8
     cams, base_dirs, eyes, ups = ocam.create_cameras(V, 1.6, 512)
-    t0 = time.time()
-    sub = cams[:sample_views]
-    pr = oproj.project_batch(sub, sh['vertices'], sh['points'], True, 0.05)
-    hard, fid, depth = oproj.rasterize(pr['pos'], sh['faces'], 512)
-    hard_r = oproj.downsample_masks(hard, 256)
-    vis, _ = oproj.point_validation_by_depth(512, pr['point_uvs'], pr['point_depths'], depth, 0.0001)
-    pp = oproj.point_pixels_for_res(pr['point_uvs'], 256)
-    sp, m0, m2, sf = osparse.get_sparse_images(pp, sh['colors'], vis, hard_r, sample_views, 256, 1, 1, 0.82)
-    inp = np.stack([oinp.reference_nearest_inpaint_scipy(sp[i], m2[i]) for i in range(sample_views)]).astype(np.float32)
-    t_views = time.time() - t0
-    t1 = time.time()
-    o = ounp.unproject(inp, sh['f_normals'], 256, sub, 512, base_dirs[:sample_views], sh['gb_pos'], sh['mask'],
-                       sh['per_atlas_pixel_face_id'], pr['uv_centers'], pr['uv_scales'], 0.05, sf, depth, [21], True)
-    oinp.reference_nearest_inpaint_scipy(o['atlas_img'].transpose(2, 0, 1), sh['mask'][..., 0])
-    t_unproj = time.time() - t1
-    per_shape = t_views * (V / sample_views) + t_unproj * (0.5 + 0.5 * V / sample_views)
+    times = []
+    for _ in range(repeats):
+        t0 = time.time()
+        pr = oproj.project_batch(cams, sh['vertices'], sh['points'], True, 0.05)
+        hard, fid, depth = oproj.rasterize(pr['pos'], sh['faces'], 512)
+        hard_r = oproj.downsample_masks(hard, 256)
+        vis, _ = oproj.point_validation_by_depth(512, pr['point_uvs'], pr['point_depths'], depth, 0.0001)
+        vis = vis | oproj.point_validation_by_hpr(sh['points'], eyes, 100)
+        pp = oproj.point_pixels_for_res(pr['point_uvs'], 256)
+        sp, m0, m2, sf = osparse.get_sparse_images(pp, sh['colors'], vis, hard_r, V, 256, 1, 1, 0.82)
+        inp = np.stack([oinp.reference_nearest_inpaint_scipy(sp[i], m2[i]) for i in range(V)]).astype(np.float32)
+        o = ounp.unproject(inp, sh['f_normals'], 256, cams, 512, base_dirs, sh['gb_pos'], sh['mask'],
+                           sh['per_atlas_pixel_face_id'], pr['uv_centers'], pr['uv_scales'], 0.05, sf, depth, [21], True)
+        oinp.reference_nearest_inpaint_scipy(o['atlas_img'].transpose(2, 0, 1), sh['mask'][..., 0])
+        times.append(time.time() - t0)
+    per_shape = sorted(times)[len(times) // 2]
     return dict(value=3600.0 / per_shape, unit="shapes/hour", cores=1, kind="port",
-                sample=f"oracle CPU restatement, texture_gen_method='nearest' (scipy griddata), {sample_views}/8 views measured "
-                       f"({t_views:.1f}s per-view stages + {t_unproj:.1f}s NBF/unproject/dilate at A=1024) extrapolated to 8 views "
-                       f"= {per_shape:.1f} s/shape; no DDNM on the CPU (a CPU fp32 UNet forward is ~8 s, x800 per shape)")
+                sample=f"oracle CPU restatement of the reference's texture_gen_method='nearest' path (scipy griddata / qhull), one full "
+                       f"30k-point 8-view shape at A=1024, median of {repeats} runs = {per_shape:.2f} s/shape "
+                       f"(runs: {', '.join('%.2f' % t for t in times)} s); the CPU path has no diffusion "
+                       f"(a CPU fp32 UNet forward is ~8 s, x800 per DDNM shape)")
 
 
 def main():
@@ -142,8 +144,12 @@ def main():
         ms, flops, launches = inpainter.model.profile_read()
         inpainter.model.profile(False)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv.json')
+        if os.path.exists(pmc):          # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh)
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
         roofline = dict(bound="mfma", kernel="k_conv_igemm<9> (3x3 implicit-GEMM conv, f16 in / f32 acc)", achieved=achieved,
-                        peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=None,
+                        peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=traffic,
                         launches=int(launches), avg_launch_ms=ms / max(launches, 1),
                         flops_per_launch=flops / max(launches, 1),
                         unet_forward_tflops_effective=(UNET_FLOP_PER_FORWARD * views_here * args.ddnm_steps * args.steps) / dt / 1e12)
