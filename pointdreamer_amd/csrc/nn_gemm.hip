@@ -319,16 +319,16 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     // tile geometry: 256x256 (wave tile 128x64: 25 % fewer LDS reads per MFMA, half the L2 traffic) once it still yields
     // at least one workgroup per CU; 128x128 otherwise
     int geo = g_force_wmw;
-    if (geo != 2 && geo != 4 && geo != 8)
+    if (geo != 2 && geo != 4 && geo != 8 && geo != 16)
         geo = (Cout_pad % 256 == 0 && ((M + 255) / 256) * (Cout_pad / 256) >= 256) ? 8 : 2;
     if (geo == 8 && Cout_pad % 256 != 0) geo = 2;
-    const int bmt = geo == 2 ? 128 : 256, bnt = geo == 8 ? 256 : 128;
+    const int bmt = geo == 2 ? 128 : 256, bnt = geo == 8 ? 256 : 128;    // geo 16: 256x128, 4 waves with 128x64 wave tiles
     const int m_tiles = (int)((M + bmt - 1) / bmt), n_tiles = Cout_pad / bnt;
     const int total = m_tiles * n_tiles;
     // small-M layers (16x16 / 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups
     const int KI = taps * (Cin / bk);
     int splits = 1;
-    if (splitk_ws != nullptr && total < 384) {
+    if (splitk_ws != nullptr && total < (geo == 8 ? 256 : 384)) {
         splits = std::min(std::min((640 + total - 1) / total, KI / 2), 16);
         while (splits > 1 && (size_t)splits * M * Cout > splitk_ws_floats) --splits;
         if (splits < 1) splits = 1;
@@ -349,7 +349,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
 #define BY_STAGE(T, B, WM_, WN_, TM_)                                                   \
     (stages == 2 ? launch_conv<T, B, 2, WM_, WN_, TM_>(ARGS) : stages == 3 ? launch_conv<T, B, 3, WM_, WN_, TM_>(ARGS) \
                                                               : launch_conv<T, B, 4, WM_, WN_, TM_>(ARGS))
-#define BY_GEO(T, B) (geo == 2 ? BY_STAGE(T, B, 2, 2, 4) : geo == 4 ? BY_STAGE(T, B, 4, 2, 4) : BY_STAGE(T, B, 2, 4, 8))
+#define BY_GEO(T, B) (geo == 2 ? BY_STAGE(T, B, 2, 2, 4) : geo == 4 ? BY_STAGE(T, B, 4, 2, 4) : geo == 8 ? BY_STAGE(T, B, 2, 4, 8) : BY_STAGE(T, B, 2, 2, 8))
     int rc;
     if (taps == 9) rc = (bk == 64) ? BY_GEO(9, 64) : BY_GEO(9, 32);
     else rc = (bk == 64) ? BY_GEO(1, 64) : BY_GEO(1, 32);

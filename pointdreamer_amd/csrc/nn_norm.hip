@@ -172,32 +172,20 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
                 o[e] = f;
             }
         };
-        for (int p = p_begin + sub; p < p_end; p += pps) {
-            float r[8];
-            if (RES == 0) {
-                const half8 v = *reinterpret_cast<const half8*>(X + ((size_t)n * H * W + p) * C + c0);
+        auto finish = [&](const half8& v, float* r) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float f = (float)v[e] * ga[e] + gb[e];
-                    if (!OUT_F32) f = (float)(half_t)f;
-                    if (FILM) {
-                        f = (float)(half_t)(f * t1[e]);
-                        f = (float)(half_t)(f + sh[e]);
-                    }
-                    if (silu) { f = silu_f(f); if (!OUT_F32) f = (float)(half_t)f; }
-                    r[e] = f;
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[e] * ga[e] + gb[e];
+                if (!OUT_F32) f = (float)(half_t)f;
+                if (FILM) {
+                    f = (float)(half_t)(f * t1[e]);
+                    f = (float)(half_t)(f + sh[e]);
                 }
-            } else {
-                const int yo = p / Wo, xo = p - yo * Wo;
-                if (RES == 1) {
-                    float a[8], b[8], c[8], d[8];
-                    act(2 * yo, 2 * xo, a); act(2 * yo, 2 * xo + 1, b); act(2 * yo + 1, 2 * xo, c); act(2 * yo + 1, 2 * xo + 1, d);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = (a[e] + b[e] + c[e] + d[e]) * 0.25f;
-                } else {
-                    act(yo >> 1, xo >> 1, r);
-                }
+                if (silu) { f = silu_f(f); if (!OUT_F32) f = (float)(half_t)f; }
+                r[e] = f;
             }
+        };
+        auto store = [&](int p, const float* r) {
             const size_t o = ((size_t)n * Ho * Wo + p) * C + c0;
             if (OUT_F32) {
                 float* Y = reinterpret_cast<float*>(Yv);
@@ -208,6 +196,35 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)r[e];
                 *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(Yv) + o) = hv;
+            }
+        };
+        if (RES == 0) {
+            // four independent 16-byte loads in flight per thread (memory-level parallelism for the HBM stream)
+            int p = p_begin + sub;
+            for (; p + 3 * pps < p_end; p += 4 * pps) {
+                half8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8*>(X + ((size_t)n * H * W + p + u * pps) * C + c0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { float r[8]; finish(v[u], r); store(p + u * pps, r); }
+            }
+            for (; p < p_end; p += pps) {
+                const half8 v = *reinterpret_cast<const half8*>(X + ((size_t)n * H * W + p) * C + c0);
+                float r[8]; finish(v, r); store(p, r);
+            }
+        } else {
+            for (int p = p_begin + sub; p < p_end; p += pps) {
+                float r[8];
+                const int yo = p / Wo, xo = p - yo * Wo;
+                if (RES == 1) {
+                    float a[8], b[8], c[8], d[8];
+                    act(2 * yo, 2 * xo, a); act(2 * yo, 2 * xo + 1, b); act(2 * yo + 1, 2 * xo, c); act(2 * yo + 1, 2 * xo + 1, d);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = (a[e] + b[e] + c[e] + d[e]) * 0.25f;
+                } else {
+                    act(yo >> 1, xo >> 1, r);
+                }
+                store(p, r);
             }
         }
     }

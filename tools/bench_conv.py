@@ -11,7 +11,7 @@ SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (8, 256, 256, 256, 256, 9), (8, 256, 256, 512, 256, 9), (8, 128, 128, 256, 256, 9), (8, 64, 64, 512, 512, 9),
     (8, 64, 64, 1024, 512, 9), (8, 32, 32, 512, 512, 9), (8, 128, 128, 512, 256, 9), (8, 256, 256, 512, 256, 1),
     (8, 32, 32, 512, 1536, 1)]
-ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64x2x8', '32x3x8', '32x4x8', '0x0x0']); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--shapes', type=int, nargs='*', default=None)
+ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64x2x8', '64x3x16', '64x2x16', '64x2x8']); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--shapes', type=int, nargs='*', default=None)
 a = ap.parse_args()
 dev = 'cuda:0'
 zp = torch.zeros(128, dtype=torch.float16, device=dev)
