@@ -53,6 +53,14 @@ int pdhip_raster_mesh(const float* pos /*[V,Vn,4]*/, int V, int Vn, const int32_
                       int R, uint64_t* zkey_ws, uint8_t* hard_masks, int64_t* face_idxs, float* depths,
                       void* stream);
 
+/* ---- nvdiffrast contract pieces used by the UV-atlas producer (models/get3d/extract_texture_map.py:57-63) and by
+ *      optimize_color (pointdreamer/ours_utils.py:1700-1705): barycentrics (u,v) of triangle vertices 0 and 1 at each covered
+ *      pixel centre (rast[...,0:2]), and interpolate(attr, rast, tri) = u*a0 + v*a1 + (1-u-v)*a2 (zeros where empty). */
+int pdhip_raster_barycentrics(const float* pos /*[V,Vn,4]*/, int V, int Vn, const int32_t* faces, int R,
+                              const int64_t* face_idxs /*[V,R,R]*/, float* bary /*[V,R,R,2]*/, void* stream);
+int pdhip_interpolate(const float* attr /*[Na,C]*/, int C, const int32_t* tri /*[F,3]*/, const int64_t* face_idxs,
+                      const float* bary, long long pixels, float* out /*[pixels,C]*/, void* stream);
+
 /* ---- P2b: torchvision Resize(bilinear, no antialias) + .bool() on masks (demo.py:103-104,
  *      ours_utils.py:989-995): out is 1 iff any source pixel with non-zero bilinear weight is set. */
 int pdhip_resize_mask(const uint8_t* in /*[B,in_h,in_w]*/, int B, int in_h, int in_w,

@@ -198,3 +198,38 @@ def point_validation_by_hpr(points, eye_positions, radius):
         vid = hull.vertices
         out[i, vid[vid < points.shape[0]]] = True
     return out
+
+
+# ----------------------------------------------------------------------------- nvdiffrast pieces for the atlas producer
+def raster_barycentrics(pos, faces, face_idxs, res):
+    """(u, v) = weights of triangle vertices 0 and 1 at covered pixel centres, from the snapped int64 edge functions
+    (float64 ratio rounded to float32); zeros where empty.  Mirrors k_raster_bary."""
+    pos = np.asarray(pos, F32)
+    faces = np.asarray(faces, np.int64)
+    V, R = pos.shape[0], int(res)
+    out = np.zeros((V, R, R, 2), F32)
+    for v in range(V):
+        X, Y = snap(pos[v, :, 0], R), snap(pos[v, :, 1], R)
+        ii, jj = np.nonzero(face_idxs[v] >= 0)
+        f = face_idxs[v][ii, jj]
+        i0, i1, i2 = faces[f, 0], faces[f, 1], faces[f, 2]
+        px, py = jj.astype(np.int64) * SUBPIX + 128, ii.astype(np.int64) * SUBPIX + 128
+        area = (X[i1] - X[i0]) * (Y[i2] - Y[i0]) - (Y[i1] - Y[i0]) * (X[i2] - X[i0])
+        E0 = (X[i2] - X[i1]) * (py - Y[i1]) - (Y[i2] - Y[i1]) * (px - X[i1])
+        E1 = (X[i0] - X[i2]) * (py - Y[i2]) - (Y[i0] - Y[i2]) * (px - X[i2])
+        out[v, ii, jj, 0] = (E0.astype(np.float64) / area.astype(np.float64)).astype(F32)
+        out[v, ii, jj, 1] = (E1.astype(np.float64) / area.astype(np.float64)).astype(F32)
+    return out
+
+
+def interpolate(attr, tri, face_idxs, bary):
+    """u*a0 + v*a1 + ((1-u)-v)*a2 in float32, zeros where empty (nvdiffrast.interpolate contract)."""
+    attr = np.asarray(attr, F32)
+    tri = np.asarray(tri, np.int64)
+    out = np.zeros(face_idxs.shape + (attr.shape[1],), F32)
+    m = face_idxs >= 0
+    f = face_idxs[m]
+    u, v = bary[m][:, 0:1], bary[m][:, 1:2]
+    w = (F32(1) - u) - v
+    out[m] = (u * attr[tri[f, 0]] + v * attr[tri[f, 1]]) + w * attr[tri[f, 2]]
+    return out

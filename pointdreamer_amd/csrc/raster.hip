@@ -112,3 +112,67 @@ extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t*
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Barycentrics + attribute interpolation: the parts of nvdiffrast's rasterize()/interpolate() contract that the UV-atlas
+// producer (models/get3d/extract_texture_map.py:57-63) and optimize_color (pointdreamer/ours_utils.py:1700-1705) use.
+// bary[...,0:2] = weights (u, v) of the triangle's vertices 0 and 1 at the pixel centre (third weight 1-u-v), recomputed
+// from the same snapped int64 edge functions that decided coverage; out = (u*a0 + v*a1) + ((1-u)-v)*a2 in float32.
+__global__ void k_raster_bary(const float* __restrict__ pos, int Vn, const int32_t* __restrict__ faces, int R,
+                              const int64_t* __restrict__ fid, float* __restrict__ bary, long long n) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const long long f = fid[idx];
+        float u = 0.f, w = 0.f;
+        if (f >= 0) {
+            const int v = (int)(idx / ((long long)R * R));
+            const int rem = (int)(idx - (long long)v * R * R);
+            const int i = rem / R, j = rem - i * R;
+            const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)v * Vn;
+            const float4 a = P[faces[3 * f]], b = P[faces[3 * f + 1]], c = P[faces[3 * f + 2]];
+            const long long x0 = snap_fix(a.x, R), y0 = snap_fix(a.y, R), x1 = snap_fix(b.x, R), y1 = snap_fix(b.y, R);
+            const long long x2 = snap_fix(c.x, R), y2 = snap_fix(c.y, R);
+            const long long px = (long long)j * SUBPIX + 128, py = (long long)i * SUBPIX + 128;
+            const long long area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
+            const long long E0 = (x2 - x1) * (py - y1) - (y2 - y1) * (px - x1);
+            const long long E1 = (x0 - x2) * (py - y2) - (y0 - y2) * (px - x2);
+            u = (float)((double)E0 / (double)area);
+            w = (float)((double)E1 / (double)area);
+        }
+        bary[2 * idx] = u;
+        bary[2 * idx + 1] = w;
+    }
+}
+
+extern "C" int pdhip_raster_barycentrics(const float* pos, int V, int Vn, const int32_t* faces, int R,
+                                         const int64_t* face_idxs, float* bary, void* stream) {
+    PD_REQUIRE(V > 0 && Vn > 0 && R > 0 && pos && faces && face_idxs && bary, "pdhip_raster_barycentrics: bad arguments");
+    const long long n = (long long)V * R * R;
+    k_raster_bary<<<min(cdiv(n, 256), 4096), 256, 0, as_stream(stream)>>>(pos, Vn, faces, R, face_idxs, bary, n);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+__global__ void k_interpolate(const float* __restrict__ attr, int C, const int32_t* __restrict__ tri,
+                              const int64_t* __restrict__ fid, const float* __restrict__ bary, float* __restrict__ out,
+                              long long n) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n; idx += (long long)gridDim.x * blockDim.x) {
+        const long long f = fid[idx];
+        if (f < 0) {
+            for (int c = 0; c < C; ++c) out[idx * C + c] = 0.f;
+            continue;
+        }
+        const float u = bary[2 * idx], v = bary[2 * idx + 1], w = (1.0f - u) - v;
+        const float* a0 = attr + (size_t)tri[3 * f] * C;
+        const float* a1 = attr + (size_t)tri[3 * f + 1] * C;
+        const float* a2 = attr + (size_t)tri[3 * f + 2] * C;
+        for (int c = 0; c < C; ++c) out[idx * C + c] = (u * a0[c] + v * a1[c]) + w * a2[c];
+    }
+}
+
+extern "C" int pdhip_interpolate(const float* attr, int C, const int32_t* tri, const int64_t* face_idxs, const float* bary,
+                                 long long pixels, float* out, void* stream) {
+    PD_REQUIRE(attr && tri && face_idxs && bary && out && C > 0 && pixels > 0, "pdhip_interpolate: bad arguments");
+    k_interpolate<<<min(cdiv(pixels, 256), 4096), 256, 0, as_stream(stream)>>>(attr, C, tri, face_idxs, bary, out, pixels);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}

@@ -301,3 +301,38 @@ def test_p3b_skip_mask_gives_the_or(pd):
     assert torch.equal(ored, torch.logical_or(full, pre))
     allv = hpr.hidden_point_removal(T(pts), eyes, 100, already_valid=torch.ones_like(pre))
     assert bool(allv.all())
+
+
+def test_uv_atlas_producer_vs_oracle(pd):
+    """rasterise the UV triangles + interpolate world positions (extract_texture_map.py:48-64)."""
+    from pointdreamer_amd import extract_texture_map as etm
+    syn = pd['syn']
+    verts, faces, _ = syn.uv_sphere(12, 24)
+    rng = np.random.default_rng(3)
+    # a toy parametrisation: every face gets its own little right triangle in a grid of UV cells (3 vt per face)
+    F = faces.shape[0]
+    g = int(np.ceil(np.sqrt(F)))
+    cell = 1.0 / g
+    fi = np.arange(F)
+    ox, oy = (fi % g) * cell, (fi // g) * cell
+    tri_uv = np.stack([np.stack([ox + 0.1 * cell, oy + 0.1 * cell], -1), np.stack([ox + 0.9 * cell, oy + 0.1 * cell], -1),
+                       np.stack([ox + 0.1 * cell, oy + 0.9 * cell], -1)], 1)
+    uvs = tri_uv.reshape(-1, 2).astype(np.float32)
+    tex_idx = np.arange(F * 3).reshape(F, 3)
+    R = 256
+    _, _, gb_pos, mask, fid = etm.uvmap_w_face_id(T(verts), T(faces), T(uvs), T(tex_idx), R)
+    pos = np.concatenate([uvs * 2 - 1, np.zeros((F * 3, 1), np.float32), np.ones((F * 3, 1), np.float32)], 1)[None]
+    oh, of, od = oproj.rasterize(pos, tex_idx, R)
+    assert np.array_equal(N_(fid), of) and np.array_equal(N_(mask)[..., 0], oh)
+    ob = oproj.raster_barycentrics(pos, tex_idx, of, R)
+    og = oproj.interpolate(verts, faces, of, ob)
+    assert np.array_equal(N_(gb_pos), og)
+    m = of[0] >= 0
+    assert m.mean() > 0.15
+    # interpolated positions lie on the (flat) faces: inside the unit-ish ball and close to the sphere
+    r = np.linalg.norm(N_(gb_pos)[0][m], axis=1)
+    assert r.max() <= 0.5 + 1e-5 and r.min() > 0.45
+    # each covered texel belongs to the face whose UV triangle contains it
+    ii, jj = np.nonzero(m)
+    u, v = (jj + 0.5) / R, (ii + 0.5) / R
+    assert np.array_equal(of[0][ii, jj], (np.floor(v / cell) * g + np.floor(u / cell)).astype(np.int64))
