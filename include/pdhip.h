@@ -61,6 +61,18 @@ int pdhip_raster_barycentrics(const float* pos /*[V,Vn,4]*/, int V, int Vn, cons
 int pdhip_interpolate(const float* attr /*[Na,C]*/, int C, const int32_t* tri /*[F,3]*/, const int64_t* face_idxs,
                       const float* bary, long long pixels, float* out /*[pixels,C]*/, void* stream);
 
+/* ---- ours_utils.optimize_color (pointdreamer/ours_utils.py:1583-1785).
+ *      pdhip_rescale_vertices: pos.xy <- clip((((xy-c)/s)*(1-2pad))*factor_v + 0.5, 0, 1)*2-1  (:1688-1695), in place.
+ *      pdhip_optimize_color: `iterations` Adam steps (lr, StepLR(15, 0.5)) of the masked L1 texture loss, atlas[3,A,A] f32
+ *      updated in place; uv_map[V,res,res,2] / face_idxs[V,res,res] are the UNflipped raster + interpolate outputs;
+ *      shrinked[V,A,A] u8 may be NULL; final_images[V,3,res,res] f32 (render of the last iteration) may be NULL. */
+int pdhip_rescale_vertices(float* pos /*[V,Vn,4]*/, int V, int Vn, const float* uv_centers, const float* uv_scales,
+                           const float* factors /*[V]*/, double padding, void* stream);
+size_t pdhip_optimize_color_ws_bytes(int V, int res, int A);
+int pdhip_optimize_color(float* atlas, int A, const float* uv_map, const int64_t* face_idxs, int V, int res,
+                         const float* inpainted /*[V,3,r,r]*/, int r, const uint8_t* shrinked, double lr, int iterations,
+                         float* final_images, void* ws, void* stream);
+
 /* ---- P2b: torchvision Resize(bilinear, no antialias) + .bool() on masks (demo.py:103-104,
  *      ours_utils.py:989-995): out is 1 iff any source pixel with non-zero bilinear weight is set. */
 int pdhip_resize_mask(const uint8_t* in /*[B,in_h,in_w]*/, int B, int in_h, int in_w,

@@ -23,6 +23,9 @@ _SIGS = {
     'pdhip_raster_mesh': (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
     'pdhip_raster_barycentrics': (C.c_int, [vp, i32, i32, vp, i32, vp, vp, vp]),
     'pdhip_interpolate': (C.c_int, [vp, i32, vp, vp, vp, C.c_longlong, vp, vp]),
+    'pdhip_rescale_vertices': (C.c_int, [vp, i32, i32, vp, vp, vp, f64, vp]),
+    'pdhip_optimize_color_ws_bytes': (sz, [i32, i32, i32]),
+    'pdhip_optimize_color': (C.c_int, [vp, i32, vp, vp, i32, i32, vp, i32, vp, f64, i32, vp, vp, vp]),
     'pdhip_resize_mask': (C.c_int, [vp, i32, i32, i32, vp, i32, i32, vp]),
     'pdhip_point_visibility': (C.c_int, [i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     'pdhip_hpr_ws_bytes': (sz, [i32, i32]),

@@ -23,8 +23,8 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
     if complete_unseen_by != 'unproject':
         raise NotImplementedError(f"complete_unseen_by={complete_unseen_by!r}: only 'unproject' is built (SURVEY 8f lists "
                                   "'neighbor' and 'optimize' as next)")
-    if optimize_from not in (None, 'None'):
-        raise NotImplementedError("optimize_color (optimize_from != None) is SURVEY 8f item 1: not built yet")
+    if optimize_from not in (None, 'None', 'scratch', 'naive', 'ours'):
+        raise ValueError(f"optimize_from={optimize_from!r}")
     cams = camera_info['cams']
     base_dirs = camera_info['base_dirs']
     eye_positions = camera_info['eye_positions']
@@ -53,6 +53,16 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
             inpainted, f_normals, res, cams, cam_res, base_dirs, gb_pos, mask, face_id, uv_centers, uv_scales, padding,
             scale_factors, mesh_depths, list(edge_dilate_kernels), True)
         atlas = up.dilate_atlas(atlas, mask)
+        if optimize_from not in (None, 'None'):
+            # demo.py:211-236: 100 Adam steps of the atlas against the inpainted views (flip to image orientation and back)
+            from .optimize import optimize_color
+            init = None if optimize_from == 'scratch' else atlas.permute(2, 0, 1).flip(1).contiguous()
+            shr = shrinked if optimize_from == 'ours' else None
+            eyes_t = torch.tensor(eye_positions).float().to(atlas.device)
+            opt, _ = optimize_color(init, inpainted, vertices, faces, xatlas_dict['uvs'], xatlas_dict['mesh_tex_idx'], cams, eyes_t,
+                                    torch.zeros_like(eyes_t), camera_info.get('up_dirs'), uv_centers, uv_scales, padding,
+                                    scale_factors, glctx, shrinked_per_view_per_pixel_visibility=shr)
+            atlas = opt[0].flip(1).permute(1, 2, 0).contiguous()
     if return_intermediates:
         return dict(atlas=atlas, inpainted=inpainted, sparse=sparse_imgs, mask0=hard_mask0s, mask2=hard_mask2s,
                     view_ids=view_ids, painted=painted, shrinked=shrinked, visibility=vis,
