@@ -114,7 +114,8 @@ int pdhip_sparse_views(const int64_t* point_pixels /*[V,N,2]*/, const float* col
  *      Euclidean-nearest site; ties -> lexicographically smallest (row,col).
  *      img/out: B images; element (b,c,y,x) at b*batch_stride + c*chan_stride + (y*W+x)*pix_stride.
  *      mask: per image H*W; mask_is_f32 != 0 -> float (site iff != 0), else uint8.
- *      mask_batch_stride in elements.  ws: B*H*W int32. */
+ *      mask_batch_stride in elements.  ws: pdhip_nearest_fill_ws_ints(B,H,W) int32. */
+size_t pdhip_nearest_fill_ws_ints(int B, int H, int W);
 int pdhip_nearest_fill(const float* img, float* out, int B, int C, int H, int W,
                        int64_t batch_stride, int64_t chan_stride, int64_t pix_stride,
                        const void* mask, int mask_is_f32, int64_t mask_batch_stride,

@@ -7,25 +7,49 @@
 #include "common.h"
 using namespace pdhip;
 
+// Column pass, parallel over (column, 64-row segment).  Pass A records every segment's first / last site row; pass B
+// scans its own segment down and up with the carries taken from the other segments' summaries.
+#define SEG 64
 template <bool F32MASK>
-__global__ void k_nearest_cols(const void* __restrict__ mask, int64_t mask_bstride, int H, int W,
+__device__ __forceinline__ bool is_site(const void* mask, size_t base, size_t idx) {
+    if (F32MASK) return reinterpret_cast<const float*>(mask)[base + idx] != 0.0f;
+    return reinterpret_cast<const uint8_t*>(mask)[base + idx] != 0;
+}
+
+template <bool F32MASK>
+__global__ void k_nearest_seg_summary(const void* __restrict__ mask, int64_t mask_bstride, int H, int W, int nseg,
+                                      int32_t* __restrict__ seg_first, int32_t* __restrict__ seg_last) {
+    const int b = blockIdx.z, s = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    const size_t base = (size_t)b * mask_bstride;
+    int first = -1, last = -1;
+    const int r1 = min(H, (s + 1) * SEG);
+    for (int r = s * SEG; r < r1; ++r)
+        if (is_site<F32MASK>(mask, base, (size_t)r * W + c)) { if (first < 0) first = r; last = r; }
+    seg_first[((size_t)b * nseg + s) * W + c] = first;
+    seg_last[((size_t)b * nseg + s) * W + c] = last;
+}
+
+template <bool F32MASK>
+__global__ void k_nearest_cols(const void* __restrict__ mask, int64_t mask_bstride, int H, int W, int nseg,
+                               const int32_t* __restrict__ seg_first, const int32_t* __restrict__ seg_last,
                                int32_t* __restrict__ near_row) {
-    const int b = blockIdx.y;
+    const int b = blockIdx.z, s = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= W) return;
     int32_t* nr = near_row + (size_t)b * H * W;
-    auto site = [&](int r) -> bool {
-        if (F32MASK) return reinterpret_cast<const float*>(mask)[(size_t)b * mask_bstride + (size_t)r * W + c] != 0.0f;
-        return reinterpret_cast<const uint8_t*>(mask)[(size_t)b * mask_bstride + (size_t)r * W + c] != 0;
-    };
-    int last = -1;
-    for (int r = 0; r < H; ++r) {              // nearest site at or above
-        if (site(r)) last = r;
+    const size_t base = (size_t)b * mask_bstride;
+    int last = -1, next = -1;                  // carries: nearest site above this segment / below this segment
+    for (int t = s - 1; t >= 0 && last < 0; --t) last = seg_last[((size_t)b * nseg + t) * W + c];
+    for (int t = s + 1; t < nseg && next < 0; ++t) next = seg_first[((size_t)b * nseg + t) * W + c];
+    const int r0 = s * SEG, r1 = min(H, (s + 1) * SEG);
+    for (int r = r0; r < r1; ++r) {            // nearest site at or above
+        if (is_site<F32MASK>(mask, base, (size_t)r * W + c)) last = r;
         nr[(size_t)r * W + c] = last;
     }
-    int next = -1;
-    for (int r = H - 1; r >= 0; --r) {         // merge with nearest site at or below; ties -> up (smaller row)
-        if (site(r)) next = r;
+    for (int r = r1 - 1; r >= r0; --r) {       // merge with nearest site at or below; ties -> up (smaller row)
+        if (is_site<F32MASK>(mask, base, (size_t)r * W + c)) next = r;
         int up = nr[(size_t)r * W + c];
         int pick = up;
         if (next >= 0 && (up < 0 || (next - r) < (r - up))) pick = next;
@@ -76,6 +100,10 @@ __global__ void k_nearest_rows(const int32_t* __restrict__ near_row, int H, int 
     }
 }
 
+extern "C" size_t pdhip_nearest_fill_ws_ints(int B, int H, int W) {
+    return (size_t)B * H * W + 2 * (size_t)B * ((H + SEG - 1) / SEG) * W;
+}
+
 extern "C" int pdhip_nearest_fill(const float* img, float* out, int B, int C, int H, int W, int64_t batch_stride,
                                   int64_t chan_stride, int64_t pix_stride, const void* mask, int mask_is_f32,
                                   int64_t mask_batch_stride, int32_t* ws, void* stream) {
@@ -83,9 +111,17 @@ extern "C" int pdhip_nearest_fill(const float* img, float* out, int B, int C, in
     PD_REQUIRE(img && out && mask && ws, "pdhip_nearest_fill: null pointer");
     PD_REQUIRE(img != out, "pdhip_nearest_fill: in-place operation is not supported");
     hipStream_t s = as_stream(stream);
-    dim3 g1(cdiv(W, 64), B);
-    if (mask_is_f32) k_nearest_cols<true><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, ws);
-    else k_nearest_cols<false><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, ws);
+    const int nseg = cdiv(H, SEG);
+    int32_t* seg_first = ws + (size_t)B * H * W;
+    int32_t* seg_last = seg_first + (size_t)B * nseg * W;
+    dim3 g1(cdiv(W, 64), nseg, B);
+    if (mask_is_f32) {
+        k_nearest_seg_summary<true><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, nseg, seg_first, seg_last);
+        k_nearest_cols<true><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, nseg, seg_first, seg_last, ws);
+    } else {
+        k_nearest_seg_summary<false><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, nseg, seg_first, seg_last);
+        k_nearest_cols<false><<<g1, 64, 0, s>>>(mask, mask_batch_stride, H, W, nseg, seg_first, seg_last, ws);
+    }
     dim3 g2(H, B);
     k_nearest_rows<<<g2, 256, W * sizeof(int32_t), s>>>(ws, H, W, img, out, C, batch_stride, chan_stride, pix_stride);
     PD_LAUNCH_CHECK();

@@ -24,6 +24,7 @@ struct SparseWs {
     uint32_t* winB;       // [V][r*r]
     int32_t* nn_idx;      // [V][r*r]
     int32_t* pp;          // [V][N] packed (row<<16|col) or -1
+    uint32_t* minidx;     // [V][r*r] smallest valid point index landing on the pixel (0xffffffff: none)
 };
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -40,6 +41,7 @@ static SparseWs carve(void* ws, int V, int N, int res, size_t* total) {
     w.winB = (uint32_t*)(base + off); off += align256(4 * px);
     w.nn_idx = (int32_t*)(base + off); off += align256(4 * px);
     w.pp = (int32_t*)(base + off); off += align256(4 * (size_t)V * (N > 0 ? N : 1));
+    w.minidx = (uint32_t*)(base + off); off += align256(4 * px);
     if (total) *total = off;
     return w;
 }
@@ -100,7 +102,8 @@ __device__ __forceinline__ void bilinear_taps_s(int n_in, int n_out, int d, int&
 
 // new foreground mask (Resize+Pad when the view is rescaled) and winner-buffer init
 __global__ void k_sparse_mask(const uint8_t* __restrict__ hard, int res, const ViewParams* __restrict__ params,
-                              uint8_t* __restrict__ mask_new, uint32_t* __restrict__ winA, uint32_t* __restrict__ winB) {
+                              uint8_t* __restrict__ mask_new, uint32_t* __restrict__ winA, uint32_t* __restrict__ winB,
+                              uint32_t* __restrict__ minidx) {
     const int v = blockIdx.y;
     const ViewParams p = params[v];
     const uint8_t* src = hard + (size_t)v * res * res;
@@ -124,13 +127,14 @@ __global__ void k_sparse_mask(const uint8_t* __restrict__ hard, int res, const V
         mask_new[o] = m;
         winA[o] = 0;
         winB[o] = 0;
+        minidx[o] = 0xffffffffu;
     }
 }
 
 // P5: splat valid points (write index -> atomicMax), remember the (rescaled) pixel of every point
 __global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* __restrict__ valid, int N, int res,
                                int point_size, const ViewParams* __restrict__ params, uint32_t* __restrict__ winA,
-                               int32_t* __restrict__ pp) {
+                               int32_t* __restrict__ pp, uint32_t* __restrict__ minidx) {
     const int v = blockIdx.y;
     const ViewParams p = params[v];
     const int g = 2 * point_size - 1;
@@ -148,6 +152,7 @@ __global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* _
                 col = clip_to_int(uc * (float)res, res - 1);
             }
             packed = (row << 16) | col;
+            atomicMin(&minidx[(size_t)v * res * res + row * res + col], (uint32_t)n);
             for (int a = 0; a < g; ++a) {
                 int rr = row + a - (point_size - 1);
                 if (rr < 0 || rr >= res) continue;
@@ -162,16 +167,17 @@ __global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* _
     }
 }
 
-// P6 + edge colouring: one block per (view,row); for each inner-edge pixel all threads scan the points
+// P6 + edge colouring: one block per (view,row).  Every inner-edge pixel takes the colour of its nearest valid point
+// (exact integer distance, ties -> smallest point index): one wave per edge pixel searches the per-pixel min-index image
+// in a growing square window -- the window is exhaustive once its radius covers the best distance found.
 __global__ void k_sparse_edges(const uint8_t* __restrict__ mask_new, int N, int res, int edge_point_size,
-                               const ViewParams* __restrict__ params, const int32_t* __restrict__ pp,
+                               const ViewParams* __restrict__ params, const uint32_t* __restrict__ minidx,
                                uint32_t* __restrict__ winB, int32_t* __restrict__ nn_idx) {
     const int v = blockIdx.y, row = blockIdx.x;
     const ViewParams p = params[v];
     if (p.degenerate) return;
-    extern __shared__ int s_edge[];            // [res] edge columns, then reduction scratch
+    extern __shared__ int s_edge[];            // [res] edge columns of this row
     __shared__ int s_n;
-    __shared__ unsigned long long s_red[4];
     const uint8_t* m = mask_new + (size_t)v * res * res;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -194,26 +200,41 @@ __global__ void k_sparse_edges(const uint8_t* __restrict__ mask_new, int N, int 
     __syncthreads();
     const int ne = s_n;
     const int ge = 2 * edge_point_size - 1;
-    const int32_t* ppv = pp + (size_t)v * N;
-    for (int e = 0; e < ne; ++e) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t* mi = minidx + (size_t)v * res * res;
+    for (int e = wave; e < ne; e += nw) {
         const int col = s_edge[e];
         unsigned long long best = ~0ull;
-        for (int n = threadIdx.x; n < N; n += blockDim.x) {
-            int q = ppv[n];
-            if (q < 0) continue;
-            int dr = row - (q >> 16), dc = col - (q & 0xffff);
-            unsigned long long key = ((unsigned long long)(unsigned)(dr * dr + dc * dc) << 32) | (unsigned)n;
-            best = key < best ? key : best;
-        }
+        int rho = 8;
+        while (true) {
+            const int side = 2 * rho + 1;
+            best = ~0ull;
+            for (int i = lane; i < side * side; i += 64) {
+                const int dr = i / side - rho, dc = i - (i / side) * side - rho;
+                const int rr = row + dr, cc = col + dc;
+                if (rr < 0 || rr >= res || cc < 0 || cc >= res) continue;
+                const uint32_t q = mi[rr * res + cc];
+                if (q == 0xffffffffu) continue;
+                const unsigned long long key = ((unsigned long long)(unsigned)(dr * dr + dc * dc) << 32) | q;
+                best = key < best ? key : best;
+            }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            unsigned long long o = __shfl_xor(best, off);
-            best = o < best ? o : best;
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(best, off);
+                best = o < best ? o : best;
+            }
+            if (rho >= res) break;                                         // window covers the whole image
+            if (best != ~0ull) {
+                const long long d2 = (long long)(best >> 32);
+                if (d2 <= (long long)rho * rho) break;                      // nothing outside the window can be closer or tie
+                int need = (int)ceil(sqrt((double)d2));
+                rho = max(need, rho + 1);
+            } else {
+                rho *= 4;
+            }
+            if (rho > res) rho = res;
         }
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int k = 1; k < (int)(blockDim.x >> 6); ++k) best = s_red[k] < best ? s_red[k] : best;
+        if (lane == 0) {
             const int lin = row * res + col;
             nn_idx[(size_t)v * res * res + lin] = (int)(best & 0xffffffffu);
             for (int a = 0; a < ge; ++a) {
@@ -226,7 +247,6 @@ __global__ void k_sparse_edges(const uint8_t* __restrict__ mask_new, int N, int 
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -279,12 +299,12 @@ extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colo
     const float omt = (float)(1.0 - mask_ratio_thresh);
     k_sparse_counts<<<V, 256, 0, s>>>(hard_masks, validation, N, res, thr, omt, w.params, w.counts);
     dim3 gm(min(cdiv((long long)res * res, 256), 256), V);
-    k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB);
+    k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB, w.minidx);
     if (N > 0) {
         dim3 gs(min(cdiv(N, 256), 256), V);
-        k_sparse_splat<<<gs, 256, 0, s>>>(point_pixels, validation, N, res, point_size, w.params, w.winA, w.pp);
+        k_sparse_splat<<<gs, 256, 0, s>>>(point_pixels, validation, N, res, point_size, w.params, w.winA, w.pp, w.minidx);
         dim3 ge(res, V);
-        k_sparse_edges<<<ge, 256, res * sizeof(int), s>>>(w.mask_new, N, res, edge_point_size, w.params, w.pp, w.winB,
+        k_sparse_edges<<<ge, 256, res * sizeof(int), s>>>(w.mask_new, N, res, edge_point_size, w.params, w.minidx, w.winB,
                                                          w.nn_idx);
     }
     k_sparse_compose<<<gm, 256, 0, s>>>(colors, res, point_size, edge_point_size, w.params, w.mask_new, w.winA, w.winB,

@@ -120,6 +120,12 @@ extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, 
     dim3 g(min(cdiv((long long)A * A, 256), 2048), V);
     k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges);
     for (int k = 0; k < K; ++k) {
+        int same = -1;                              // the reference's list repetition yields identical levels: copy them
+        for (int j = 0; j < k; ++j) if (kernels[j] == kernels[k]) { same = j; break; }
+        if (same >= 0) {
+            PD_HIP(hipMemcpyAsync(out + (size_t)k * n, out + (size_t)same * n, n, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
         int r = (kernels[k] - 1) / 2;
         k_nbf_dilate_h<<<g, 256, 0, s>>>(edges, A, r, tmp);
         k_nbf_dilate_v_shrink<<<g, 256, 0, s>>>(tmp, visibility, A, r, out + (size_t)k * n);

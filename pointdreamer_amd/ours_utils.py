@@ -159,7 +159,7 @@ def nearest_fill(img, site_mask, layout='CHW'):
         if site_mask.dtype != torch.uint8:
             raise _lib.PdhipError("site mask must be bool, uint8 or float32")
     out = torch.empty_like(img)
-    ws = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    ws = torch.empty((L.pdhip_nearest_fill_ws_ints(B, H, W),), dtype=torch.int32, device=dev)
     check(L.pdhip_nearest_fill(ptr(img), ptr(out), B, Cn, H, W, bs, cs, ps, ptr(site_mask), is_f32, H * W, ptr(ws),
                                stream()), 'pdhip_nearest_fill')
     return out

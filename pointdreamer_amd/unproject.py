@@ -80,8 +80,10 @@ def unproject_dense(inpainted_images, f_normals, view_img_res, cams, cam_res, ba
     kernel_sizes = list(edge_dilate_kernels) * (A // 256)          # list repetition, unproject.py:289
     if len(kernel_sizes) == 0:
         raise _lib.PdhipError("atlas resolution < 256 gives an empty kernel list in the reference (IndexError); use A >= 256")
-    per_kernel = shrink_visibility(per_pixel_mask, vis, kernel_sizes)
-    K = min(len(edge_dilate_kernels), per_kernel.shape[0])
+    # the reference shrinks with every entry of the repeated list but only levels 0..len(edge_dilate_kernels)-1 are ever
+    # consulted (unproject.py:324-346): compute exactly those
+    K = 1 if int(kernel_sizes[0]) == 0 else min(len(edge_dilate_kernels), len(kernel_sizes))
+    per_kernel = shrink_visibility(per_pixel_mask, vis, kernel_sizes[:K])
     cp = stack_params(cams)
     gb = gb_pos[0].float().contiguous()
     fid = per_atlas_pixel_face_id[0].to(torch.int64).contiguous()
