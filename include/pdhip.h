@@ -200,6 +200,7 @@ int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* mask
 int pdhip_debug_set_conv_bk(int bk);
 int pdhip_debug_set_conv_tile(int m_waves);     /* 2 = 128x128 tile / 4 waves, 4 = 256x128 tile / 8 waves; 0 = automatic */
 int pdhip_debug_set_conv_stages(int stages);   /* 2..4 LDS pipeline stages; 0 = automatic */
+int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int splits); /* split-K workspace for pdhip_conv2d_nhwc_f16 + forced factor (0 = automatic) */
 int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed /*[Cout][taps*Cin] f16*/, void* stream);
 int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*Cin]*/, const float* bias, const void* residual,
                           void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, const void* zero_page,

@@ -266,36 +266,77 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     }
 }
 
-// sum of split-K partials (fixed order) + bias -> f16 (+ residual) -> Y
+// sum of split-K partials (fixed order) + bias -> f16 (+ residual) -> Y, plus the same fused GroupNorm octet partials as
+// the direct epilogue.  Block = SK_ROWS consecutive pixels x 64 channel octets; thread (octet, lane q) takes rows q, q+4, ...
+#define SK_ROWS 16
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int splits, long long M, int Cout,
                                                        const float* __restrict__ bias, const half_t* __restrict__ residual,
-                                                       half_t* __restrict__ Y) {
-    const long long total = M * (Cout >> 3);
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const size_t o = (size_t)idx * 8;
-        const int n = (int)(o % Cout);
-        float a[8];
+                                                       half_t* __restrict__ Y, float* __restrict__ gn_part, int hw) {
+    __shared__ float s_st[4][64][2];
+    const int ol = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int oct = blockIdx.y * 64 + ol;
+    const bool live = oct < (Cout >> 3);
+    const long long m0 = (long long)blockIdx.x * SK_ROWS;
+    const size_t MC = (size_t)M * Cout;
+    float gs = 0.f, gq = 0.f;
+    if (live) {
+        float bv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+        for (int e = 0; e < 8; ++e) bv[e] = bias ? bias[oct * 8 + e] : 0.f;
+        float a[SK_ROWS / 4][8];
+#pragma unroll
+        for (int j = 0; j < SK_ROWS / 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[j][e] = 0.f;
         for (int sp = 0; sp < splits; ++sp) {
-            const float4 v0 = *reinterpret_cast<const float4*>(partial + (size_t)sp * M * Cout + o);
-            const float4 v1 = *reinterpret_cast<const float4*>(partial + (size_t)sp * M * Cout + o + 4);
-            a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
-        }
-        half8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)(a[e] + (bias ? bias[n + e] : 0.f));
-        if (residual != nullptr) {
-            const half8 rv = *reinterpret_cast<const half8*>(residual + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            for (int j = 0; j < SK_ROWS / 4; ++j) {
+                const long long m = m0 + q + 4 * j;
+                if (m < M) {
+                    const float* src = partial + (size_t)sp * MC + (size_t)m * Cout + (size_t)oct * 8;
+                    const float4 v0 = *reinterpret_cast<const float4*>(src);
+                    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+                    a[j][0] += v0.x; a[j][1] += v0.y; a[j][2] += v0.z; a[j][3] += v0.w;
+                    a[j][4] += v1.x; a[j][5] += v1.y; a[j][6] += v1.z; a[j][7] += v1.w;
+                }
+            }
         }
-        *reinterpret_cast<half8*>(Y + o) = v;
+#pragma unroll
+        for (int j = 0; j < SK_ROWS / 4; ++j) {
+            const long long m = m0 + q + 4 * j;
+            if (m >= M) continue;
+            const size_t o = (size_t)m * Cout + (size_t)oct * 8;
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)(a[j][e] + bv[e]);
+            if (residual != nullptr) {
+                const half8 rv = *reinterpret_cast<const half8*>(residual + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<half8*>(Y + o) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
+        }
+    }
+    if (gn_part == nullptr) return;                        // (uniform) host guarantees hw % SK_ROWS == 0: one image per block
+    s_st[q][ol][0] = gs; s_st[q][ol][1] = gq;
+    __syncthreads();
+    if (q == 0 && live) {
+        gs = (s_st[0][ol][0] + s_st[1][ol][0]) + (s_st[2][ol][0] + s_st[3][ol][0]);
+        gq = (s_st[0][ol][1] + s_st[1][ol][1]) + (s_st[2][ol][1] + s_st[3][ol][1]);
+        const int chunks = hw / SK_ROWS;
+        const long long img = m0 / hw;
+        const int chunk = (int)((m0 - img * hw) / SK_ROWS);
+        float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + oct) * 2;
+        dst[0] = gs; dst[1] = gq;
     }
 }
 
 int g_force_bk = 0;       // tuning hook: 32 / 64 forces the K-step, 0 = automatic
 int g_force_stages = 0;   // tuning hook: 2 / 3 / 4 LDS stages, 0 = automatic
+int g_force_splits = 0;   // tuning hook: >= 1 forces the split-K factor, 0 = automatic
+float* g_dbg_splitk_ws = nullptr; size_t g_dbg_splitk_floats = 0;   // split-K workspace for the stand-alone conv entry point
 int g_force_wmw = 0;      // tuning hook, tile geometry: 2 = 128x128/4 waves, 4 = 256x128/8 waves, 8 = 256x256/8 waves, 0 = automatic
 
 template <int TAPS, int BKT, int NSTAGE, int WM, int WN, int TM>
@@ -325,19 +366,24 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const int bmt = geo == 2 ? 128 : 256, bnt = geo == 8 ? 256 : 128;    // geo 16: 256x128, 4 waves with 128x64 wave tiles
     const int m_tiles = (int)((M + bmt - 1) / bmt), n_tiles = Cout_pad / bnt;
     const int total = m_tiles * n_tiles;
-    // small-M layers (16x16 / 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups
+    // small-M 3x3 layers (32x32 .. 8x8 levels) leave most of the 256 CUs idle: split the K loop across workgroups, aiming at
+    // ~512 work items but never more than 8 splits -- the f32 partial round trip costs more than it buys beyond that, and
+    // never for 1x1 convs, whose K loop is too short to amortise it (tools/bench_splitk.py holds the measured table)
     const int KI = taps * (Cin / bk);
     int splits = 1;
-    if (splitk_ws != nullptr && total < (geo == 8 ? 256 : 384)) {
-        splits = std::min(std::min((640 + total - 1) / total, KI / 2), 16);
+    if (splitk_ws != nullptr && taps == 9 && total <= 256) {
+        splits = std::min(std::min((512 + total / 2) / total, KI / 2), 8);
         while (splits > 1 && (size_t)splits * M * Cout > splitk_ws_floats) --splits;
-        if (splits < 1) splits = 1;
     }
+    if (g_force_splits >= 1 && splitk_ws != nullptr)
+        splits = (int)std::min<size_t>(std::min(g_force_splits, std::max(KI / 2, 1)), splitk_ws_floats / ((size_t)M * Cout));
+    if (splits < 1) splits = 1;
     float* partial = splits > 1 ? splitk_ws : nullptr;
     dim3 grid(total, splits);
     // fused GroupNorm partial statistics: only when a tile never straddles two images
     const bool fuse = gn_part != nullptr && splits == 1 && ((long long)H * W) % bmt == 0;
-    if (gn_fused) *gn_fused = fuse ? (int)(((long long)H * W) / bmt) : 0;     // number of partial chunks per image
+    const bool fuse_sk = gn_part != nullptr && splits > 1 && ((long long)H * W) % SK_ROWS == 0;   // stats from the reduce kernel
+    if (gn_fused) *gn_fused = fuse ? (int)(((long long)H * W) / bmt) : fuse_sk ? (int)(((long long)H * W) / SK_ROWS) : 0;
     float* gnp = fuse ? gn_part : nullptr;
     int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);
     if (stages < 2) stages = 2;
@@ -358,8 +404,8 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
 #undef ARGS
     if (rc) return rc;
     if (splits > 1) {
-        const long long tot = M * (Cout >> 3);
-        k_splitk_reduce<<<(int)std::min<long long>((tot + 255) / 256, 2048), 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y);
+        dim3 gr((unsigned)((M + SK_ROWS - 1) / SK_ROWS), (unsigned)(((Cout >> 3) + 63) / 64));
+        k_splitk_reduce<<<gr, 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y, fuse_sk ? gn_part : nullptr, H * W);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

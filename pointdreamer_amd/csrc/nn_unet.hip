@@ -156,7 +156,8 @@ int prof_end(Ctx& c) {
 int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false) {
     out->C = w.cout; out->H = x.H; out->W = x.W; out->gn_part = nullptr; out->gn_chunks = 0; out->gn_partB = nullptr; out->Ca = 0;
     out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
-    float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 127) / 128) * (w.cout / 8) * 2 * 2)) : nullptr;
+    // octet partials: [N][chunks][cout/8][2] floats, chunks <= HW/16 (split-K reduce) -- sized for the finest chunking
+    float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 15) / 16) * (w.cout / 8) * 2 * 2)) : nullptr;
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
     if (w.taps == 9) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
@@ -638,9 +639,14 @@ extern "C" int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed, const 
                                      void* stream) {
     PD_REQUIRE(x && w_packed && y && zero_page, "pdhip_conv2d_nhwc_f16: null argument");
     return conv_igemm((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
-                      Cout_pad, taps, (const half_t*)zero_page, as_stream(stream));
+                      Cout_pad, taps, (const half_t*)zero_page, as_stream(stream), pdnn::g_dbg_splitk_ws, pdnn::g_dbg_splitk_floats);
 }
-namespace pdnn { extern int g_force_bk; extern int g_force_stages; extern int g_force_wmw; }
+/* tuning / test hook: split-K workspace (device floats) for pdhip_conv2d_nhwc_f16 and a forced split factor (0 = automatic) */
+extern "C" int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int splits) {
+    int old = pdnn::g_force_splits;
+    pdnn::g_dbg_splitk_ws = (float*)ws; pdnn::g_dbg_splitk_floats = ws ? (size_t)ws_floats : 0; pdnn::g_force_splits = splits;
+    return old;
+}
 extern "C" int pdhip_debug_set_conv_tile(int wmw) { int old = pdnn::g_force_wmw; pdnn::g_force_wmw = wmw; return old; }
 extern "C" int pdhip_debug_set_conv_stages(int st) { int old = pdnn::g_force_stages; pdnn::g_force_stages = st; return old; }
 /* tuning / test hook: force the conv K-step (32 or 64; 0 = automatic). Returns the previous value. */
