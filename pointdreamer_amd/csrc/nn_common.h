@@ -18,11 +18,12 @@ extern int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tunin
 extern float* g_dbg_splitk_ws; extern size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
-               float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr);
+               float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr,
+               const half_t* X2 = nullptr, int Cin1 = 0);   // X2: second tensor of a never-materialised channel concat (1x1 only)
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
 // the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).
-int gn_finalize_oct(const float* partA, int Ca, const float* partB, int Cb, int chunks, int N, int HW, float eps, float* stats,
-                    hipStream_t s);
+int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,
+                    float* stats, hipStream_t s);
 
 // ---- normalisation / elementwise (nn_norm.hip)
 // GroupNorm(32) statistics of X [N,HW,C] f16 -> stats [N][32][2] (mean, rstd) f32.  ws: N*chunks*32*2 floats.
@@ -30,7 +31,8 @@ int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, flo
 // y = silu?( GN(x)*gamma+beta [*(1+scale)+shift] ), optional 2x resample; RESAMPLE: 0 none, 1 avgpool2, 2 nearest-up2.
 // film: rows of (scale[C] | shift[C]) f32, row n at film + n*film_stride, or null.  Output f16 NHWC (or f32 when out_f32).
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
-             long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s);
+             long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
+             const half_t* XB = nullptr, int Ca = 0);     // XB: second tensor of a never-materialised channel concat
 int resample2x(const half_t* X, int N, int H, int W, int C, int mode, half_t* Y, hipStream_t s);
 int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long pixels, half_t* Y, hipStream_t s);
 
@@ -39,7 +41,7 @@ int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStr
 
 // ---- small dense ops (nn_misc.hip)
 int conv_in_3x3(const float* x_nchw, const half_t* Wt /*[Cout_pad][32] k=(ky*3+kx)*3+c, k>=27 zero*/, const float* bias, half_t* Y,
-                int N, int H, int W, int Cout, int Cout_pad, half_t* im2col_ws /*[N*H*W][32]*/, const half_t* zero_page, hipStream_t s);
+                int N, int H, int W, int Cout, int Cout_pad, half_t* im2col_ws /*[N*H*W][32]*/, const half_t* zero_page, hipStream_t s, float* gn_part = nullptr, int* gn_fused = nullptr);
 int conv_out_3x3_f32(const float* X_nhwc, const float* Wt /*[Cout][9*Cin]*/, const float* bias, float* y_nchw, int N, int H,
                      int W, int Cin, int Cout, hipStream_t s);
 int timestep_mlp(const float* t, int N, int mc, const float* w0, const float* b0, const float* w2, const float* b2,

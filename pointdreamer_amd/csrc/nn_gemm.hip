@@ -42,7 +42,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
                                                     const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                     half_t* __restrict__ Y, int N, int H, int W, int Cin, int Cout,
                                                     int n_tiles, int total_tiles, const half_t* __restrict__ zero_page,
-                                                    int splits, float* __restrict__ partial, float* __restrict__ gn_part) {
+                                                    int splits, float* __restrict__ partial, float* __restrict__ gn_part,
+                                                    const half_t* __restrict__ X2, int Cin1) {
     constexpr int ROWB = BKT * 2;                 // bytes per tile row
     constexpr int CPR = BKT / 8;                  // 16-byte chunks per row
     constexpr int RPI = 1024 / ROWB;              // rows per wave-instruction (1 KiB)
@@ -76,9 +77,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
 
     // ---- loader role: this lane stages rows {wave*32 + i*RPI + lane/CPR}, 16-byte slot (lane % CPR) of each tile.
     // Running source pointers: advanced by BKT halfs per K-step, re-derived once per filter tap (uniform branch).
+    // Two-source input (1x1 convs over a channel concat that is never materialised): channels [0, Cin1) come from X
+    // (pixel stride Cin1), the rest from X2 (pixel stride Cin - Cin1); X2 == nullptr -> one tensor, Cin1 == Cin.
     const int lrow = lane / CPR, lpos = lane % CPR;
     int py[LPO], pxx[LPO];
-    long long pbase[LPO];
+    long long pbase[LPO], pbase2[LPO];
     const half_t* bp[LPB];
     const half_t* ap[LPO];
     int astep[LPO];
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
         const int rem = (int)(mm - (long long)img * H * W);
         py[i] = inm ? rem / W : -100000;
         pxx[i] = rem - (rem / W) * W;
-        pbase[i] = (((long long)img * H + rem / W) * W + pxx[i]) * Cin + c * 8;
+        pbase[i] = (((long long)img * H + rem / W) * W + pxx[i]) * Cin1 + c * 8;
+        if (TAPS == 1) pbase2[i] = inm ? (((long long)img * H + rem / W) * W + pxx[i]) * (Cin - Cin1) + c * 8 : (long long)(zero_page - X2);
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
         for (int i = 0; i < LPO; ++i) {
             const int yy = py[i] + dy, xx = pxx[i] + dx;
             const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-            const long long off = pbase[i] + ((long long)dy * W + dx) * Cin;
+            const long long off = pbase[i] + ((long long)dy * W + dx) * Cin1;
             ap[i] = X + (ok ? off : zoff);
             astep[i] = ok ? BKT : 0;
         }
@@ -133,7 +137,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
             glds16(bp[i], wave_dst_b + stage * STAGE_BYTES + i * 1024);
             bp[i] += BKT;
         }
-        if (++nc == kc) {
+        if (TAPS == 1) {
+            if (X2 != nullptr && ++nc == Cin1 / BKT) {     // the concat's first tensor is exhausted: continue in the second
+#pragma unroll
+                for (int i = 0; i < LPO; ++i) ap[i] = X2 + pbase2[i];
+            }
+        } else if (++nc == kc) {
             nc = 0;
             if (++ntap < TAPS) set_tap(ntap);
         }
@@ -342,17 +351,20 @@ int g_force_wmw = 0;      // tuning hook, tile geometry: 2 = 128x128/4 waves, 4 
 template <int TAPS, int BKT, int NSTAGE, int WM, int WN, int TM>
 static int launch_conv(dim3 grid, size_t smem, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias,
                        const half_t* residual, half_t* Y, int N, int H, int W, int Cin, int Cout, int n_tiles, int total,
-                       const half_t* zero_page, int splits, float* partial, float* gnp) {
+                       const half_t* zero_page, int splits, float* partial, float* gnp, const half_t* X2, int Cin1) {
     auto kern = k_conv_igemm<TAPS, BKT, NSTAGE, WM, WN, TM>;
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, WM * WN * 64, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp);
+    kern<<<grid, WM * WN * 64, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp, X2, Cin1);
     return PDHIP_OK;
 }
 
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
-               size_t splitk_ws_floats, float* gn_part, int* gn_fused) {
+               size_t splitk_ws_floats, float* gn_part, int* gn_fused, const half_t* X2, int Cin1) {
     PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
+    if (X2 == nullptr) Cin1 = Cin;
+    PD_REQUIRE(X2 == nullptr || (taps == 1 && Cin1 > 0 && Cin1 < Cin && Cin1 % 64 == 0 && (Cin - Cin1) % 64 == 0),
+               "conv_igemm: a two-source input needs a 1x1 conv and channel counts that are multiples of 64");
     PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
     const long long M = (long long)N * H * W;
@@ -377,7 +389,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     }
     if (g_force_splits >= 1 && splitk_ws != nullptr)
         splits = (int)std::min<size_t>(std::min(g_force_splits, std::max(KI / 2, 1)), splitk_ws_floats / ((size_t)M * Cout));
-    if (splits < 1) splits = 1;
+    if (splits < 1 || X2 != nullptr) splits = 1;
     float* partial = splits > 1 ? splitk_ws : nullptr;
     dim3 grid(total, splits);
     // fused GroupNorm partial statistics: only when a tile never straddles two images
@@ -391,7 +403,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const size_t stage_bytes = (size_t)(bmt + bnt) * bk * 2;
     while (stages > 2 && stages * stage_bytes > 160 * 1024) --stages;
     const size_t smem = std::max<size_t>((size_t)stages * stage_bytes, (size_t)bmt * (bnt + 8) * 2);
-#define ARGS grid, smem, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp
+#define ARGS grid, smem, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp, X2, Cin1
 #define BY_STAGE(T, B, WM_, WN_, TM_)                                                   \
     (stages == 2 ? launch_conv<T, B, 2, WM_, WN_, TM_>(ARGS) : stages == 3 ? launch_conv<T, B, 3, WM_, WN_, TM_>(ARGS) \
                                                               : launch_conv<T, B, 4, WM_, WN_, TM_>(ARGS))

@@ -43,11 +43,11 @@ __global__ __launch_bounds__(256) void k_im2col_in(const float* __restrict__ x, 
 }
 
 int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t* Y, int N, int H, int W, int Cout, int Cout_pad,
-                half_t* im2col_ws, const half_t* zero_page, hipStream_t s) {
+                half_t* im2col_ws, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused) {
     const long long pixels = (long long)N * H * W;
     k_im2col_in<<<(int)std::min<long long>((pixels + 255) / 256, 8192), 256, 0, s>>>(x_nchw, im2col_ws, H, W, pixels);
     PD_LAUNCH_CHECK();
-    return conv_igemm(im2col_ws, Wt, bias, nullptr, Y, N, H, W, 32, Cout, Cout_pad, 1, zero_page, s);
+    return conv_igemm(im2col_ws, Wt, bias, nullptr, Y, N, H, W, 32, Cout, Cout_pad, 1, zero_page, s, nullptr, 0, gn_part, gn_fused);
 }
 
 // ------------------------------------------------------------------------------------------------

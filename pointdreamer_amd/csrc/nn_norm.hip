@@ -90,25 +90,31 @@ int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, flo
     return PDHIP_OK;
 }
 
-// stats from the conv epilogue's octet partials; thread (slice j = tid>>5, group g = tid&31), fixed-order combine
-__global__ __launch_bounds__(256) void k_gn_finalize_oct(const float* __restrict__ partA, int Ca, const float* __restrict__ partB,
-                                                         int Cb, int chunks, int HW, float eps, float* __restrict__ stats) {
-    __shared__ double s_s[8][32], s_q[8][32];
+// stats from the conv epilogue's octet partials (the two sources of a channel concat may be chunked differently);
+// block = image, thread (slice j = tid>>5, group g = tid&31): 32 slices walk the chunks, fixed-order f64 combine
+__global__ __launch_bounds__(1024) void k_gn_finalize_oct(const float* __restrict__ partA, int Ca, int chunksA,
+                                                          const float* __restrict__ partB, int Cb, int chunksB, int HW, float eps,
+                                                          float* __restrict__ stats) {
+    __shared__ double s_s[32][33], s_q[32][33];
     const int n = blockIdx.x, g = threadIdx.x & 31, j = threadIdx.x >> 5;
     const int C = Ca + Cb, opg = (C / 32) >> 3;           // octets per group
     const int oa = Ca >> 3, ob = Cb >> 3;
     double ds = 0.0, dq = 0.0;
-    for (int c = j; c < chunks; c += 8)
-        for (int k = 0; k < opg; ++k) {
-            const int o = g * opg + k;
-            const float* src = (o < oa) ? partA + (((size_t)n * chunks + c) * oa + o) * 2
-                                        : partB + (((size_t)n * chunks + c) * ob + (o - oa)) * 2;
-            ds += (double)src[0]; dq += (double)src[1];
+    for (int k = 0; k < opg; ++k) {
+        const int o = g * opg + k;
+        const bool inA = o < oa;
+        const int chunks = inA ? chunksA : chunksB, os = inA ? oa : ob;
+        const float2* src = reinterpret_cast<const float2*>(inA ? partA : partB) + (size_t)n * chunks * os + (inA ? o : o - oa);
+#pragma unroll 4
+        for (int c = j; c < chunks; c += 32) {
+            const float2 v = src[(size_t)c * os];
+            ds += (double)v.x; dq += (double)v.y;
         }
+    }
     s_s[j][g] = ds; s_q[j][g] = dq;
     __syncthreads();
     if (j == 0) {
-        for (int k = 1; k < 8; ++k) { ds += s_s[k][g]; dq += s_q[k][g]; }
+        for (int k = 1; k < 32; ++k) { ds += s_s[k][g]; dq += s_q[k][g]; }
         const double cnt = (double)HW * (C / 32);
         const double mean = ds / cnt;
         double var = dq / cnt - mean * mean;
@@ -118,15 +124,17 @@ __global__ __launch_bounds__(256) void k_gn_finalize_oct(const float* __restrict
     }
 }
 
-int gn_finalize_oct(const float* partA, int Ca, const float* partB, int Cb, int chunks, int N, int HW, float eps, float* stats,
-                    hipStream_t s) {
+int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,
+                    float* stats, hipStream_t s) {
     PD_REQUIRE(((Ca + Cb) / 32) % 8 == 0 && Ca % 8 == 0 && Cb % 8 == 0 && (Ca + Cb) % 32 == 0, "gn_finalize_oct: group size must be a multiple of 8");
-    k_gn_finalize_oct<<<N, 256, 0, s>>>(partA, Ca, partB, Cb, chunks, HW, eps, stats);
+    k_gn_finalize_oct<<<N, 1024, 0, s>>>(partA, Ca, chunksA, partB, Cb, chunksB, HW, eps, stats);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to f16 (or feeds the f32 head,
+// tolerance 1e-3) and the divide was half of this HBM-bound kernel's VALU work
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // grid (pixel chunks, N).  thread -> (pixel sub-slot, channel octet): the octet's affine constants live in
 // registers for the whole chunk; consecutive threads touch consecutive 16-byte octets (full 128-B lines).
@@ -136,7 +144,7 @@ template <int RES, bool OUT_F32, bool FILM>
 __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ film, long long film_stride, int H, int W,
-                                                  int C, int silu, void* __restrict__ Yv) {
+                                                  int C, int silu, void* __restrict__ Yv, const half_t* __restrict__ XB, int Ca) {
     const int opp = C >> 3, cg = C / 32;
     const int pps = max(1, 256 / opp);
     const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
@@ -146,6 +154,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
     const int p_begin = blockIdx.x * (pps * GNA_ITERS), p_end = min(Ho * Wo, p_begin + pps * GNA_ITERS);
     for (int oc = threadIdx.x - sub * opp; oc < opp; oc += 256) {
         const int c0 = oc * 8;
+        // input of a never-materialised channel concat: channels [0, Ca) live in X (pixel stride Ca), the rest in XB
+        const bool second = XB != nullptr && c0 >= Ca;
+        const half_t* const Xs = second ? XB + (c0 - Ca) : X + c0;
+        const int cs = XB == nullptr ? C : (second ? C - Ca : Ca);
         float ga[8], gb[8], t1[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
             }
         }
         auto act = [&](int yi, int xi, float* o) {
-            const half8 v = *reinterpret_cast<const half8*>(X + (((size_t)n * H + yi) * W + xi) * C + c0);
+            const half8 v = *reinterpret_cast<const half8*>(Xs + (((size_t)n * H + yi) * W + xi) * cs);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float f = (float)v[e] * ga[e] + gb[e];
@@ -204,12 +216,12 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
             for (; p + 3 * pps < p_end; p += 4 * pps) {
                 half8 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8*>(X + ((size_t)n * H * W + p + u * pps) * C + c0);
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { float r[8]; finish(v[u], r); store(p + u * pps, r); }
             }
             for (; p < p_end; p += pps) {
-                const half8 v = *reinterpret_cast<const half8*>(X + ((size_t)n * H * W + p) * C + c0);
+                const half8 v = *reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p) * cs);
                 float r[8]; finish(v, r); store(p, r);
             }
         } else {
@@ -231,7 +243,9 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
 }
 
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
-             long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s) {
+             long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
+             const half_t* XB, int Ca) {
+    PD_REQUIRE(XB == nullptr || (Ca > 0 && Ca < C && Ca % 8 == 0), "gn_apply: bad two-source split");
     PD_REQUIRE(C % 32 == 0 && resample >= 0 && resample <= 2, "gn_apply: bad arguments");
     PD_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avgpool needs even H, W");
     PD_REQUIRE(!out_f32 || (resample == 0 && film == nullptr), "gn_apply: f32 output only without resampling / FiLM");
@@ -239,11 +253,11 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     const int Ho = resample == 1 ? H / 2 : (resample == 2 ? H * 2 : H), Wo = resample == 1 ? W / 2 : (resample == 2 ? W * 2 : W);
     const int opp = C >> 3, pps = max(1, 256 / opp);
     dim3 grid(cdiv((long long)Ho * Wo, pps * GNA_ITERS), N);
-    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
-    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
-    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
-    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
-    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y);
+    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
+    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
+    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
+    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
+    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -25,7 +25,8 @@ struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 
 // gn_part: octet partial sums fused into the producing conv's epilogue ([N][chunks][C/8][2]); for a channel concat the
 // second source's partials are gn_partB (first Ca channels come from gn_part)
-struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chunks = 0; const float* gn_partB = nullptr; int Ca = 0; };
+struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chunks = 0; const float* gn_partB = nullptr; int Ca = 0; int gn_chunksB = 0;
+             half_t* p2 = nullptr; };   // p2: virtual channel concat [p (Ca channels) | p2 (C - Ca channels)], never materialised
 
 struct Prof { std::vector<hipEvent_t> ev; size_t used = 0; double flops = 0; bool on = false; };
 
@@ -154,7 +155,7 @@ int prof_end(Ctx& c) {
 }
 
 int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false) {
-    out->C = w.cout; out->H = x.H; out->W = x.W; out->gn_part = nullptr; out->gn_chunks = 0; out->gn_partB = nullptr; out->Ca = 0;
+    *out = Act{nullptr, w.cout, x.H, x.W};
     out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
     // octet partials: [N][chunks][cout/8][2] floats, chunks <= HW/16 (split-K reduce) -- sized for the finest chunking
     float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 15) / 16) * (w.cout / 8) * 2 * 2)) : nullptr;
@@ -163,7 +164,7 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     if (w.taps == 9) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
     int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
-                        c.u->splitk_ws, c.u->splitk_floats, part, &fused);
+                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0);
     if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = w.cout; }
     if (w.taps == 9) PD_TRY(prof_end(c));
     return rc;
@@ -172,19 +173,20 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
 // GroupNorm statistics of x: from the fused conv-epilogue partials when available, else a pass over the tensor
 int run_gn_stats(Ctx& c, const Act& x) {
     if (x.gn_part != nullptr && ((x.C / 32) % 8) == 0)
-        return gn_finalize_oct(x.gn_part, x.Ca, x.gn_partB, x.C - x.Ca, x.gn_chunks, c.N, x.H * x.W, 1e-5f, c.u->stats, c.s);
+        return gn_finalize_oct(x.gn_part, x.Ca, x.gn_chunks, x.gn_partB, x.C - x.Ca, x.gn_chunksB, c.N, x.H * x.W, 1e-5f, c.u->stats, c.s);
+    PD_REQUIRE(x.p2 == nullptr, "unet: a virtual concat needs fused GroupNorm partials of both tensors");
     return gn_stats(x.p, c.N, x.H * x.W, x.C, 1e-5f, c.u->stats, c.u->gn_ws, c.u->gn_ws_floats, c.s);
 }
 
 int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, int silu, int resample, Act* out) {
-    out->C = x.C;
+    *out = Act{nullptr, x.C, 0, 0};
     out->H = resample == 1 ? x.H / 2 : (resample == 2 ? x.H * 2 : x.H);
     out->W = resample == 1 ? x.W / 2 : (resample == 2 ? x.W * 2 : x.W);
     out->p = arena_take(c.u, (size_t)c.N * out->H * out->W * x.C);
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
     PD_TRY(run_gn_stats(c, x));
-    return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s);
+    return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2, x.p2 ? x.Ca : 0);
 }
 
 int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
@@ -221,10 +223,13 @@ int run_blocks(Ctx& c, std::vector<Block>& blocks, Act* h, const float* x_nchw) 
             o.C = c.u->mult[0] * c.u->mc; o.H = o.W = c.u->image_size;
             o.p = arena_take(c.u, (size_t)c.N * o.H * o.W * o.C);
             half_t* col = arena_take(c.u, (size_t)c.N * o.H * o.W * 32);
+            float* part = reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((o.H * o.W + 127) / 128) * (o.C / 8) * 2 * 2));
             if (!c.dry) {
                 PD_REQUIRE(c.u->have_win && c.u->have_bin, "unet: input conv not loaded");
+                int fused = 0;
                 PD_TRY(conv_in_3x3(x_nchw, c.u->w_in, c.u->b_in, o.p, c.N, o.H, o.W, o.C, ((o.C + 127) / 128) * 128, col,
-                                   c.u->zero_page, c.s));
+                                   c.u->zero_page, c.s, part, &fused));
+                if (fused) { o.gn_part = part; o.gn_chunks = fused; o.Ca = o.C; }
             }
         } else if (b.kind == 1) {
             PD_TRY(run_res(c, *h, c.u->res[b.idx], &o));
@@ -254,11 +259,22 @@ int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* ou
     PD_TRY(run_blocks(c, u->middle, &h, x));
     for (auto& blk : u->output) {
         Act sk = hs.back(); hs.pop_back();
-        Act cat{arena_take(u, (size_t)N * h.H * h.W * (h.C + sk.C)), h.C + sk.C, h.H, h.W};
-        if (h.gn_part && sk.gn_part && !h.gn_partB && !sk.gn_partB && h.gn_chunks == sk.gn_chunks) {
-            cat.gn_part = h.gn_part; cat.gn_partB = sk.gn_part; cat.Ca = h.C; cat.gn_chunks = h.gn_chunks;
+        // torch.cat([h, skip], dim=1): when both tensors carry fused GroupNorm partials (and 64-channel granularity for the
+        // 1x1 skip conv's K loop) the concat stays virtual -- its two consumers (GroupNorm apply, skip conv) read both tensors
+        Act cat{nullptr, h.C + sk.C, h.H, h.W};
+        const bool part_ok = h.gn_part && sk.gn_part && !h.gn_partB && !sk.gn_partB && !h.p2 && !sk.p2;
+        if (part_ok) {
+            cat.gn_part = h.gn_part; cat.gn_partB = sk.gn_part; cat.Ca = h.C; cat.gn_chunks = h.gn_chunks; cat.gn_chunksB = sk.gn_chunks;
         }
-        if (!dry) PD_TRY(concat_channels(h.p, h.C, sk.p, sk.C, (long long)N * h.H * h.W, cat.p, s));
+        const Block& first = blk.front();
+        const bool virt = part_ok && h.C % 64 == 0 && sk.C % 64 == 0 && ((cat.C / 32) % 8) == 0 && first.kind == 1 &&
+                          u->res[first.idx].mode == 0 && u->res[first.idx].has_skip;
+        if (virt) {
+            cat.p = h.p; cat.p2 = sk.p;
+        } else {
+            cat.p = arena_take(u, (size_t)N * h.H * h.W * (h.C + sk.C));
+            if (!dry) PD_TRY(concat_channels(h.p, h.C, sk.p, sk.C, (long long)N * h.H * h.W, cat.p, s));
+        }
         h = cat;
         PD_TRY(run_blocks(c, blk, &h, x));
     }
