@@ -208,6 +208,12 @@ int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*
 int pdhip_groupnorm_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film /*[N][2C] or NULL*/, int N,
                              int H, int W, int C, int silu, int resample, void* y, float* stats_ws, float* ws,
                              long long ws_floats, void* stream);
+/* Output head of the UNet on its own (models/DDNM/guided_diffusion/unet.py:613-617): GroupNorm(32) -> SiLU -> conv3x3 in
+ * float32-equivalent arithmetic.  x: f16 NHWC [N,H,W,C] (C in {32,64,128,256}); w_oihw f32 [Cout][C][3][3], Cout 3 or 6;
+ * y f32 NCHW [N,Cout,H,W]; ws: pdhip_unet_head_ws_floats() device floats. */
+size_t pdhip_unet_head_ws_floats(int N, int H, int W, int C, int Cout);
+int pdhip_unet_head_f32(const void* x, const float* gamma, const float* beta, const float* w_oihw, const float* bias,
+                        int N, int H, int W, int C, int Cout, float* y_nchw, float* ws, long long ws_floats, void* stream);
 int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim, void* stream);
 int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream);
 

@@ -42,8 +42,11 @@ int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStr
 // ---- small dense ops (nn_misc.hip)
 int conv_in_3x3(const float* x_nchw, const half_t* Wt /*[Cout_pad][32] k=(ky*3+kx)*3+c, k>=27 zero*/, const float* bias, half_t* Y,
                 int N, int H, int W, int Cout, int Cout_pad, half_t* im2col_ws /*[N*H*W][32]*/, const half_t* zero_page, hipStream_t s, float* gn_part = nullptr, int* gn_fused = nullptr);
-int conv_out_3x3_f32(const float* X_nhwc, const float* Wt /*[Cout][9*Cin]*/, const float* bias, float* y_nchw, int N, int H,
-                     int W, int Cin, int Cout, hipStream_t s);
+// output head (nn_head.hip): GroupNorm affine -> SiLU -> conv3x3 (C -> 3|6) in f32-equivalent arithmetic, y f32 NCHW.
+// wz = head_pack(w f32 [NO][9*C] (k = tap*C + c)): [2][64][C] f16 hi/lo.
+int head_pack(const float* w, int NO, int C, half_t* wz, hipStream_t s);
+int head_gn_silu_conv3x3(const half_t* X, const float* stats, const float* gamma, const float* beta, const half_t* wz,
+                         const float* bias, float* y_nchw, int N, int H, int W, int C, int NO, hipStream_t s);
 int timestep_mlp(const float* t, int N, int mc, const float* w0, const float* b0, const float* w2, const float* b2,
                  float* emb_silu /*[N][4mc] = silu(time_embed(t))*/, float* tmp, hipStream_t s);
 int gemv_rows(const float* Wm /*[R][K]*/, const float* b, const float* x /*[N][K]*/, float* y /*[N][R]*/, int R, int K, int N,

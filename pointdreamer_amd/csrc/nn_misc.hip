@@ -51,84 +51,6 @@ int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_out: X f32 NHWC [N,H,W,Cin] -> conv3x3 (f32 weights [Cout][9*Cin], k = tap*Cin + c) -> y f32 NCHW.
-// The head stays f32 like the reference (unet.py:613-617 is outside convert_to_fp16).  One wave owns PXW = 8
-// horizontally adjacent output pixels; lanes split the channels (c = lane + 64 j), the 6 x Cin/64 weights of a tap live
-// in registers and are reused by all 8 pixels; per (pixel, tap) each lane issues coalesced 256-B row reads.
-#define PXW 8
-template <int COUT, int Cin>
-__global__ __launch_bounds__(256) void k_conv_out(const float* __restrict__ X, const float* __restrict__ Wt,
-                                                  const float* __restrict__ bias, float* __restrict__ y, int H, int W,
-                                                  long long groups) {
-    constexpr int CJ = (Cin + 63) / 64;
-    const int lane = threadIdx.x & 63;
-    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    const int gpr = W / PXW;                                       // pixel groups per image row
-    for (long long g = wave; g < groups; g += nwaves) {
-        const int x0 = (int)(g % gpr) * PXW, yy = (int)((g / gpr) % H);
-        const long long n = g / ((long long)gpr * H);
-        float acc[PXW][COUT];
-#pragma unroll
-        for (int p = 0; p < PXW; ++p)
-#pragma unroll
-            for (int o = 0; o < COUT; ++o) acc[p][o] = 0.f;
-        for (int ky = 0; ky < 3; ++ky) {
-            const int sy = yy + ky - 1;
-            if (sy < 0 || sy >= H) continue;
-            const float* rowp = X + ((size_t)n * H + sy) * W * Cin;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float wv[COUT][CJ];
-#pragma unroll
-                for (int o = 0; o < COUT; ++o)
-#pragma unroll
-                    for (int j = 0; j < CJ; ++j)
-                        wv[o][j] = (lane + 64 * j < Cin) ? Wt[(size_t)o * 9 * Cin + (size_t)(ky * 3 + kx) * Cin + lane + 64 * j] : 0.f;
-#pragma unroll
-                for (int p = 0; p < PXW; ++p) {
-                    const int sx = x0 + p + kx - 1;
-                    if (sx < 0 || sx >= W) continue;
-                    const float* src = rowp + (size_t)sx * Cin;
-#pragma unroll
-                    for (int j = 0; j < CJ; ++j) {
-                        const float v = (lane + 64 * j < Cin) ? src[lane + 64 * j] : 0.f;
-#pragma unroll
-                        for (int o = 0; o < COUT; ++o) acc[p][o] += v * wv[o][j];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < PXW; ++p)
-#pragma unroll
-            for (int o = 0; o < COUT; ++o) {
-                float a = acc[p][o];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-                if (lane == 0) y[(((size_t)n * COUT + o) * H + yy) * W + x0 + p] = a + bias[o];
-            }
-    }
-}
-
-int conv_out_3x3_f32(const float* X_nhwc, const float* Wt, const float* bias, float* y_nchw, int N, int H, int W, int Cin,
-                     int Cout, hipStream_t s) {
-    PD_REQUIRE(Cout == 6 || Cout == 3, "conv_out_3x3_f32: Cout must be 3 or 6");
-    PD_REQUIRE(W % PXW == 0, "conv_out_3x3_f32: W must be a multiple of %d", PXW);
-    const long long groups = (long long)N * H * (W / PXW);
-    const int grid = (int)std::min<long long>((groups + 3) / 4, 16384);
-#define LCO(CO, CJ_) k_conv_out<CO, CJ_><<<grid, 256, 0, s>>>(X_nhwc, Wt, bias, y_nchw, H, W, groups)
-    if (Cin == 256) { if (Cout == 6) LCO(6, 256); else LCO(3, 256); }
-    else if (Cin == 128) { if (Cout == 6) LCO(6, 128); else LCO(3, 128); }
-    else if (Cin == 64) { if (Cout == 6) LCO(6, 64); else LCO(3, 64); }
-    else if (Cin == 32) { if (Cout == 6) LCO(6, 32); else LCO(3, 32); }
-    else PD_REQUIRE(false, "conv_out_3x3_f32: final channel count must be 32, 64, 128 or 256 (got %d)", Cin);
-#undef LCO
-    PD_LAUNCH_CHECK();
-    return PDHIP_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
 // y[n][r] = b[r] + sum_k W[r][k] x[n][k]   (one wave per output row r, all batch entries), f32.
 __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm, const float* __restrict__ b,
                                                    const float* __restrict__ x, float* __restrict__ y, int R, int K, int N,

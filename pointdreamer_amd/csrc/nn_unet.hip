@@ -49,7 +49,8 @@ struct pdhip_unet {
     // workspace
     char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
     float *stats = nullptr, *gn_ws = nullptr; size_t gn_ws_floats = 0;
-    float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr, *head_in = nullptr;
+    float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr;
+    half_t* head_wz = nullptr;                   // output-head weights as f16 hi/lo pairs (nn_head.hip)
     float *t_dev = nullptr;
     float* splitk_ws = nullptr; size_t splitk_floats = 0;
     // sampler state
@@ -281,8 +282,8 @@ int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* ou
     if (!dry) {
         PD_REQUIRE(u->out_norm.have_g && u->out_norm.have_b && u->have_ow && u->have_ob, "unet: output head not loaded");
         PD_TRY(run_gn_stats(c, h));
-        PD_TRY(gn_apply(h.p, u->stats, u->out_norm.g, u->out_norm.b, nullptr, 0, N, h.H, h.W, h.C, 1, 0, u->head_in, 1, s));
-        PD_TRY(conv_out_3x3_f32(u->head_in, u->out_w, u->out_b, out, N, h.H, h.W, h.C, u->out_ch, s));
+        PD_TRY(head_gn_silu_conv3x3(h.p, u->stats, u->out_norm.g, u->out_norm.b, u->head_wz, u->out_b, out, N, h.H, h.W, h.C,
+                                    u->out_ch, s));
     }
     return PDHIP_OK;
 }
@@ -403,7 +404,8 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     u->gn_ws_floats = (size_t)max_batch * ((S2 + 255) / 256) * 64;
     chk(dalloc(u, &u->stats, (size_t)max_batch * 64)); chk(dalloc(u, &u->gn_ws, u->gn_ws_floats));
     chk(dalloc(u, &u->emb_silu, (size_t)max_batch * u->ted)); chk(dalloc(u, &u->emb_tmp, (size_t)max_batch * (u->mc + u->ted)));
-    chk(dalloc(u, &u->emb_all, (size_t)max_batch * emb_rows)); chk(dalloc(u, &u->head_in, (size_t)max_batch * S2 * u->final_ch));
+    chk(dalloc(u, &u->emb_all, (size_t)max_batch * emb_rows));
+    { float* wz = nullptr; chk(dalloc(u, &wz, (size_t)64 * u->final_ch)); u->head_wz = reinterpret_cast<half_t*>(wz); }
     chk(dalloc(u, &u->t_dev, (size_t)max_batch));
     u->splitk_floats = (size_t)16 * 384 * 128 * 128;               // 16 splits x (< 384 tiles of 128x128) f32
     chk(dalloc(u, &u->splitk_ws, u->splitk_floats));
@@ -508,6 +510,7 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
         PD_TRY(want((long long)u->out_ch * u->final_ch * 9, "out conv weight"));
         k_pack_conv_f32<<<grid_for(numel), 256, 0, s>>>(data, is_f16, u->out_ch, u->final_ch, 9, u->out_w);
         PD_LAUNCH_CHECK();
+        PD_TRY(head_pack(u->out_w, u->out_ch, u->final_ch, u->head_wz, s));
         u->have_ow = true;
         return PDHIP_OK;
     }
@@ -679,6 +682,26 @@ extern "C" int pdhip_groupnorm_nhwc_f16(const void* x, const float* gamma, const
     PD_REQUIRE(x && gamma && beta && y && stats_ws && ws, "pdhip_groupnorm_nhwc_f16: null argument");
     PD_TRY(gn_stats((const half_t*)x, N, H * W, C, 1e-5f, stats_ws, ws, (size_t)ws_floats, as_stream(stream)));
     return gn_apply((const half_t*)x, stats_ws, gamma, beta, film, 2LL * C, N, H, W, C, silu, resample, y, 0, as_stream(stream));
+}
+// output head on its own: GroupNorm(32) statistics + the fused GN -> SiLU -> conv3x3 kernel (f32-equivalent arithmetic)
+extern "C" size_t pdhip_unet_head_ws_floats(int N, int H, int W, int C, int Cout) {
+    return (size_t)N * 64 + (size_t)N * 64 * ((H * W + 255) / 256) + (size_t)Cout * 9 * C + (size_t)64 * C;
+}
+extern "C" int pdhip_unet_head_f32(const void* x, const float* gamma, const float* beta, const float* w_oihw, const float* bias,
+                                   int N, int H, int W, int C, int Cout, float* y_nchw, float* ws, long long ws_floats, void* stream) {
+    PD_REQUIRE(x && gamma && beta && w_oihw && bias && y_nchw && ws, "pdhip_unet_head_f32: null argument");
+    PD_REQUIRE((size_t)ws_floats >= pdhip_unet_head_ws_floats(N, H, W, C, Cout), "pdhip_unet_head_f32: workspace too small");
+    hipStream_t s = as_stream(stream);
+    float* stats = ws;
+    float* gws = stats + (size_t)N * 64;
+    const size_t gws_floats = (size_t)N * 64 * ((H * W + 255) / 256);
+    float* wp = gws + gws_floats;
+    half_t* wz = reinterpret_cast<half_t*>(wp + (size_t)Cout * 9 * C);
+    PD_TRY(gn_stats((const half_t*)x, N, H * W, C, 1e-5f, stats, gws, gws_floats, s));
+    k_pack_conv_f32<<<grid_for((long long)Cout * 9 * C), 256, 0, s>>>(w_oihw, 0, Cout, C, 9, wp);
+    PD_LAUNCH_CHECK();
+    PD_TRY(head_pack(wp, Cout, C, wz, s));
+    return head_gn_silu_conv3x3((const half_t*)x, stats, gamma, beta, wz, bias, y_nchw, N, H, W, C, Cout, s);
 }
 extern "C" int pdhip_attention_f16(const void* qkv, void* out, int N, int T, int C, int head_dim, void* stream) {
     PD_REQUIRE(qkv && out, "pdhip_attention_f16: null argument");

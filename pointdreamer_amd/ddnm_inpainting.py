@@ -38,6 +38,8 @@ _reg('pdhip_debug_set_conv_stages', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_tile', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_splitk', C.c_int, [vp, C.c_longlong, i32])
 _reg('pdhip_pack_conv_weight_f16', C.c_int, [vp, i32, i32, i32, vp, vp])
+_reg('pdhip_unet_head_ws_floats', C.c_size_t, [i32, i32, i32, i32, i32])
+_reg('pdhip_unet_head_f32', C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, C.c_longlong, vp])
 _reg('pdhip_conv2d_nhwc_f16', C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_groupnorm_nhwc_f16', C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.c_longlong, vp])
 _reg('pdhip_attention_f16', C.c_int, [vp, vp, i32, i32, i32, i32, vp])

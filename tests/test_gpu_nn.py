@@ -117,6 +117,28 @@ def test_groupnorm_silu_film_resample_vs_torch(nn, N, H, W, Cc, film, silu, resa
     assert (out - ref).abs().max().item() <= 6e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("N,H,W,Cc,Cout", [(2, 32, 32, 256, 6), (1, 24, 40, 64, 3), (1, 16, 64, 128, 6), (3, 8, 32, 32, 6)])
+def test_output_head_f32_equivalent_vs_torch(nn, N, H, W, Cc, Cout):
+    """GN -> SiLU -> conv3x3 head (unet.py:613-617, f32 in the reference): the fused kernel's f16 hi/lo split must be
+    f32-accurate (1e-5 of the output scale), including tiles that straddle the image border (H, W not multiples of 8/32)."""
+    L = nn['L']
+    g = torch.Generator().manual_seed(Cc + H + Cout)
+    x = (torch.randn((N, Cc, H, W), generator=g) * 1.3 + 0.2).half().float()
+    gamma = 1 + 0.2 * torch.randn((Cc,), generator=g)
+    beta = 0.2 * torch.randn((Cc,), generator=g)
+    w = torch.randn((Cout, Cc, 3, 3), generator=g) / math.sqrt(9 * Cc)
+    b = 0.1 * torch.randn((Cout,), generator=g)
+    ref = F.conv2d(F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), eps=1e-5)), w.double(), b.double(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    gd, bd, wd, cd = gamma.to(DEV), beta.to(DEV), w.contiguous().to(DEV), b.to(DEV)
+    y = torch.empty((N, Cout, H, W), device=DEV)
+    ws = torch.empty((L.pdhip_unet_head_ws_floats(N, H, W, Cc, Cout),), device=DEV)
+    rc = L.pdhip_unet_head_f32(_ptr(xd), _ptr(gd), _ptr(bd), _ptr(wd), _ptr(cd), N, H, W, Cc, Cout, _ptr(y), _ptr(ws), ws.numel(), _stream())
+    assert rc == 0, L.pdhip_last_error()
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("N,T,Cc,D", [(1, 64, 128, 64), (2, 256, 128, 32), (1, 1024, 512, 64), (2, 64, 1024, 64)])
 def test_attention_vs_torch(nn, N, T, Cc, D):
     L = nn['L']
