@@ -60,6 +60,8 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     constexpr int STAGE_BYTES = A_BYTES + BNT * ROWB;
     constexpr int CS_LD = BNT + 8;                // epilogue tile leading dimension (halfs)
     constexpr int KSTEPS = BKT / 32;              // MFMA k-steps per K-step
+    constexpr bool PIPE = NSTAGE == 12;           // NSTAGE 12 = two LDS stages + register-pipelined fragment schedule
+    constexpr int NST = PIPE ? 2 : NSTAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -126,17 +128,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     for (int i = 0; i < LPO; ++i) ap[i] += astep[i] * nc;
 #pragma unroll
     for (int i = 0; i < LPB; ++i) bp[i] += (size_t)it0 * BKT;
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < LPO; ++i) {
-            glds16(ap[i], wave_dst + stage * STAGE_BYTES + i * 1024);
-            ap[i] += astep[i];
+    // one 1 KiB LDS-DMA piece of a stage (p < LPO: activation rows, else weight rows) / the K-step bookkeeping after the last
+    auto issue_piece = [&](int stage, int p) {
+        if (p < LPO) {
+            glds16(ap[p], wave_dst + stage * STAGE_BYTES + p * 1024);
+            ap[p] += astep[p];
+        } else {
+            glds16(bp[p - LPO], wave_dst_b + stage * STAGE_BYTES + (p - LPO) * 1024);
+            bp[p - LPO] += BKT;
         }
-#pragma unroll
-        for (int i = 0; i < LPB; ++i) {
-            glds16(bp[i], wave_dst_b + stage * STAGE_BYTES + i * 1024);
-            bp[i] += BKT;
-        }
+    };
+    auto issue_advance = [&]() {
         if (TAPS == 1) {
             if (X2 != nullptr && ++nc == Cin1 / BKT) {     // the concat's first tensor is exhausted: continue in the second
 #pragma unroll
@@ -146,6 +148,11 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
             nc = 0;
             if (++ntap < TAPS) set_tap(ntap);
         }
+    };
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < LPO + LPB; ++p) issue_piece(stage, p);
+        issue_advance();
     };
 
     // ---- consumer role: fragment byte offset inside a 16-row group (row = lane&15, k-chunk = lane>>4 (+4 per k-step))
@@ -159,17 +166,109 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+    constexpr int OPS_ = LPO + LPB;
+    if constexpr (PIPE) {
+        // Register-pipelined schedule.  A K-step is G = KSTEPS*TM groups of 4 MFMAs (one A fragment x 4 B fragments).  The
+        // A fragment of group g+2 is read from LDS while group g multiplies (ring of 4 registers), the B fragments of the
+        // second k-step are read during groups 0..3.  The stage hand-over (vmcnt wait + barrier + LDS-DMA issue for K-step
+        // it+2 + first fragment reads of K-step it+1) sits in front of the LAST TWO groups, whose 8 MFMAs cover the barrier
+        // skew and the LDS latency of the next step's first reads.
+        // hipcc only emits lgkmcnt(0) around LDS-DMA kernels, which would expose every read's latency, so the fragment reads
+        // are inline-asm ds_read_b128 with hand-counted s_waitcnt lgkmcnt(N): LDS reads return in issue order, N = number of
+        // reads issued after the one a group needs (table below).  No scalar loads may sit in this loop (they share lgkmcnt).
+        static_assert(BKT == 64 && (TM == 4 || TM == 8), "pipelined schedule: BKT 64, TM 4 or 8");
+        static_assert(OPS_ == 6 || OPS_ == 8 || OPS_ == 12, "unexpected loads per stage");
+        constexpr int G = KSTEPS * TM;
+#define PD_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        const uint32_t a_base = lds0 + (wm * TM * 16) * ROWB, b_base = lds0 + TILE_BYTES + (wn * 64) * ROWB;
+        half8 ar[4], bf[KSTEPS][4];
+        // LDS-DMA pieces of K-step it+1 are spread over the MFMA groups (PPG per group): the first two groups' worth right
+        // after the hand-over of K-step it-1 (groups G-2, G-1), the rest in groups 0.. of K-step it -- an LDS-DMA issue costs
+        // ~60+ cycles of the wave's issue slot, which hides behind the preceding group's MFMAs instead of stalling the pipe
+        constexpr int PPG = OPS_ / 6 >= 2 ? 2 : 1;           // pieces per group (12 pieces -> 2)
+        constexpr int NPG = OPS_ / PPG;                       // groups that carry pieces: 2 at the hand-over + NPG-2 after it
+        static_assert(NPG - 2 <= G - 2, "not enough MFMA groups to carry the LDS-DMA pieces");
+        issue(0);
+        if (it0 + 1 < it1) {
+#pragma unroll
+            for (int p = 0; p < 2 * PPG; ++p) issue_piece(1, p);
+            if (PPG == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const uint32_t b0 = b_base + frag_off[0], a0 = a_base + frag_off[0];
+            PD_DSR(bf[0][0], b0, 0); PD_DSR(bf[0][1], b0, 16 * ROWB); PD_DSR(bf[0][2], b0, 32 * ROWB); PD_DSR(bf[0][3], b0, 48 * ROWB);
+            PD_DSR(ar[0], a0, 0); PD_DSR(ar[1], a0, 16 * ROWB);
+        }
+        int cur = 0;
+        for (int it = it0; it < it1; ++it) {
+            const uint32_t a_ad0 = a_base + cur * STAGE_BYTES + frag_off[0], a_ad1 = a_base + cur * STAGE_BYTES + frag_off[1];
+            const uint32_t b_ad1 = b_base + cur * STAGE_BYTES + frag_off[1];
+            const uint32_t a_nx0 = a_base + (cur ^ 1) * STAGE_BYTES + frag_off[0], b_nx0 = b_base + (cur ^ 1) * STAGE_BYTES + frag_off[0];
+            const bool more = it + 1 < it1;
+            // reads still allowed in flight when group g starts (TM 8: A(g+1), A(g+2) (+ the interleaved B reads); TM 4 likewise)
+#define PD_WAITN(g_) ((TM == 8) ? ((g_) == 0 ? 3 : (g_) == 1 ? 4 : (g_) == 2 ? 5 : (g_) == 3 ? 5 : (g_) == 4 ? 4 : (g_) == 5 ? 3 : 2) \
+                                : ((g_) == 0 ? 3 : (g_) == 1 ? 4 : (g_) == 2 ? 5 : (g_) == 3 ? 5 : (g_) == 4 ? 1 : 2))
+#define PD_GROUP(g)                                                                                                      \
+    if constexpr ((g) < G) {                                                                                             \
+        if constexpr ((g) + 2 < G) {                                                                                     \
+            if constexpr (((g) + 2) / TM == 0) PD_DSR(ar[((g) + 2) & 3], a_ad0, (((g) + 2) % TM) * 16 * ROWB);           \
+            else PD_DSR(ar[((g) + 2) & 3], a_ad1, (((g) + 2) % TM) * 16 * ROWB);                                         \
+        }                                                                                                                \
+        if constexpr ((g) < 4) PD_DSR(bf[1][(g) & 3], b_ad1, ((g) & 3) * 16 * ROWB);                                     \
+        if constexpr ((g) == G - 2) {                                                                                    \
+            if (more) {                                                                                                  \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]) :: "memory");  \
+                __builtin_amdgcn_s_barrier();                                                                            \
+                asm volatile("" ::: "memory");                                                                           \
+                PD_DSR(bf[0][0], b_nx0, 0); PD_DSR(bf[0][1], b_nx0, 16 * ROWB);                                          \
+                PD_DSR(bf[0][2], b_nx0, 32 * ROWB); PD_DSR(bf[0][3], b_nx0, 48 * ROWB);                                  \
+                PD_DSR(ar[0], a_nx0, 0);                                                                                 \
+                if (it + 2 < it1) { _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur, p); }               \
+            } else {                                                                                                     \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]));                       \
+            }                                                                                                            \
+        } else if constexpr ((g) == G - 1) {                                                                             \
+            if (more) PD_DSR(ar[1], a_nx0, 16 * ROWB);                                                                   \
+            if (it + 2 < it1) { _Pragma("unroll") for (int p = PPG; p < 2 * PPG; ++p) issue_piece(cur, p); }             \
+        } else {                                                                                                         \
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ar[(g) & 3]) : "n"(PD_WAITN(g)));                                \
+            if constexpr ((g) == 0) asm volatile("" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[0][3]));    \
+            if constexpr ((g) == TM) asm volatile("" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]), "+v"(bf[1][3]));   \
+        }                                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+            acc[(g) % TM][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[(g) & 3], bf[(g) / TM][j], acc[(g) % TM][j], 0, 0, 0); \
+        if constexpr ((g) < NPG - 2) {                                                                                   \
+            if (more) {                                                                                                  \
+                _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur ^ 1, (2 + (g)) * PPG + p);               \
+                if constexpr ((g) == NPG - 3) issue_advance();                                                           \
+            }                                                                                                            \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+            PD_GROUP(0) PD_GROUP(1) PD_GROUP(2) PD_GROUP(3) PD_GROUP(4) PD_GROUP(5) PD_GROUP(6) PD_GROUP(7)
+            PD_GROUP(8) PD_GROUP(9) PD_GROUP(10) PD_GROUP(11) PD_GROUP(12) PD_GROUP(13) PD_GROUP(14) PD_GROUP(15)
+#undef PD_GROUP
+#undef PD_WAITN
+            cur ^= 1;
+        }
+#undef PD_DSR
+    } else {
     // Software pipeline: NSTAGE LDS stages, loads run NSTAGE-1 K-steps ahead and stay in flight ACROSS the barrier
     // (counted s_waitcnt vmcnt + raw s_barrier; __syncthreads() would drain the LDS-DMA queue -- cdna guide T3/T4).
-    constexpr int D = NSTAGE - 1;                          // prefetch distance
+    constexpr int D = NST - 1;                          // prefetch distance
     constexpr int OPS = LPO + LPB;                         // VMEM ops per lane per stage
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (it0 + d < it1) issue(d);
-    int cur = 0, nxt = D % NSTAGE;
+    int cur = 0, nxt = D % NST;
     for (int it = it0; it < it1; ++it) {
         const int inflight = min(D, it1 - it);             // stages issued and not yet consumed (incl. this one)
         static_assert(OPS == 3 || OPS == 4 || OPS == 6 || OPS == 8 || OPS == 12, "unexpected loads per stage");
+#ifndef PD_LAB_NOWAIT                                      // (lab builds only: timing without the load dependency)
         if (D >= 3 && inflight >= 3) {
             if (OPS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else if (OPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -183,7 +282,10 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
             else if (OPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef PD_LAB_NOBARRIER
         __builtin_amdgcn_s_barrier();                      // stage `cur` landed for every wave; stage `nxt` is free again
+#endif
         asm volatile("" ::: "memory");
         if (it + D < it1) issue(nxt);
         const char* As = smem + cur * STAGE_BYTES + (wm * TM * 16) * ROWB;
@@ -191,19 +293,38 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             half8 a[TM], b[4];
+#ifdef PD_LAB_NOLDS                                        // (lab builds only: MFMA-only ceiling, fragments from registers)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b[j] = (half8){(half_t)j, 1, 2, 3, 4, 5, 6, (half_t)lane}; asm volatile("" : "+v"(b[j])); }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { a[i] = (half8){(half_t)i, 1, 2, 3, 4, 5, 6, (half_t)kk}; asm volatile("" : "+v"(a[i])); }
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * ROWB + frag_off[kk]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-        nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+        cur = (cur + 1 == NST) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
+    }
     }
     __syncthreads();                                       // all fragment reads done before the tile is reused
+#ifdef PD_LAB_NOEPI                                        // (lab builds only: mainloop without the epilogue)
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123456.789f) Y[0] = (half_t)t;
+        return;
+    }
+#endif
 
     if (partial != nullptr) {                              // split-K: raw f32 partial tile, reduced by k_splitk_reduce
         float* P = partial + (size_t)blockIdx.y * (size_t)M * Cout;
@@ -397,21 +518,28 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const bool fuse_sk = gn_part != nullptr && splits > 1 && ((long long)H * W) % SK_ROWS == 0;   // stats from the reduce kernel
     if (gn_fused) *gn_fused = fuse ? (int)(((long long)H * W) / bmt) : fuse_sk ? (int)(((long long)H * W) / SK_ROWS) : 0;
     float* gnp = fuse ? gn_part : nullptr;
-    int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);
+    int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);     // 12 = two stages + register-pipelined schedule
+    const bool pipe = stages == 12 && bk == 64;
+    if (pipe) stages = 2;
     if (stages < 2) stages = 2;
     if (stages > 4) stages = 4;
     const size_t stage_bytes = (size_t)(bmt + bnt) * bk * 2;
     while (stages > 2 && stages * stage_bytes > 160 * 1024) --stages;
     const size_t smem = std::max<size_t>((size_t)stages * stage_bytes, (size_t)bmt * (bnt + 8) * 2);
+    if (pipe) stages = 12;
 #define ARGS grid, smem, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, partial, gnp, X2, Cin1
 #define BY_STAGE(T, B, WM_, WN_, TM_)                                                   \
     (stages == 2 ? launch_conv<T, B, 2, WM_, WN_, TM_>(ARGS) : stages == 3 ? launch_conv<T, B, 3, WM_, WN_, TM_>(ARGS) \
                                                               : launch_conv<T, B, 4, WM_, WN_, TM_>(ARGS))
+#define BY_STAGE64(T, WM_, WN_, TM_) (stages == 12 ? launch_conv<T, 64, 12, WM_, WN_, TM_>(ARGS) : BY_STAGE(T, 64, WM_, WN_, TM_))
 #define BY_GEO(T, B) (geo == 2 ? BY_STAGE(T, B, 2, 2, 4) : geo == 4 ? BY_STAGE(T, B, 4, 2, 4) : geo == 8 ? BY_STAGE(T, B, 2, 4, 8) : BY_STAGE(T, B, 2, 2, 8))
+#define BY_GEO64(T) (geo == 2 ? BY_STAGE64(T, 2, 2, 4) : geo == 4 ? BY_STAGE64(T, 4, 2, 4) : geo == 8 ? BY_STAGE64(T, 2, 4, 8) : BY_STAGE64(T, 2, 2, 8))
     int rc;
-    if (taps == 9) rc = (bk == 64) ? BY_GEO(9, 64) : BY_GEO(9, 32);
-    else rc = (bk == 64) ? BY_GEO(1, 64) : BY_GEO(1, 32);
+    if (taps == 9) rc = (bk == 64) ? BY_GEO64(9) : BY_GEO(9, 32);
+    else rc = (bk == 64) ? BY_GEO64(1) : BY_GEO(1, 32);
+#undef BY_GEO64
 #undef BY_GEO
+#undef BY_STAGE64
 #undef BY_STAGE
 #undef ARGS
     if (rc) return rc;

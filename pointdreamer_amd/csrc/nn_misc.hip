@@ -51,39 +51,71 @@ int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// y[n][r] = b[r] + sum_k W[r][k] x[n][k]   (one wave per output row r, all batch entries), f32.
+// y[n][r] = b[r] + sum_k W[r][k] x[n][k], f32 (time-embedding MLP and every ResBlock's emb_layers in one call).
+// HBM-bound on the weight stream: x (<= 8 x K floats per pass) is staged in LDS once per block, a wave owns
+// GEMV_ROWS/4 rows and streams each row with 16-byte loads; batch entries are processed 8 at a time.
+#define GEMV_ROWS 64
 __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm, const float* __restrict__ b,
                                                    const float* __restrict__ x, float* __restrict__ y, int R, int K, int N,
                                                    int silu_out) {
-    const int lane = threadIdx.x & 63;
-    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= R) return;
+    extern __shared__ __attribute__((aligned(16))) float s_x[];          // [8][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * GEMV_ROWS + wave * (GEMV_ROWS / 4);
     for (int n0 = 0; n0 < N; n0 += 8) {
-        float acc[8];
+        const int nb = min(8, N - n0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * K; i += 256) s_x[i] = (i / K < nb) ? x[(size_t)n0 * K + i] : 0.f;
+        __syncthreads();
+        for (int rr = 0; rr < GEMV_ROWS / 4; rr += 4) {          // 4 rows at a time: 4 x K/64 independent 16-byte loads in flight
+            const int r = r0 + rr;
+            if (r >= R) break;
+            float acc[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            const float w = Wm[(size_t)r * K + k];
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (n0 + j < N) acc[j] += w * x[(size_t)(n0 + j) * K + k];
-        }
+                for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+            if ((K & 3) == 0) {
+                for (int k = lane * 4; k < K; k += 256) {
+                    float4 w[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float a = acc[j];
+                    for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const float4*>(Wm + (size_t)min(r + q, R - 1) * K + k);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-            if (lane == 0 && n0 + j < N) {
-                a += b[r];
-                if (silu_out) a = a / (1.0f + expf(-a));
-                y[(size_t)(n0 + j) * R + r] = a;
+                    for (int j = 0; j < 8; ++j) {
+                        const float4 xv = *reinterpret_cast<const float4*>(s_x + j * K + k);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q][j] += w[q].x * xv.x + w[q].y * xv.y + w[q].z * xv.z + w[q].w * xv.w;
+                    }
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float w = Wm[(size_t)min(r + q, R - 1) * K + k];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[q][j] += w * s_x[j * K + k];
+                    }
+                }
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = acc[q][j];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                    if (lane == 0 && j < nb && r + q < R) {
+                        a += b[r + q];
+                        if (silu_out) a = a / (1.0f + expf(-a));
+                        y[(size_t)(n0 + j) * R + r + q] = a;
+                    }
+                }
         }
     }
 }
 
 static int gemv_launch(const float* Wm, const float* b, const float* x, float* y, int R, int K, int N, int silu_out, hipStream_t s) {
-    k_gemv_rows<<<cdiv((long long)R * 64, 256), 256, 0, s>>>(Wm, b, x, y, R, K, N, silu_out);
+    PD_REQUIRE((size_t)8 * K * sizeof(float) <= 64 * 1024, "gemv_rows: K too large (%d)", K);
+    k_gemv_rows<<<cdiv(R, GEMV_ROWS), 256, (size_t)8 * K * sizeof(float), s>>>(Wm, b, x, y, R, K, N, silu_out);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -279,14 +279,15 @@ def test_philox_normal_stream(nn):
 
 
 @pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4),
-                                           (64, 2, 8)])
+                                           (64, 2, 8), (64, 12, 2), (64, 12, 4), (64, 12, 8), (64, 12, 16)])
 def test_conv_igemm_all_kernel_variants(nn, bk, stages, wmw):
-    """Every (K-step, pipeline depth, tile height) instantiation of the conv kernel computes the same convolution."""
+    """Every (K-step, pipeline depth, tile height) instantiation of the conv kernel computes the same convolution
+    (stages 12 = two LDS stages with the hand-scheduled register-pipelined fragment loop)."""
     L = nn['L']
     old = (L.pdhip_debug_set_conv_bk(bk), L.pdhip_debug_set_conv_stages(stages), L.pdhip_debug_set_conv_tile(wmw))
     try:
         for (N, H, W, Cin, Cout, k, res) in [(2, 16, 16, 128, 192, 3, True), (1, 24, 24, 64, 128, 1, False), (3, 8, 8, 256, 64, 3, False),
-                                             (2, 16, 16, 128, 256, 3, True), (1, 20, 20, 64, 512, 1, False)]:
+                                             (2, 16, 16, 128, 256, 3, True), (1, 20, 20, 64, 512, 1, False), (1, 32, 32, 64, 256, 3, False)]:
             g = torch.Generator().manual_seed(bk + stages + wmw + Cin)
             x = torch.randn((N, Cin, H, W), generator=g).half().float()
             w = (torch.randn((Cout, Cin, k, k), generator=g) / math.sqrt(Cin * k * k)).half().float()

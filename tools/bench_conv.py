@@ -5,14 +5,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pointdreamer_amd import _lib
 import pointdreamer_amd.ddnm_inpainting  # noqa
-L = _lib.lib()
 P = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (8, 256, 256, 256, 256, 9), (8, 256, 256, 512, 256, 9), (8, 128, 128, 256, 256, 9), (8, 64, 64, 512, 512, 9),
     (8, 64, 64, 1024, 512, 9), (8, 32, 32, 512, 512, 9), (8, 128, 128, 512, 256, 9), (8, 256, 256, 512, 256, 1),
     (8, 32, 32, 512, 1536, 1)]
 ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64x2x8', '64x3x16', '64x2x16', '64x2x8']); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--shapes', type=int, nargs='*', default=None)
+ap.add_argument('--custom', type=int, nargs='*', default=None, help='extra shapes as N H W Cin Cout taps ...')
+ap.add_argument('--lib', default=None, help='alternative libpdhip.so (lab builds)')
 a = ap.parse_args()
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
+L = _lib.lib()
+if a.custom:
+    SHAPES = [tuple(a.custom[i:i + 6]) for i in range(0, len(a.custom), 6)]
 dev = 'cuda:0'
 zp = torch.zeros(128, dtype=torch.float16, device=dev)
 for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
