@@ -168,72 +168,70 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
 
     constexpr int OPS_ = LPO + LPB;
     if constexpr (PIPE) {
-        // Register-pipelined schedule.  A K-step is G = KSTEPS*TM groups of 4 MFMAs (one A fragment x 4 B fragments).  The
-        // A fragment of group g+2 is read from LDS while group g multiplies (ring of 4 registers), the B fragments of the
-        // second k-step are read during groups 0..3.  The stage hand-over (vmcnt wait + barrier + LDS-DMA issue for K-step
-        // it+2 + first fragment reads of K-step it+1) sits in front of the LAST TWO groups, whose 8 MFMAs cover the barrier
-        // skew and the LDS latency of the next step's first reads.
+        // Register-pipelined schedule.  A K-step is G = 16 groups of 4 MFMAs (one A fragment x 4 B fragments; groups 0..7 are
+        // MFMA k-step 0, 8..15 k-step 1).  The A fragment of group g+3 is read from LDS at the start of group g into the ring
+        // slot group g-1 just released (ring of 4 registers), the B fragments of k-step 1 are read during groups 0..3.  The
+        // stage hand-over (vmcnt wait + barrier, then the first fragment reads of K-step it+1) sits in front of the LAST THREE
+        // groups, whose 12 MFMAs cover the barrier skew and the LDS latency of the next step's first reads.  The LDS-DMA pieces
+        // of K-step it+2 follow one per group (an LDS-DMA issue costs ~60+ cycles of the wave's issue slot: behind a group's
+        // MFMAs it is free, in a block it stalls the pipe).
         // hipcc only emits lgkmcnt(0) around LDS-DMA kernels, which would expose every read's latency, so the fragment reads
         // are inline-asm ds_read_b128 with hand-counted s_waitcnt lgkmcnt(N): LDS reads return in issue order, N = number of
         // reads issued after the one a group needs (table below).  No scalar loads may sit in this loop (they share lgkmcnt).
-        static_assert(BKT == 64 && (TM == 4 || TM == 8), "pipelined schedule: BKT 64, TM 4 or 8");
-        static_assert(OPS_ == 6 || OPS_ == 8 || OPS_ == 12, "unexpected loads per stage");
+        static_assert(BKT == 64 && TM == 8, "pipelined schedule: BKT 64, TM 8");
+        static_assert(OPS_ == 8 || OPS_ == 12, "unexpected loads per stage");
         constexpr int G = KSTEPS * TM;
+        constexpr int HO = G - 3;                             // hand-over group
+        constexpr int PPG = OPS_ == 12 ? 2 : 1;              // LDS-DMA pieces per group
+        constexpr int NPG = OPS_ / PPG;                       // groups that carry pieces: 3 from the hand-over + NPG-3 after it
 #define PD_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
         const uint32_t a_base = lds0 + (wm * TM * 16) * ROWB, b_base = lds0 + TILE_BYTES + (wn * 64) * ROWB;
         half8 ar[4], bf[KSTEPS][4];
-        // LDS-DMA pieces of K-step it+1 are spread over the MFMA groups (PPG per group): the first two groups' worth right
-        // after the hand-over of K-step it-1 (groups G-2, G-1), the rest in groups 0.. of K-step it -- an LDS-DMA issue costs
-        // ~60+ cycles of the wave's issue slot, which hides behind the preceding group's MFMAs instead of stalling the pipe
-        constexpr int PPG = OPS_ / 6 >= 2 ? 2 : 1;           // pieces per group (12 pieces -> 2)
-        constexpr int NPG = OPS_ / PPG;                       // groups that carry pieces: 2 at the hand-over + NPG-2 after it
-        static_assert(NPG - 2 <= G - 2, "not enough MFMA groups to carry the LDS-DMA pieces");
         issue(0);
         if (it0 + 1 < it1) {
 #pragma unroll
-            for (int p = 0; p < 2 * PPG; ++p) issue_piece(1, p);
-            if (PPG == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            for (int p = 0; p < 3 * PPG; ++p) issue_piece(1, p);
+            if (PPG == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         {
             const uint32_t b0 = b_base + frag_off[0], a0 = a_base + frag_off[0];
             PD_DSR(bf[0][0], b0, 0); PD_DSR(bf[0][1], b0, 16 * ROWB); PD_DSR(bf[0][2], b0, 32 * ROWB); PD_DSR(bf[0][3], b0, 48 * ROWB);
-            PD_DSR(ar[0], a0, 0); PD_DSR(ar[1], a0, 16 * ROWB);
+            PD_DSR(ar[0], a0, 0); PD_DSR(ar[1], a0, 16 * ROWB); PD_DSR(ar[2], a0, 32 * ROWB);
         }
         int cur = 0;
         for (int it = it0; it < it1; ++it) {
             const uint32_t a_ad0 = a_base + cur * STAGE_BYTES + frag_off[0], a_ad1 = a_base + cur * STAGE_BYTES + frag_off[1];
             const uint32_t b_ad1 = b_base + cur * STAGE_BYTES + frag_off[1];
             const uint32_t a_nx0 = a_base + (cur ^ 1) * STAGE_BYTES + frag_off[0], b_nx0 = b_base + (cur ^ 1) * STAGE_BYTES + frag_off[0];
-            const bool more = it + 1 < it1;
-            // reads still allowed in flight when group g starts (TM 8: A(g+1), A(g+2) (+ the interleaved B reads); TM 4 likewise)
-#define PD_WAITN(g_) ((TM == 8) ? ((g_) == 0 ? 3 : (g_) == 1 ? 4 : (g_) == 2 ? 5 : (g_) == 3 ? 5 : (g_) == 4 ? 4 : (g_) == 5 ? 3 : 2) \
-                                : ((g_) == 0 ? 3 : (g_) == 1 ? 4 : (g_) == 2 ? 5 : (g_) == 3 ? 5 : (g_) == 4 ? 1 : 2))
+            const bool more = it + 1 < it1, more2 = it + 2 < it1;
+            // reads still allowed in flight when group g starts: A(g+1..g+3) plus the B reads interleaved after A(g)
+#define PD_WAITN(g_) ((g_) == 0 ? 4 : (g_) == 1 ? 5 : (g_) == 2 ? 6 : (g_) == 3 ? 7 : (g_) == 4 ? 6 : (g_) == 5 ? 5 : (g_) == 6 ? 4 : 3)
 #define PD_GROUP(g)                                                                                                      \
-    if constexpr ((g) < G) {                                                                                             \
-        if constexpr ((g) + 2 < G) {                                                                                     \
-            if constexpr (((g) + 2) / TM == 0) PD_DSR(ar[((g) + 2) & 3], a_ad0, (((g) + 2) % TM) * 16 * ROWB);           \
-            else PD_DSR(ar[((g) + 2) & 3], a_ad1, (((g) + 2) % TM) * 16 * ROWB);                                         \
+    {                                                                                                                    \
+        if constexpr ((g) + 3 < G) {                                                                                     \
+            if constexpr (((g) + 3) / TM == 0) PD_DSR(ar[((g) + 3) & 3], a_ad0, (((g) + 3) % TM) * 16 * ROWB);           \
+            else PD_DSR(ar[((g) + 3) & 3], a_ad1, (((g) + 3) % TM) * 16 * ROWB);                                         \
         }                                                                                                                \
         if constexpr ((g) < 4) PD_DSR(bf[1][(g) & 3], b_ad1, ((g) & 3) * 16 * ROWB);                                     \
-        if constexpr ((g) == G - 2) {                                                                                    \
+        if constexpr ((g) == HO) {                                                                                       \
             if (more) {                                                                                                  \
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]) :: "memory");  \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]), "+v"(ar[((g) + 2) & 3]) :: "memory"); \
                 __builtin_amdgcn_s_barrier();                                                                            \
                 asm volatile("" ::: "memory");                                                                           \
                 PD_DSR(bf[0][0], b_nx0, 0); PD_DSR(bf[0][1], b_nx0, 16 * ROWB);                                          \
                 PD_DSR(bf[0][2], b_nx0, 32 * ROWB); PD_DSR(bf[0][3], b_nx0, 48 * ROWB);                                  \
                 PD_DSR(ar[0], a_nx0, 0);                                                                                 \
-                if (it + 2 < it1) { _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur, p); }               \
             } else {                                                                                                     \
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]));                       \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]), "+v"(ar[((g) + 2) & 3])); \
             }                                                                                                            \
-        } else if constexpr ((g) == G - 1) {                                                                             \
+        } else if constexpr ((g) == HO + 1) {                                                                            \
             if (more) PD_DSR(ar[1], a_nx0, 16 * ROWB);                                                                   \
-            if (it + 2 < it1) { _Pragma("unroll") for (int p = PPG; p < 2 * PPG; ++p) issue_piece(cur, p); }             \
+        } else if constexpr ((g) == HO + 2) {                                                                            \
+            if (more) PD_DSR(ar[2], a_nx0, 32 * ROWB);                                                                   \
         } else {                                                                                                         \
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ar[(g) & 3]) : "n"(PD_WAITN(g)));                                \
             if constexpr ((g) == 0) asm volatile("" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[0][3]));    \
@@ -241,10 +239,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
         }                                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
             acc[(g) % TM][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[(g) & 3], bf[(g) / TM][j], acc[(g) % TM][j], 0, 0, 0); \
-        if constexpr ((g) < NPG - 2) {                                                                                   \
+        if constexpr ((g) >= HO) {                       /* pieces 0..2 of K-step it+2 into the stage just drained */      \
+            if (more2) { _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur, ((g) - HO) * PPG + p); }       \
+        } else if constexpr ((g) < NPG - 3) {            /* the remaining pieces of K-step it+1 */                       \
             if (more) {                                                                                                  \
-                _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur ^ 1, (2 + (g)) * PPG + p);               \
-                if constexpr ((g) == NPG - 3) issue_advance();                                                           \
+                _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur ^ 1, (3 + (g)) * PPG + p);               \
+                if constexpr ((g) == NPG - 4) issue_advance();                                                           \
             }                                                                                                            \
         }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -518,9 +518,10 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const bool fuse_sk = gn_part != nullptr && splits > 1 && ((long long)H * W) % SK_ROWS == 0;   // stats from the reduce kernel
     if (gn_fused) *gn_fused = fuse ? (int)(((long long)H * W) / bmt) : fuse_sk ? (int)(((long long)H * W) / SK_ROWS) : 0;
     float* gnp = fuse ? gn_part : nullptr;
-    int stages = g_force_stages ? g_force_stages : (bk == 64 ? 2 : 3);     // 12 = two stages + register-pipelined schedule
-    const bool pipe = stages == 12 && bk == 64;
-    if (pipe) stages = 2;
+    // 12 = two stages + register-pipelined schedule: the default for the 256x256 tile (+8..16 % over the compiler's schedule)
+    int stages = g_force_stages ? g_force_stages : (bk == 64 ? (geo == 8 ? 12 : 2) : 3);
+    const bool pipe = stages == 12 && bk == 64 && (geo == 8 || geo == 16);   // written for the 128-row wave tile
+    if (stages == 12) stages = 2;
     if (stages < 2) stages = 2;
     if (stages > 4) stages = 4;
     const size_t stage_bytes = (size_t)(bmt + bnt) * bk * 2;
@@ -533,7 +534,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
                                                               : launch_conv<T, B, 4, WM_, WN_, TM_>(ARGS))
 #define BY_STAGE64(T, WM_, WN_, TM_) (stages == 12 ? launch_conv<T, 64, 12, WM_, WN_, TM_>(ARGS) : BY_STAGE(T, 64, WM_, WN_, TM_))
 #define BY_GEO(T, B) (geo == 2 ? BY_STAGE(T, B, 2, 2, 4) : geo == 4 ? BY_STAGE(T, B, 4, 2, 4) : geo == 8 ? BY_STAGE(T, B, 2, 4, 8) : BY_STAGE(T, B, 2, 2, 8))
-#define BY_GEO64(T) (geo == 2 ? BY_STAGE64(T, 2, 2, 4) : geo == 4 ? BY_STAGE64(T, 4, 2, 4) : geo == 8 ? BY_STAGE64(T, 2, 4, 8) : BY_STAGE64(T, 2, 2, 8))
+#define BY_GEO64(T) (geo == 2 ? BY_STAGE(T, 64, 2, 2, 4) : geo == 4 ? BY_STAGE(T, 64, 4, 2, 4) : geo == 8 ? BY_STAGE64(T, 2, 4, 8) : BY_STAGE64(T, 2, 2, 8))
     int rc;
     if (taps == 9) rc = (bk == 64) ? BY_GEO64(9) : BY_GEO(9, 32);
     else rc = (bk == 64) ? BY_GEO64(1) : BY_GEO(1, 32);

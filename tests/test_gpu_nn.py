@@ -279,7 +279,7 @@ def test_philox_normal_stream(nn):
 
 
 @pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4),
-                                           (64, 2, 8), (64, 12, 2), (64, 12, 4), (64, 12, 8), (64, 12, 16)])
+                                           (64, 2, 8), (64, 12, 2), (64, 12, 8), (64, 12, 16)])
 def test_conv_igemm_all_kernel_variants(nn, bk, stages, wmw):
     """Every (K-step, pipeline depth, tile height) instantiation of the conv kernel computes the same convolution
     (stages 12 = two LDS stages with the hand-scheduled register-pipelined fragment loop)."""
