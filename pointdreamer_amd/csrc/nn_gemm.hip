@@ -19,11 +19,19 @@ using namespace pdhip;
 namespace pdnn {
 
 
+#ifdef PD_LAB_STAMP                                        // (lab builds only: per-block phase timestamps, s_memtime)
+__device__ unsigned long long g_lab_stamps[8 * 4096];
+#define PD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) g_lab_stamps[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PD_STAMP(k) do {} while (0)
+#endif
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+#ifndef PD_LAB_NODMA                                       // (lab builds only: mainloop without the HBM->LDS traffic)
     __builtin_amdgcn_global_load_lds((gbl_void*)gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+#endif
 }
 
 // 16-byte slot permutation inside a tile row: slot = chunk ^ swz(row).  Chosen so that every ds_read_b128
@@ -60,6 +68,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     constexpr int STAGE_BYTES = A_BYTES + BNT * ROWB;
     constexpr int CS_LD = BNT + 8;                // epilogue tile leading dimension (halfs)
     constexpr int KSTEPS = BKT / 32;              // MFMA k-steps per K-step
+    PD_STAMP(0);
     constexpr bool PIPE = NSTAGE == 12;           // NSTAGE 12 = two LDS stages + register-pipelined fragment schedule
     constexpr int NST = PIPE ? 2 : NSTAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,10 +140,14 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     // one 1 KiB LDS-DMA piece of a stage (p < LPO: activation rows, else weight rows) / the K-step bookkeeping after the last
     auto issue_piece = [&](int stage, int p) {
         if (p < LPO) {
+#ifndef PD_LAB_NOA
             glds16(ap[p], wave_dst + stage * STAGE_BYTES + p * 1024);
+#endif
             ap[p] += astep[p];
         } else {
+#ifndef PD_LAB_NOB
             glds16(bp[p - LPO], wave_dst_b + stage * STAGE_BYTES + (p - LPO) * 1024);
+#endif
             bp[p - LPO] += BKT;
         }
     };
@@ -167,6 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
         for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     constexpr int OPS_ = LPO + LPB;
+    PD_STAMP(1);
     if constexpr (PIPE) {
         // Register-pipelined schedule.  A K-step is G = 16 groups of 4 MFMAs (one A fragment x 4 B fragments; groups 0..7 are
         // MFMA k-step 0, 8..15 k-step 1).  The A fragment of group g+3 is read from LDS at the start of group g into the ring
@@ -184,6 +198,22 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
         constexpr int HO = G - 3;                             // hand-over group
         constexpr int PPG = OPS_ == 12 ? 2 : 1;              // LDS-DMA pieces per group
         constexpr int NPG = OPS_ / PPG;                       // groups that carry pieces: 3 from the hand-over + NPG-3 after it
+#ifdef PD_LAB_STAMP
+        unsigned long long lab_t0 = 0, lab_wait = 0, lab_bar = 0;
+        const bool lab_trace = blockIdx.x == 8 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0;    // waves 0 and 4 share SIMD 0
+#define PD_LAB_T0 lab_t0 = __builtin_readcyclecounter()
+#define PD_LAB_T1 { const unsigned long long t_ = __builtin_readcyclecounter(); lab_wait += t_ - lab_t0; lab_t0 = t_; }
+#define PD_LAB_T2 lab_bar += __builtin_readcyclecounter() - lab_t0
+#else
+#define PD_LAB_T0
+#define PD_LAB_T1
+#define PD_LAB_T2
+#endif
+#ifdef PD_LAB_NOBARRIER
+#define PD_LAB_BARRIER
+#else
+#define PD_LAB_BARRIER __builtin_amdgcn_s_barrier()
+#endif
 #define PD_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
         const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
         const uint32_t a_base = lds0 + (wm * TM * 16) * ROWB, b_base = lds0 + TILE_BYTES + (wn * 64) * ROWB;
@@ -208,10 +238,27 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
             const uint32_t b_ad1 = b_base + cur * STAGE_BYTES + frag_off[1];
             const uint32_t a_nx0 = a_base + (cur ^ 1) * STAGE_BYTES + frag_off[0], b_nx0 = b_base + (cur ^ 1) * STAGE_BYTES + frag_off[0];
             const bool more = it + 1 < it1, more2 = it + 2 < it1;
+            // The two waves of a SIMD (w, w+4) run the same stream and meet at the barrier every K-step.  Under the default
+            // oldest-first issue arbitration one of them races ahead and then idles at the barrier while the other runs alone
+            // with all its stalls exposed; alternating the priority by half K-steps keeps both in the pipe for the whole step.
+#ifdef PD_LAB_STAMP
+#define PD_LAB_G(g) if (lab_trace && it == it0 + 10) g_lab_stamps[7 * 4096 + (wave >> 2) * 32 + (g)] = __builtin_readcyclecounter();
+#else
+#define PD_LAB_G(g)
+#endif
+#ifdef PD_LAB_NOPRIO
+#define PD_PRIO(g)
+#else
+#define PD_PRIO(g)                                                                                                       \
+        if constexpr ((g) == 0) { if (wave < NWAVES / 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }   \
+        if constexpr ((g) == G / 2) { if (wave < NWAVES / 2) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+#endif
             // reads still allowed in flight when group g starts: A(g+1..g+3) plus the B reads interleaved after A(g)
 #define PD_WAITN(g_) ((g_) == 0 ? 4 : (g_) == 1 ? 5 : (g_) == 2 ? 6 : (g_) == 3 ? 7 : (g_) == 4 ? 6 : (g_) == 5 ? 5 : (g_) == 6 ? 4 : 3)
 #define PD_GROUP(g)                                                                                                      \
     {                                                                                                                    \
+        PD_PRIO(g)                                                                                                       \
+        PD_LAB_G(g)                                                                                                      \
         if constexpr ((g) + 3 < G) {                                                                                     \
             if constexpr (((g) + 3) / TM == 0) PD_DSR(ar[((g) + 3) & 3], a_ad0, (((g) + 3) % TM) * 16 * ROWB);           \
             else PD_DSR(ar[((g) + 3) & 3], a_ad1, (((g) + 3) % TM) * 16 * ROWB);                                         \
@@ -219,9 +266,12 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
         if constexpr ((g) < 4) PD_DSR(bf[1][(g) & 3], b_ad1, ((g) & 3) * 16 * ROWB);                                     \
         if constexpr ((g) == HO) {                                                                                       \
             if (more) {                                                                                                  \
+                PD_LAB_T0;                                                                                               \
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(ar[(g) & 3]), "+v"(ar[((g) + 1) & 3]), "+v"(ar[((g) + 2) & 3]) :: "memory"); \
-                __builtin_amdgcn_s_barrier();                                                                            \
+                PD_LAB_T1;                                                                                               \
+                PD_LAB_BARRIER;                                                                                          \
                 asm volatile("" ::: "memory");                                                                           \
+                PD_LAB_T2;                                                                                               \
                 PD_DSR(bf[0][0], b_nx0, 0); PD_DSR(bf[0][1], b_nx0, 16 * ROWB);                                          \
                 PD_DSR(bf[0][2], b_nx0, 32 * ROWB); PD_DSR(bf[0][3], b_nx0, 48 * ROWB);                                  \
                 PD_DSR(ar[0], a_nx0, 0);                                                                                 \
@@ -238,7 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
             if constexpr ((g) == TM) asm volatile("" : "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]), "+v"(bf[1][3]));   \
         }                                                                                                                \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
-            acc[(g) % TM][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar[(g) & 3], bf[(g) / TM][j], acc[(g) % TM][j], 0, 0, 0); \
+            acc[(g) % TM][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[(g) / TM][j], ar[(g) & 3], acc[(g) % TM][j], 0, 0, 0); \
         if constexpr ((g) >= HO) {                       /* pieces 0..2 of K-step it+2 into the stage just drained */      \
             if (more2) { _Pragma("unroll") for (int p = 0; p < PPG; ++p) issue_piece(cur, ((g) - HO) * PPG + p); }       \
         } else if constexpr ((g) < NPG - 3) {            /* the remaining pieces of K-step it+1 */                       \
@@ -251,11 +301,17 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     }
             PD_GROUP(0) PD_GROUP(1) PD_GROUP(2) PD_GROUP(3) PD_GROUP(4) PD_GROUP(5) PD_GROUP(6) PD_GROUP(7)
             PD_GROUP(8) PD_GROUP(9) PD_GROUP(10) PD_GROUP(11) PD_GROUP(12) PD_GROUP(13) PD_GROUP(14) PD_GROUP(15)
+            PD_LAB_G(16)
 #undef PD_GROUP
+#undef PD_LAB_G
+#undef PD_PRIO
 #undef PD_WAITN
             cur ^= 1;
         }
 #undef PD_DSR
+#ifdef PD_LAB_STAMP
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && blockIdx.y == 0) { g_lab_stamps[blockIdx.x * 8 + 6] = lab_wait; g_lab_stamps[blockIdx.x * 8 + 7] = lab_bar; }
+#endif
     } else {
     // Software pipeline: NSTAGE LDS stages, loads run NSTAGE-1 K-steps ahead and stay in flight ACROSS the barrier
     // (counted s_waitcnt vmcnt + raw s_barrier; __syncthreads() would drain the LDS-DMA queue -- cdna guide T3/T4).
@@ -307,12 +363,13 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
         cur = (cur + 1 == NST) ? 0 : cur + 1;
         nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
     }
+    PD_STAMP(2);
     __syncthreads();                                       // all fragment reads done before the tile is reused
 #ifdef PD_LAB_NOEPI                                        // (lab builds only: mainloop without the epilogue)
     {
@@ -326,35 +383,41 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
     }
 #endif
 
+    // The MFMAs are issued as (weights x activations), i.e. the accumulator tile is the TRANSPOSE of the usual layout: lane
+    // holds pixel m = 16 i + (lane & 15) and the four CONSECUTIVE channels n = 16 j + 4 (lane >> 4) + r -- 8-/16-byte packed
+    // stores along the channel dimension instead of scalar ones.
     if (partial != nullptr) {                              // split-K: raw f32 partial tile, reduced by k_splitk_reduce
         float* P = partial + (size_t)blockIdx.y * (size_t)M * Cout;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long long m = (long long)m0 + wm * TM * 16 + i * 16 + (lane >> 4) * 4 + r;
-                    if (m < M && n < Cout) P[(size_t)m * Cout + n] = acc[i][j][r];
-                }
+            for (int i = 0; i < TM; ++i) {
+                const long long m = (long long)m0 + wm * TM * 16 + i * 16 + (lane & 15);
+                if (m < M && n < Cout) *reinterpret_cast<float4_t*>(P + (size_t)m * Cout + n) = acc[i][j];
+            }
         }
         return;
     }
-    // ---- epilogue: acc (+bias) -> f16 -> LDS [128][CS_LD] -> coalesced 16-byte rows (+residual)
+    // ---- epilogue: acc (+bias) -> f16 -> LDS [BMT][CS_LD] -> coalesced 16-byte rows (+residual)
     half_t* Cs = reinterpret_cast<half_t*>(smem);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int nl = wn * 64 + j * 16 + (lane & 15);
-        const float bv = (bias != nullptr && n0 + nl < Cout) ? bias[n0 + nl] : 0.f;
+        const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+        float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && n0 + nl < Cout) bv = *reinterpret_cast<const float4_t*>(bias + n0 + nl);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int ml = wm * TM * 16 + i * 16 + (lane >> 4) * 4;
+            const int ml = wm * TM * 16 + i * 16 + (lane & 15);
+            half4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[(ml + r) * CS_LD + nl] = (half_t)(acc[i][j][r] + bv);
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
+            *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
         }
     }
+    PD_STAMP(3);
     __syncthreads();
+    PD_STAMP(4);
     constexpr int CT = BNT / 8;                            // column threads (one channel octet each)
     constexpr int RPP = NWAVES * 64 / CT;                  // rows per pass
     const int col8 = (tid % CT) * 8;
@@ -371,11 +434,16 @@ __global__ __launch_bounds__(WM * WN * 64) void k_conv_igemm(const half_t* __res
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
+#ifdef PD_LAB_NOSTORE                                      // (lab builds only: epilogue without the global stores)
+            if (v[0] == (half_t)12345.f) *reinterpret_cast<half8*>(Y + o) = v;
+#else
             *reinterpret_cast<half8*>(Y + o) = v;
+#endif
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
         }
     }
+    PD_STAMP(5);
     if (gn_part != nullptr) {
         // Fused GroupNorm statistics: per-(image, row-chunk, channel octet) sum / sum of squares of the tile just written,
         // layout [img][chunk][Cout/8][2].  Any GroupNorm(32) whose group size is a multiple of 8 channels -- also over a
@@ -552,4 +620,9 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     return PDHIP_OK;
 }
 
+#ifdef PD_LAB_STAMP
+extern "C" int pdhip_lab_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lab_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 }  // namespace pdnn

@@ -12,6 +12,7 @@ SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (8, 32, 32, 512, 1536, 1)]
 ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64x2x8', '64x3x16', '64x2x16', '64x2x8']); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--shapes', type=int, nargs='*', default=None)
 ap.add_argument('--custom', type=int, nargs='*', default=None, help='extra shapes as N H W Cin Cout taps ...')
+ap.add_argument('--stamps', action='store_true', help='lab_stamp build: print per-phase cycle averages of the last launch')
 ap.add_argument('--lib', default=None, help='alternative libpdhip.so (lab builds)')
 a = ap.parse_args()
 if a.lib:
@@ -45,4 +46,22 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
         ms = e0.elapsed_time(e1) / a.iters
         res.append(f"{cfg}: {fl/ms/1e9:6.0f}")
     print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} taps{taps} ({fl/1e9:7.1f} GFLOP)  " + " | ".join(res))
+    if a.stamps:
+        import numpy as np
+        nb = min(4096, ((N * H * W + 255) // 256) * (pad // 256))
+        buf = (C.c_ulonglong * (8 * nb))()
+        L._handle if False else None
+        fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_read_stamps
+        assert fn(buf, 8 * nb) == 0
+        st = np.array(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
+        d = np.diff(st[:, :6], axis=1)
+        names = ['setup', 'mainloop', 'acc->lds', 'sync', 'readback+store']
+        print('   phases (s_memtime ticks @100MHz?, avg over blocks): ' + '  '.join(f"{nm} {d[:, i].mean():9.1f}" for i, nm in enumerate(names)) + f"  total {(st[:, 5] - st[:, 0]).mean():9.1f}  | in mainloop (wave 0): hand-over waitcnt {st[:, 6].mean():9.1f}  barrier {st[:, 7].mean():9.1f}")
+        tb = (C.c_ulonglong * (8 * 4096))()
+        assert fn(tb, 8 * 4096) == 0
+        tr = np.array(tb, dtype=np.uint64).astype(np.int64)[7 * 4096:7 * 4096 + 64].reshape(2, 32)[:, :17]
+        base = tr[:, 0].min()
+        print('   group start ticks, K-step it0+10 of block 8 (rows: wave 0, wave 4):')
+        for r in tr: print('      ' + ' '.join(f"{v - base:5d}" for v in r))
+        print('   block start spread: min %d max %d; end spread: min %d max %d' % (st[:, 0].min() - st[:, 0].min(), st[:, 0].max() - st[:, 0].min(), st[:, 5].min() - st[:, 0].min(), st[:, 5].max() - st[:, 0].min()))
 L.pdhip_debug_set_conv_bk(0); L.pdhip_debug_set_conv_stages(0); L.pdhip_debug_set_conv_tile(0)
