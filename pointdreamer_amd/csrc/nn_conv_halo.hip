@@ -1,0 +1,283 @@
+// Row U1: 3x3 convolution with an LDS-resident activation halo -- the large-image layers of the UNet (W = 64 / 128 / 256).
+// Same contract as k_conv_igemm (nn_gemm.hip) for taps == 9: Y[m, n] = sum_{tap, c} X[m + d(tap), c] * Wt[n, tap*Cin + c] + bias
+// (+ residual), NHWC f16, f32 accumulation, fused GroupNorm octet partials.
+//
+// Why a second kernel: k_conv_igemm re-loads the activation tile once per filter tap, so every 64-deep K-step moves
+// 32 KB (activations) + 32 KB (weights) L2 -> LDS for 8.4 MFLOP.  Measured on MI355X (tools/lab_build.sh, NODMA / NOA / NOB
+// variants) that traffic is what bounds it: the same kernel without the LDS-DMA runs at 1.9 PFLOP/s, with half of it at
+// 1.45-1.7, with all of it at 1.1-1.2.  Here the tile is 512 pixels (whole image rows) x 128 channels and the K loop is
+// CHUNK-major: per 32 input channels the (rows + 2) x (W + 2) halo is staged ONCE and all nine taps read it at shifted
+// addresses, so a 32-deep step moves 8 KB of weights + ~7 KB of halo: 2.1x less L2 -> LDS traffic per flop, and half the
+// LDS-DMA instructions per MFMA.  Zero padding is resolved when the halo is staged (zero page) -- no per-tap predicates.
+//
+// LDS: 2 halo buffers (chunk c / c+1) + 3 weight stages of 8 KB.  8 waves as 4 (pixels) x 2 (channels), wave tile 128 x 64,
+// the register-pipelined fragment schedule of nn_gemm.hip (inline-asm ds_read_b128, counted waits) with 8 groups per step.
+// Halo row = 64 B (32 channels); 16-byte slot swizzle s(hp) = 2 * ((hp >> 2) & 1): conflict-free ds_read_b128 for ANY
+// start pixel (the tap shift moves the 16-pixel fragment window by +-1), mirrored on the LDS-DMA source address.
+#include "nn_common.h"
+using namespace pdhip;
+namespace pdnn {
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_h;
+typedef const __attribute__((address_space(1))) void gbl_void_h;
+__device__ __forceinline__ void glds16h(const void* gsrc, void* lds_wave_base) {
+#ifndef PD_LAB_NODMA                                       // (lab builds only: mainloop without the L2 -> LDS traffic)
+    __builtin_amdgcn_global_load_lds((gbl_void_h*)gsrc, (lds_void_h*)lds_wave_base, 16, 0, 0);
+#endif
+}
+__device__ __forceinline__ int swz_b(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // weight tile: aligned 16-row windows
+__device__ __forceinline__ int swz_a(int hp) { return ((hp >> 2) & 1) << 1; }                     // halo: any window start
+
+template <int WLOG>
+__global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
+                                                      const float* __restrict__ bias, const half_t* __restrict__ residual,
+                                                      half_t* __restrict__ Y, int N, int H, int Cin, int Cout, int n_tiles,
+                                                      int total_tiles, const half_t* __restrict__ zero_page,
+                                                      float* __restrict__ gn_part) {
+    constexpr int W = 1 << WLOG, BMT = 512, BNT = 128, TM = 8, ROWB = 64, NWAVES = 8;
+    constexpr int RT = BMT / W, HW2 = W + 2, HP = (RT + 2) * HW2;     // tile rows, halo row length, halo pixels
+    constexpr int NPA = (HP + 15) / 16, PA = (NPA + 7) / 8;           // 1 KiB halo pieces per chunk, per wave
+    constexpr int AH_BYTES = NPA * 1024, B_BYTES = BNT * ROWB;
+    constexpr int RPW = W >= 128 ? 1 : 128 / W;                       // image rows inside one wave's 128 pixels
+    constexpr int FPR = TM / RPW;                                     // A fragments per such row
+    constexpr int CS_LD = BNT + 8;
+    static_assert(PA <= 9 && RPW <= 2, "halo schedule: at most one halo piece per wave per tap, W >= 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile;
+    {
+        const int b = blockIdx.x, q = total_tiles >> 3, r = total_tiles & 7, xcd = b & 7, i = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int m0 = (tile / n_tiles) * BMT, n0 = (tile % n_tiles) * BNT;
+    const int HWp = H << WLOG;
+    const int img = m0 / HWp, ty0 = (m0 - img * HWp) >> WLOG;
+    const int K = 9 * Cin, NC = Cin >> 5;
+
+    // ---- loader role.  Halo piece slot t of this wave = piece min(8 t + wave, NPA - 1) (the tail slots of the last waves
+    // re-load the last piece: every wave issues the same number of LDS-DMA instructions, which keeps the vmcnt counts static)
+    uint32_t aoff[PA];                                                // byte offset from X; ~0u = zero page (padding)
+    const char* const Xb = reinterpret_cast<const char*>(X);
+#pragma unroll
+    for (int t = 0; t < PA; ++t) {
+        const int pi = min(t * 8 + wave, NPA - 1);
+        const int hp = pi * 16 + (lane >> 2), cq = lane & 3;
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const int y = ty0 - 1 + hy, x = hx - 1;
+        const bool ok = (hp < HP) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+        aoff[t] = ok ? (uint32_t)((((((long long)img * H + y) << WLOG) + x) * Cin + ((cq ^ swz_a(hp)) << 3)) * 2) : ~0u;
+    }
+    const int brow = wave * 16 + (lane >> 2);
+    const half_t* bp = Wt + (size_t)(n0 + brow) * K + (((lane & 3) ^ swz_b(brow)) << 3);   // next weight slice to stage
+    char* const ah_dst = smem;                                        // + buf * AH_BYTES + piece * 1024
+    char* const b_dst = smem + 2 * AH_BYTES + wave * 1024;            // + stage * B_BYTES
+
+    // ---- consumer role
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int p0 = wm * 128;
+    const int hp0 = ((p0 >> WLOG) + 1) * HW2 + (p0 & (W - 1)) + 1 + r16;          // halo pixel of (fragment 0, tap centre)
+    const uint32_t b_frag = lds0 + 2 * AH_BYTES + (wn * 64 + r16) * ROWB + ((q4 ^ swz_b(r16)) << 4);
+    float4_t acc[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+#define HL_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+    // swizzled LDS address of this lane's halo pixel for tap (dy, dx) in halo buffer `buf` (+ second image row for W = 64)
+#define HL_AADDR(buf, toff, row2)                                                                                    \
+    (lds0 + (buf) * AH_BYTES + (uint32_t)((hpv + (toff) + (row2) * HW2) << 6) + (uint32_t)((q4 ^ swz_a(hpv + (toff) + (row2) * HW2)) << 4))
+    half8 ar[4], bf[2][4];
+
+    // ---- prologue: halo of chunk 0, weight slices 0 and 1
+    auto halo_src = [&](uint32_t off) -> const void* { return off == ~0u ? (const void*)zero_page : (const void*)(Xb + off); };
+#pragma unroll
+    for (int t = 0; t < PA; ++t) glds16h(halo_src(aoff[t]), ah_dst + min(t * 8 + wave, NPA - 1) * 1024);
+    glds16h(bp, b_dst);
+    bp += Cin;
+    glds16h(bp, b_dst + B_BYTES);
+    bp += Cin;
+    if (PA == 9) {                                                    // keeps the issue order of the steady state (see HL_VMN)
+        glds16h(halo_src(aoff[PA - 1]), ah_dst + min((PA - 1) * 8 + wave, NPA - 1) * 1024);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const int hpv = hp0;
+        const uint32_t a0 = HL_AADDR(0, -HW2 - 1, 0);
+        HL_DSR(bf[0][0], b_frag, 0); HL_DSR(bf[0][1], b_frag, 16 * ROWB); HL_DSR(bf[0][2], b_frag, 32 * ROWB); HL_DSR(bf[0][3], b_frag, 48 * ROWB);
+        HL_DSR(ar[0], a0, 0); HL_DSR(ar[1], a0, 1024); HL_DSR(ar[2], a0, 2048);
+    }
+
+    int bs = 0;                                                       // weight stage of the current step (s mod 3)
+    const int S = 9 * NC;
+    for (int c0 = 0; c0 < NC; c0 += 2) {                              // two chunks per trip: buffer / register-set parities static
+        // One step = (chunk c, tap T): 8 groups of 4 MFMAs.  Reads: A fragment g+3 at group g (ring of 4), the next step's
+        // four weight fragments + A fragments 0..2 from the hand-over on.  LDS-DMA: weight slice s+2 after group 0, halo
+        // piece T of chunk c+1 after group 1.  Hand-over in front of group 5: counted vmcnt (weight slice s+1 landed -- issued
+        // after it: the previous step's halo piece, this step's weight and halo pieces), drain of my LDS reads, barrier.
+#define HL_VMN(T) (1 + ((T) < PA ? 1 : 0) + ((((T) + 8) % 9) < PA ? 1 : 0))
+#define HL_RDA(slot, base0, base1, i)                                                                                 \
+    { if constexpr ((i) < FPR) HL_DSR(ar[slot], base0, (i) * 1024); else HL_DSR(ar[slot], base1, ((i) - FPR) * 1024); }
+#define HL_GROUP(P, T, g)                                                                                              \
+    {                                                                                                                 \
+        if constexpr ((g) + 3 < TM) HL_RDA(((g) + 3) & 3, a_ad0, a_ad1, (g) + 3)                                       \
+        if constexpr ((g) == 5) {                                                                                     \
+            if (more) {                                                                                               \
+                asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]) : "n"(HL_VMN(T)) : "memory"); \
+                __builtin_amdgcn_s_barrier();                                                                         \
+                asm volatile("" ::: "memory");                                                                        \
+                HL_DSR(bf[bn][0], b_nx, 0); HL_DSR(bf[bn][1], b_nx, 16 * ROWB);                                       \
+                HL_DSR(bf[bn][2], b_nx, 32 * ROWB); HL_DSR(bf[bn][3], b_nx, 48 * ROWB);                               \
+                HL_DSR(ar[0], a_nx0, 0);                                                                              \
+            } else {                                                                                                  \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]));                         \
+            }                                                                                                         \
+        } else if constexpr ((g) == 6) {                                                                              \
+            if (more) HL_DSR(ar[1], a_nx0, 1024);                                                                     \
+        } else if constexpr ((g) == 7) {                                                                              \
+            if (more) HL_DSR(ar[2], a_nx0, 2048);                                                                     \
+        } else {                                                                                                      \
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ar[(g) & 3]));                                                 \
+            if constexpr ((g) == 0) asm volatile("" : "+v"(bf[bc][0]), "+v"(bf[bc][1]), "+v"(bf[bc][2]), "+v"(bf[bc][3])); \
+        }                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
+            acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[bc][j], ar[(g) & 3], acc[g][j], 0, 0, 0);           \
+        if constexpr ((g) == 0) {                                     /* weight slice s + 2 into stage (s + 2) % 3 */     \
+            const int st2 = bs == 0 ? 2 : bs - 1;                                                                     \
+            if (s + 2 < S) {                                                                                          \
+                glds16h(bp, b_dst + st2 * B_BYTES);                                                                   \
+                if constexpr (((T) + 2) % 9 < 8) bp += Cin; else bp += 32 - 8 * Cin;                                  \
+            } else glds16h(zero_page, b_dst + st2 * B_BYTES);         /* past the end: harmless load, static counts */   \
+        }                                                                                                             \
+        if constexpr ((g) == 1 && (T) < PA) {                         /* halo piece T of chunk c + 1 */                 \
+            if (c + 1 < NC) aoff[T] += aoff[T] == ~0u ? 0u : 64u;                                                      \
+            glds16h(halo_src(aoff[T]), ah_dst + (ab ^ 1) * AH_BYTES + min((T) * 8 + wave, NPA - 1) * 1024);           \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+#define HL_STEP(P, T)                                                                                                 \
+    {                                                                                                                 \
+        constexpr int dy_ = (T) / 3 - 1, dx_ = (T) % 3 - 1, tn_ = ((T) + 1) % 9;                                      \
+        constexpr int dyn_ = tn_ / 3 - 1, dxn_ = tn_ % 3 - 1;                                                         \
+        constexpr int ab = (P), bc = ((P) + (T)) & 1, bn = bc ^ 1;    /* halo buffer; fragment register set of this / next step */ \
+        const int s = c * 9 + (T);                                                                                    \
+        const bool more = s + 1 < S;                                                                                  \
+        int hpv = hp0;                                                                                                \
+        asm volatile("" : "+v"(hpv));                                 /* keeps the per-tap addresses out of loop-invariant registers */ \
+        const uint32_t a_ad0 = HL_AADDR(ab, dy_ * HW2 + dx_, 0);                                                      \
+        const uint32_t a_ad1 = RPW == 2 ? HL_AADDR(ab, dy_ * HW2 + dx_, 1) : a_ad0;                                   \
+        const int abn = (T) == 8 ? (ab ^ 1) : ab;                                                                     \
+        const uint32_t a_nx0 = HL_AADDR(abn, dyn_ * HW2 + dxn_, 0);                                                   \
+        const uint32_t b_nx = b_frag + (bs == 2 ? 0 : bs + 1) * B_BYTES;                                              \
+        HL_GROUP(P, T, 0) HL_GROUP(P, T, 1) HL_GROUP(P, T, 2) HL_GROUP(P, T, 3)                                        \
+        HL_GROUP(P, T, 4) HL_GROUP(P, T, 5) HL_GROUP(P, T, 6) HL_GROUP(P, T, 7)                                        \
+        bs = bs == 2 ? 0 : bs + 1;                                                                                    \
+    }
+#define HL_CHUNK(P) HL_STEP(P, 0) HL_STEP(P, 1) HL_STEP(P, 2) HL_STEP(P, 3) HL_STEP(P, 4) HL_STEP(P, 5) HL_STEP(P, 6) HL_STEP(P, 7) HL_STEP(P, 8)
+        { const int c = c0; HL_CHUNK(0) }
+        if (c0 + 1 < NC) { const int c = c0 + 1; HL_CHUNK(1) }
+#undef HL_CHUNK
+#undef HL_STEP
+#undef HL_GROUP
+#undef HL_RDA
+#undef HL_VMN
+    }
+#undef HL_AADDR
+#undef HL_DSR
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the harmless tail re-loads must land before the LDS is reused
+    __syncthreads();
+
+    // ---- epilogue (as k_conv_igemm: transposed accumulator tile -> f16 -> LDS -> coalesced rows, residual, GN partials)
+    half_t* Cs = reinterpret_cast<half_t*>(smem);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+        float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr && n0 + nl < Cout) bv = *reinterpret_cast<const float4_t*>(bias + n0 + nl);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int ml = wm * TM * 16 + i * 16 + (lane & 15);
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
+            *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
+        }
+    }
+    __syncthreads();
+    constexpr int CT = BNT / 8;                            // column threads (one channel octet each)
+    constexpr int RPP = NWAVES * 64 / CT;                  // rows per pass
+    const int col8 = (tid % CT) * 8;
+    float gs = 0.f, gq = 0.f;
+#pragma unroll 4
+    for (int p = 0; p < BMT / RPP; ++p) {
+        const int row = p * RPP + tid / CT;
+        const long long m = (long long)m0 + row;
+        if (n0 + col8 < Cout) {
+            half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
+            const size_t o = (size_t)m * Cout + n0 + col8;
+            if (residual != nullptr) {
+                const half8 rv = *reinterpret_cast<const half8*>(residual + o);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
+            }
+            *reinterpret_cast<half8*>(Y + o) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
+        }
+    }
+    if (gn_part != nullptr) {                              // [img][chunk][Cout/8][2], chunk = 512-pixel tile of the image
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid * 2] = gs; red[tid * 2 + 1] = gq;
+        __syncthreads();
+        if (tid < CT && n0 + tid * 8 < Cout) {
+            float s1 = 0.f, q1 = 0.f;
+            for (int r = 0; r < RPP; ++r) { s1 += red[(r * CT + tid) * 2]; q1 += red[(r * CT + tid) * 2 + 1]; }
+            const int chunks = HWp / BMT;
+            const int chunk = (m0 - img * HWp) / BMT;
+            float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + tid) * 2;
+            dst[0] = s1; dst[1] = q1;
+        }
+    }
+}
+
+template <int WLOG>
+int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
+                int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part) {
+    constexpr int W = 1 << WLOG, RT = 512 / W, HP = (RT + 2) * (W + 2), NPA = (HP + 15) / 16;
+    const size_t smem = std::max<size_t>((size_t)2 * NPA * 1024 + 3 * 8192, (size_t)512 * (128 + 8) * 2);
+    auto kern = k_conv3x3_halo<WLOG>;
+    PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int n_tiles = Cout_pad / 128;
+    const int total = (int)(((long long)N * H * W) / 512) * n_tiles;
+    kern<<<total, 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part);
+    return PDHIP_OK;
+}
+
+}  // namespace
+
+bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad) {
+    return (W == 64 || W == 128 || W == 256) && ((long long)H * W) % 512 == 0 && Cin % 32 == 0 && Cout_pad % 128 == 0 &&
+           (long long)N * H * W <= 0x7fffffffLL;
+}
+
+// gn_part (optional): fused GroupNorm octet partials, chunks = H*W / 512 per image (returned through gn_fused)
+int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
+                 int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused) {
+    PD_REQUIRE(conv3x3_halo_eligible(N, H, W, Cin, Cout_pad), "conv3x3_halo: unsupported geometry (N=%d H=%d W=%d Cin=%d)", N, H, W, Cin);
+    if (gn_fused) *gn_fused = gn_part ? (int)(((long long)H * W) / 512) : 0;
+    int rc;
+    if (W == 256) rc = launch_halo<8>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part);
+    else if (W == 128) rc = launch_halo<7>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part);
+    else rc = launch_halo<6>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part);
+    if (rc) return rc;
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+}  // namespace pdnn

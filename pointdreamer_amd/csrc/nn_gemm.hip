@@ -557,6 +557,11 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     PD_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % 128 == 0 && Cout_pad >= Cout,
                "conv_igemm: need Cin %% 32 == 0, Cout %% 8 == 0, padded Cout %% 128 == 0 (Cin=%d Cout=%d pad=%d)", Cin, Cout, Cout_pad);
     const long long M = (long long)N * H * W;
+    // large-image 3x3 layers: halo-resident kernel (2.1x less L2 -> LDS traffic per flop) once it fills the chip
+    // (tuning hook: tile geometry 32 forces it, any other forced geometry disables it)
+    if (taps == 9 && X2 == nullptr && conv3x3_halo_eligible(N, H, W, Cin, Cout_pad) &&
+        (g_force_wmw == 32 || (g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && (M / 512) * (Cout_pad / 128) >= 256)))
+        return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused);
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
     // tile geometry: 256x256 (wave tile 128x64: 25 % fewer LDS reads per MFMA, half the L2 traffic) once it still yields
     // at least one workgroup per CU; 128x128 otherwise

@@ -278,6 +278,29 @@ def test_philox_normal_stream(nn):
     assert abs((a ** 4).mean().item() - 3.0) < 0.1
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res", [(2, 8, 64, 64, 128, False), (1, 16, 64, 96, 192, True), (1, 4, 128, 32, 128, False),
+                                              (2, 8, 128, 64, 256, True), (1, 2, 256, 64, 128, False), (1, 6, 256, 32, 256, True),
+                                              (1, 8, 256, 160, 128, False)])
+def test_conv3x3_halo_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, res):
+    """The halo-resident 3x3 kernel (nn_conv_halo.hip; W = 64 / 128 / 256, 512-pixel tiles): image borders, tile borders
+    inside an image, several images, odd / single channel-chunk counts, residual."""
+    L = nn['L']
+    old = L.pdhip_debug_set_conv_tile(32)
+    try:
+        g = torch.Generator().manual_seed(N * 1000 + H * W + Cin + Cout)
+        x = torch.randn((N, Cin, H, W), generator=g).half().float()
+        w = (torch.randn((Cout, Cin, 3, 3), generator=g) / math.sqrt(Cin * 9)).half().float()
+        b = (torch.randn((Cout,), generator=g) * 0.1).half().float()
+        r = torch.randn((N, Cout, H, W), generator=g).half().float() if res else None
+        ref = F.conv2d(x, w, b, padding=1).half().float()
+        if res:
+            ref = (ref + r).half().float()
+        out = hip_conv(nn, x, w, b, r)
+        assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+    finally:
+        L.pdhip_debug_set_conv_tile(old)
+
+
 @pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4),
                                            (64, 2, 8), (64, 12, 2), (64, 12, 8), (64, 12, 16)])
 def test_conv_igemm_all_kernel_variants(nn, bk, stages, wmw):

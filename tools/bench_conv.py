@@ -12,6 +12,7 @@ SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (8, 32, 32, 512, 1536, 1)]
 ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64x2x8', '64x3x16', '64x2x16', '64x2x8']); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--shapes', type=int, nargs='*', default=None)
 ap.add_argument('--custom', type=int, nargs='*', default=None, help='extra shapes as N H W Cin Cout taps ...')
+ap.add_argument('--zeros', action='store_true', help='zero activations and weights (DVFS reference)')
 ap.add_argument('--stamps', action='store_true', help='lab_stamp build: print per-phase cycle averages of the last launch')
 ap.add_argument('--lib', default=None, help='alternative libpdhip.so (lab builds)')
 a = ap.parse_args()
@@ -29,6 +30,8 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
     pad = (Cout + 127) // 128 * 128
     w = (torch.randn((pad, taps * Cin), device=dev) * 0.05).half()
     b = torch.zeros(Cout, device=dev)
+    if a.zeros:
+        x.zero_(); w.zero_()
     y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev)
     fl = 2.0 * N * H * W * Cout * taps * Cin
     res = []
