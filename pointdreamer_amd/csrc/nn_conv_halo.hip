@@ -44,7 +44,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     constexpr int CS_LD = BNT + 8;
     static_assert(PA <= 9 && RPW <= 2, "halo schedule: at most one halo piece per wave per tap, W >= 64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps the piece / stage arithmetic on the scalar unit
     const int wm = wave >> 1, wn = wave & 1;
     int tile;
     {
@@ -57,18 +58,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     const int K = 9 * Cin, NC = Cin >> 5;
 
     // ---- loader role.  Halo piece slot t of this wave = piece min(8 t + wave, NPA - 1) (the tail slots of the last waves
-    // re-load the last piece: every wave issues the same number of LDS-DMA instructions, which keeps the vmcnt counts static)
-    uint32_t aoff[PA];                                                // byte offset from X; ~0u = zero page (padding)
-    const char* const Xb = reinterpret_cast<const char*>(X);
-#pragma unroll
-    for (int t = 0; t < PA; ++t) {
+    // re-load the last piece: every wave issues the same number of LDS-DMA instructions, which keeps the vmcnt counts static).
+    // The source address of a piece is recomputed when it is issued (~20 VALU ops behind 32 MFMAs) rather than kept in 9
+    // registers: the kernel sits at the 256-VGPR limit of two waves per SIMD.
+    const int cq = lane & 3;
+    auto halo_src = [&](int t, int chunk) -> const void* {
         const int pi = min(t * 8 + wave, NPA - 1);
-        const int hp = pi * 16 + (lane >> 2), cq = lane & 3;
+        int lq = lane >> 2;
+        asm volatile("" : "+v"(lq));                                  // recompute here, every time (no loop-invariant hoisting)
+        const int hp = pi * 16 + lq;
         const int hy = hp / HW2, hx = hp - hy * HW2;
         const int y = ty0 - 1 + hy, x = hx - 1;
         const bool ok = (hp < HP) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
-        aoff[t] = ok ? (uint32_t)((((((long long)img * H + y) << WLOG) + x) * Cin + ((cq ^ swz_a(hp)) << 3)) * 2) : ~0u;
-    }
+        const int off = ((((img * H + y) << WLOG) + x) * Cin) + chunk * 32 + ((cq ^ swz_a(hp)) << 3);   // < 2^31 (host check)
+        return ok ? (const void*)(X + off) : (const void*)zero_page;
+    };
     const int brow = wave * 16 + (lane >> 2);
     const half_t* bp = Wt + (size_t)(n0 + brow) * K + (((lane & 3) ^ swz_b(brow)) << 3);   // next weight slice to stage
     char* const ah_dst = smem;                                        // + buf * AH_BYTES + piece * 1024
@@ -93,15 +97,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     half8 ar[4], bf[2][4];
 
     // ---- prologue: halo of chunk 0, weight slices 0 and 1
-    auto halo_src = [&](uint32_t off) -> const void* { return off == ~0u ? (const void*)zero_page : (const void*)(Xb + off); };
 #pragma unroll
-    for (int t = 0; t < PA; ++t) glds16h(halo_src(aoff[t]), ah_dst + min(t * 8 + wave, NPA - 1) * 1024);
+    for (int t = 0; t < PA; ++t) glds16h(halo_src(t, 0), ah_dst + min(t * 8 + wave, NPA - 1) * 1024);
     glds16h(bp, b_dst);
     bp += Cin;
     glds16h(bp, b_dst + B_BYTES);
     bp += Cin;
     if (PA == 9) {                                                    // keeps the issue order of the steady state (see HL_VMN)
-        glds16h(halo_src(aoff[PA - 1]), ah_dst + min((PA - 1) * 8 + wave, NPA - 1) * 1024);
+        glds16h(halo_src(PA - 1, 0), ah_dst + min((PA - 1) * 8 + wave, NPA - 1) * 1024);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -125,12 +128,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     { if constexpr ((i) < FPR) HL_DSR(ar[slot], base0, (i) * 1024); else HL_DSR(ar[slot], base1, ((i) - FPR) * 1024); }
 #define HL_GROUP(P, T, g)                                                                                              \
     {                                                                                                                 \
+        if constexpr (RPW == 2 && (g) >= 1 && (g) <= 4) a_ad1 = HL_AADDR(ab, (T / 3 - 1) * HW2 + (T % 3 - 1), 1);     \
         if constexpr ((g) + 3 < TM) HL_RDA(((g) + 3) & 3, a_ad0, a_ad1, (g) + 3)                                       \
         if constexpr ((g) == 5) {                                                                                     \
             if (more) {                                                                                               \
                 asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]) : "n"(HL_VMN(T)) : "memory"); \
                 __builtin_amdgcn_s_barrier();                                                                         \
                 asm volatile("" ::: "memory");                                                                        \
+                const uint32_t b_nx = b_frag + (bs == 2 ? 0 : bs + 1) * B_BYTES;                                      \
+                a_nx0 = HL_AADDR(abn, dyn_ * HW2 + dxn_, 0);                                                          \
                 HL_DSR(bf[bn][0], b_nx, 0); HL_DSR(bf[bn][1], b_nx, 16 * ROWB);                                       \
                 HL_DSR(bf[bn][2], b_nx, 32 * ROWB); HL_DSR(bf[bn][3], b_nx, 48 * ROWB);                               \
                 HL_DSR(ar[0], a_nx0, 0);                                                                              \
@@ -155,8 +161,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
             } else glds16h(zero_page, b_dst + st2 * B_BYTES);         /* past the end: harmless load, static counts */   \
         }                                                                                                             \
         if constexpr ((g) == 1 && (T) < PA) {                         /* halo piece T of chunk c + 1 */                 \
-            if (c + 1 < NC) aoff[T] += aoff[T] == ~0u ? 0u : 64u;                                                      \
-            glds16h(halo_src(aoff[T]), ah_dst + (ab ^ 1) * AH_BYTES + min((T) * 8 + wave, NPA - 1) * 1024);           \
+            glds16h(halo_src(T, min(c + 1, NC - 1)), ah_dst + (ab ^ 1) * AH_BYTES + min((T) * 8 + wave, NPA - 1) * 1024); \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
@@ -170,10 +175,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         int hpv = hp0;                                                                                                \
         asm volatile("" : "+v"(hpv));                                 /* keeps the per-tap addresses out of loop-invariant registers */ \
         const uint32_t a_ad0 = HL_AADDR(ab, dy_ * HW2 + dx_, 0);                                                      \
-        const uint32_t a_ad1 = RPW == 2 ? HL_AADDR(ab, dy_ * HW2 + dx_, 1) : a_ad0;                                   \
+        uint32_t a_ad1 = a_ad0;                                       /* W = 64: second image row, computed after group 0 */ \
         const int abn = (T) == 8 ? (ab ^ 1) : ab;                                                                     \
-        const uint32_t a_nx0 = HL_AADDR(abn, dyn_ * HW2 + dxn_, 0);                                                   \
-        const uint32_t b_nx = b_frag + (bs == 2 ? 0 : bs + 1) * B_BYTES;                                              \
+        uint32_t a_nx0 = 0;                                           /* computed at the hand-over (short live range) */ \
         HL_GROUP(P, T, 0) HL_GROUP(P, T, 1) HL_GROUP(P, T, 2) HL_GROUP(P, T, 3)                                        \
         HL_GROUP(P, T, 4) HL_GROUP(P, T, 5) HL_GROUP(P, T, 6) HL_GROUP(P, T, 7)                                        \
         bs = bs == 2 ? 0 : bs + 1;                                                                                    \
@@ -263,7 +267,7 @@ int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half
 
 bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad) {
     return (W == 64 || W == 128 || W == 256) && ((long long)H * W) % 512 == 0 && Cin % 32 == 0 && Cout_pad % 128 == 0 &&
-           (long long)N * H * W <= 0x7fffffffLL;
+           (long long)N * H * W * Cin <= 0x7fffffffLL;
 }
 
 // gn_part (optional): fused GroupNorm octet partials, chunks = H*W / 512 per image (returned through gn_fused)

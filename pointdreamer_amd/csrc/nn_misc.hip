@@ -54,7 +54,8 @@ int conv_in_3x3(const float* x_nchw, const half_t* Wt, const float* bias, half_t
 // y[n][r] = b[r] + sum_k W[r][k] x[n][k], f32 (time-embedding MLP and every ResBlock's emb_layers in one call).
 // HBM-bound on the weight stream: x (<= 8 x K floats per pass) is staged in LDS once per block, a wave owns
 // GEMV_ROWS/4 rows and streams each row with 16-byte loads; batch entries are processed 8 at a time.
-#define GEMV_ROWS 64
+#define GEMV_ROWS 128
+template <int KI>                                                        // KI > 0: K == KI * 256, the whole row slice is loaded up front
 __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm, const float* __restrict__ b,
                                                    const float* __restrict__ x, float* __restrict__ y, int R, int K, int N,
                                                    int silu_out) {
@@ -64,9 +65,10 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm,
     for (int n0 = 0; n0 < N; n0 += 8) {
         const int nb = min(8, N - n0);
         __syncthreads();
-        for (int i = threadIdx.x; i < 8 * K; i += 256) s_x[i] = (i / K < nb) ? x[(size_t)n0 * K + i] : 0.f;
+        for (int j = 0; j < 8; ++j)
+            for (int k = threadIdx.x; k < K; k += 256) s_x[j * K + k] = j < nb ? x[(size_t)(n0 + j) * K + k] : 0.f;
         __syncthreads();
-        for (int rr = 0; rr < GEMV_ROWS / 4; rr += 4) {          // 4 rows at a time: 4 x K/64 independent 16-byte loads in flight
+        for (int rr = 0; rr < GEMV_ROWS / 4; rr += 4) {          // 4 rows at a time, all their 16-byte loads in flight together
             const int r = r0 + rr;
             if (r >= R) break;
             float acc[4][8];
@@ -74,18 +76,22 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm,
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
-            if ((K & 3) == 0) {
-                for (int k = lane * 4; k < K; k += 256) {
-                    float4 w[4];
+            if (KI > 0) {
+                float4 w[4][KI > 0 ? KI : 1];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const float4*>(Wm + (size_t)min(r + q, R - 1) * K + k);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int it = 0; it < KI; ++it)
+                        w[q][it] = *reinterpret_cast<const float4*>(Wm + (size_t)min(r + q, R - 1) * K + it * 256 + lane * 4);
+#pragma unroll
+                for (int it = 0; it < KI; ++it)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float4 xv = *reinterpret_cast<const float4*>(s_x + j * K + k);
+                        const float4 xv = *reinterpret_cast<const float4*>(s_x + j * K + it * 256 + lane * 4);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[q][j] += w[q].x * xv.x + w[q].y * xv.y + w[q].z * xv.z + w[q].w * xv.w;
+                        for (int q = 0; q < 4; ++q)
+                            acc[q][j] += w[q][it].x * xv.x + w[q][it].y * xv.y + w[q][it].z * xv.z + w[q][it].w * xv.w;
                     }
-                }
             } else {
                 for (int k = lane; k < K; k += 64) {
 #pragma unroll
@@ -115,7 +121,12 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ Wm,
 
 static int gemv_launch(const float* Wm, const float* b, const float* x, float* y, int R, int K, int N, int silu_out, hipStream_t s) {
     PD_REQUIRE((size_t)8 * K * sizeof(float) <= 64 * 1024, "gemv_rows: K too large (%d)", K);
-    k_gemv_rows<<<cdiv(R, GEMV_ROWS), 256, (size_t)8 * K * sizeof(float), s>>>(Wm, b, x, y, R, K, N, silu_out);
+    const size_t smem = (size_t)8 * K * sizeof(float);
+    const int grid = cdiv(R, GEMV_ROWS);
+    if (K == 1024) k_gemv_rows<4><<<grid, 256, smem, s>>>(Wm, b, x, y, R, K, N, silu_out);
+    else if (K == 512) k_gemv_rows<2><<<grid, 256, smem, s>>>(Wm, b, x, y, R, K, N, silu_out);
+    else if (K == 256) k_gemv_rows<1><<<grid, 256, smem, s>>>(Wm, b, x, y, R, K, N, silu_out);
+    else k_gemv_rows<0><<<grid, 256, smem, s>>>(Wm, b, x, y, R, K, N, silu_out);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
