@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 // taps: 1 (1x1 conv / linear over pixels) or 9 (3x3, pad 1).  Cin % 32 == 0.
 // 3x3 convolution with an LDS-resident activation halo (nn_conv_halo.hip): 512-pixel x 128-channel tiles, W in {64,128,256}
 bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad);
+bool conv_uses_halo(int N, int H, int W, int Cin, int Cout_pad, int taps);   // conv_igemm's routing decision (nn_gemm.hip)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
                  int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused);
 extern int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)

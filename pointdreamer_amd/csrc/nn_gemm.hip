@@ -547,6 +547,14 @@ static int launch_conv(dim3 grid, size_t smem, hipStream_t s, const half_t* X, c
     return PDHIP_OK;
 }
 
+// does conv_igemm route this layer to the halo-resident kernel? (tuning hook: tile geometry 32 forces it, any other forced
+// geometry / K-step / stage count disables it)
+bool conv_uses_halo(int N, int H, int W, int Cin, int Cout_pad, int taps) {
+    if (taps != 9 || !conv3x3_halo_eligible(N, H, W, Cin, Cout_pad)) return false;
+    if (g_force_wmw == 32) return true;
+    return g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && ((long long)N * H * W / 512) * (Cout_pad / 128) >= 256;
+}
+
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
                size_t splitk_ws_floats, float* gn_part, int* gn_fused, const half_t* X2, int Cin1) {
@@ -559,8 +567,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const long long M = (long long)N * H * W;
     // large-image 3x3 layers: halo-resident kernel (2.1x less L2 -> LDS traffic per flop) once it fills the chip
     // (tuning hook: tile geometry 32 forces it, any other forced geometry disables it)
-    if (taps == 9 && X2 == nullptr && conv3x3_halo_eligible(N, H, W, Cin, Cout_pad) &&
-        (g_force_wmw == 32 || (g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && (M / 512) * (Cout_pad / 128) >= 256)))
+    if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout_pad, taps))
         return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused);
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
     // tile geometry: 256x256 (wave tile 128x64: 25 % fewer LDS reads per MFMA, half the L2 traffic) once it still yields

@@ -162,12 +162,14 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 15) / 16) * (w.cout / 8) * 2 * 2)) : nullptr;
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
-    if (w.taps == 9) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
+    // profile hook (bench.py roofline): the dominant kernel only -- the halo-resident 3x3 conv
+    const bool prof = x.p2 == nullptr && conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout_pad, w.taps);
+    if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
     int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
                         c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0);
     if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = w.cout; }
-    if (w.taps == 9) PD_TRY(prof_end(c));
+    if (prof) PD_TRY(prof_end(c));
     return rc;
 }
 
