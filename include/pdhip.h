@@ -208,6 +208,21 @@ int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*
 int pdhip_groupnorm_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film /*[N][2C] or NULL*/, int N,
                              int H, int W, int C, int silu, int resample, void* y, float* stats_ws, float* ws,
                              long long ws_floats, void* stream);
+/* ---- complete_unseen_by='neighbor' (pointdreamer/unproject.py:93-196, demo.py:180-200).
+ * The mesh subdivision stays on the host (as in the reference); these are the per-texel / per-vertex kernels. */
+/* flags[f] = 1 for every face f that owns a chart texel no view painted (demo.py:180-181). face_id [A*A] int64 (-1 = background). */
+int pdhip_mark_unpainted_faces(const int64_t* face_id, const uint8_t* painted, int A, int F, uint8_t* flags /*[F]*/, void* stream);
+/* texel (row, col) = long(clip(uv * A, 0, A-1))[(1, 0)], colours = atlas[texel], count = mask[texel] (unproject.py:130-139) */
+int pdhip_vertex_texel_fetch(const float* vert_uvs /*[V,2]*/, int V, const float* atlas /*[A,A,3]*/, const uint8_t* mask /*[A,A]*/,
+                             int A, int32_t* texel /*[V,2]*/, float* colors /*[V,3]*/, float* count /*[V]*/, void* stream);
+/* one Jacobi round of unproject.py:160-166 over the `invalid` vertices (CSR neighbours, ascending); *colored = number of
+ * invalid vertices that hold a colour afterwards (device int; the host drives the loop as the reference does) */
+int pdhip_neighbor_diffuse_round(const int32_t* rowptr /*[V+1]*/, const int32_t* colidx, int V, const int32_t* invalid, int IV,
+                                 float* colors, float* count, float* tmp /*[IV*4]*/, int* colored, void* stream);
+/* atlas[texel[v]] = colors[v], mask[texel[v]] = 1 (unproject.py:187-188); several vertices on one texel: largest index wins */
+int pdhip_scatter_vertex_colors(const int32_t* texel, const float* colors, int V, float* atlas, uint8_t* mask,
+                                int32_t* owner_ws /*[A*A]*/, int A, void* stream);
+
 /* Output head of the UNet on its own (models/DDNM/guided_diffusion/unet.py:613-617): GroupNorm(32) -> SiLU -> conv3x3 in
  * float32-equivalent arithmetic.  x: f16 NHWC [N,H,W,C] (C in {32,64,128,256}); w_oihw f32 [Cout][C][3][3], Cout 3 or 6;
  * y f32 NCHW [N,Cout,H,W]; ws: pdhip_unet_head_ws_floats() device floats. */

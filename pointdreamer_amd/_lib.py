@@ -40,6 +40,10 @@ _SIGS = {
     'pdhip_view_select_blend': (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp, i32, vp, i32,
                                           vp, vp, vp, vp]),
     'pdhip_compact_texels': (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_mark_unpainted_faces': (C.c_int, [vp, vp, i32, i32, vp, vp]),
+    'pdhip_vertex_texel_fetch': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, vp]),
+    'pdhip_neighbor_diffuse_round': (C.c_int, [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
+    'pdhip_scatter_vertex_colors': (C.c_int, [vp, vp, i32, vp, vp, vp, i32, vp]),
 }
 
 

@@ -2,8 +2,8 @@
 
 `colorize_one_mesh` keeps the keyword surface of the reference's demo.colorize_one_mesh
 (/root/reference/demo.py:38-253) for the stages this build covers.  Stages outside SURVEY 8 rows (a)-(e)
-(`complete_unseen_by` 'neighbor'/'optimize', `optimize_color`) raise NotImplementedError instead of
-silently doing something else; `complete_unseen_by='unproject'`, `optimize_from=None` is the measured path.
+(`complete_unseen_by='optimize'`, `texture_gen_method='linear'`) raise NotImplementedError instead of silently doing
+something else; `complete_unseen_by='unproject'`, `optimize_from=None` is the measured path.
 """
 import torch
 
@@ -20,9 +20,11 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
                       xatlas_texture_res=1024, refine_res=512, return_intermediates=False, **kwargs):
     if refine_point_validation_by_remove_abnormal_depth:
         raise NotImplementedError("refine_point_validation_by_remove_abnormal_depth (off in every shipped config) is not built")
-    if complete_unseen_by != 'unproject':
-        raise NotImplementedError(f"complete_unseen_by={complete_unseen_by!r}: only 'unproject' is built (SURVEY 8f lists "
-                                  "'neighbor' and 'optimize' as next)")
+    if complete_unseen_by not in ('unproject', 'neighbor'):
+        raise NotImplementedError(f"complete_unseen_by={complete_unseen_by!r}: 'unproject' and 'neighbor' are built ('optimize' "
+                                  "needs the TextureField network, outside SURVEY 8)")
+    if complete_unseen_by == 'neighbor' and (xatlas_dict.get('uvs') is None or xatlas_dict.get('mesh_tex_idx') is None):
+        raise ValueError("complete_unseen_by='neighbor' needs xatlas_dict['uvs'] and ['mesh_tex_idx'] (demo.py:199-200)")
     if optimize_from not in (None, 'None', 'scratch', 'naive', 'ours'):
         raise ValueError(f"optimize_from={optimize_from!r}")
     cams = camera_info['cams']
@@ -51,8 +53,14 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
                                             method=texture_gen_method)
         atlas, shrinked, view_ids, painted, vis = up.unproject_dense(
             inpainted, f_normals, res, cams, cam_res, base_dirs, gb_pos, mask, face_id, uv_centers, uv_scales, padding,
-            scale_factors, mesh_depths, list(edge_dilate_kernels), True)
-        atlas = up.dilate_atlas(atlas, mask)
+            scale_factors, mesh_depths, list(edge_dilate_kernels), complete_unseen_by == 'unproject')
+        if complete_unseen_by == 'neighbor':
+            # demo.py:180-200: faces that still own unpainted texels -> subdivide, average over mesh neighbours, nearest fill
+            tif = up.unpainted_face_ids(face_id, painted, faces.shape[0])
+            atlas = up.paint_invisible_areas_by_neighbors(vertices, faces, xatlas_dict['uvs'], xatlas_dict['mesh_tex_idx'], tif,
+                                                          atlas, painted, use_atlas=True)
+        else:
+            atlas = up.dilate_atlas(atlas, mask)
         if optimize_from not in (None, 'None'):
             # demo.py:211-236: 100 Adam steps of the atlas against the inpainted views (flip to image orientation and back)
             from .optimize import optimize_color

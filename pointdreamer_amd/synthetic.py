@@ -51,6 +51,31 @@ def uv_sphere(stacks=50, slices=100, radius=0.5):
     return np.array(verts, F32), np.array(faces, np.int64), lut
 
 
+def uv_sphere_uvs(stacks=50, slices=100, A=1024, gutter=2):
+    """Explicit UVs of the lat-long sphere in the layout `latlong_atlas` rasterises (what xatlas would hand over as `uvs`,
+    `mesh_tex_idx`): uvs[(stacks+1)*(slices+1), 2] f32 in [0,1] (u = column / A, v = row / A; seam column duplicated, one
+    pole UV per fan triangle), face_uv_idx[F,3] int64 aligned with `uv_sphere`'s faces."""
+    span = A - 2 * gutter
+    uv = np.zeros(((stacks + 1) * (slices + 1), 2), np.float64)
+    for s in range(stacks + 1):
+        for k in range(slices + 1):
+            kf = (k + 0.5) / slices if s in (0, stacks) else k / slices       # poles: one UV per fan triangle
+            uv[s * (slices + 1) + k] = ((gutter + min(kf, 1.0) * span) / A, (gutter + s / stacks * span) / A)
+
+    def uid(s, k):
+        return s * (slices + 1) + k
+    fuv = []
+    for k in range(slices):
+        fuv.append((uid(0, k), uid(1, k + 1), uid(1, k)))
+    for s in range(1, stacks - 1):
+        for k in range(slices):
+            fuv.append((uid(s, k), uid(s, k + 1), uid(s + 1, k)))
+            fuv.append((uid(s, k + 1), uid(s + 1, k + 1), uid(s + 1, k)))
+    for k in range(slices):
+        fuv.append((uid(stacks, k), uid(stacks - 1, k), uid(stacks - 1, k + 1)))
+    return uv.astype(F32), np.array(fuv, np.int64)
+
+
 def face_normals(vertices, faces):
     """Unit face normals (what kal.ops.mesh.face_normals(unit=True) provides at demo.py:422)."""
     v = vertices.astype(np.float64)

@@ -141,3 +141,66 @@ def dilate_atlas(atlas_img, mask):
     """unproject.py:480-504: atlas_img[A,A,3], mask[1,A,A,1] bool -> [A,A,3] (float32 on the GPU)."""
     m = mask[..., 0].contiguous()
     return nearest_fill(atlas_img.unsqueeze(0), m, 'HWC')[0]
+
+
+def unpainted_face_ids(per_atlas_pixel_face_id, atlas_painted_mask, num_faces):
+    """demo.py:180-181: ids of the faces that own at least one chart texel no view painted (sorted, int64, on the host)."""
+    import numpy as np
+    L = _lib.lib()
+    fid = per_atlas_pixel_face_id[0].to(torch.int64).contiguous()
+    A = fid.shape[0]
+    flags = torch.empty((int(num_faces),), dtype=torch.uint8, device=_dev(fid))
+    check(L.pdhip_mark_unpainted_faces(ptr(fid), ptr(as_u8(atlas_painted_mask.contiguous())), A, int(num_faces), ptr(flags), stream()),
+          'pdhip_mark_unpainted_faces')
+    return np.nonzero(flags.cpu().numpy())[0].astype(np.int64)
+
+
+def paint_invisible_areas_by_neighbors(vertices, faces, uvs, face_uv_idx, to_inpaint_face_id, atlas_img, atlas_inpainted_mask,
+                                       use_atlas=True):
+    """unproject.py:93-196, same arguments.  atlas_img [A,A,3] f32, atlas_inpainted_mask [A,A] bool (both on the GPU).
+    Two rounds of midpoint subdivision of the unpainted faces (host numpy, as in the reference), per-vertex colour fetch,
+    Jacobi neighbour averaging with the reference's loop control, scatter back, exact nearest fill.
+    use_atlas=True -> atlas [A,A,3]; False -> (subdivided_vertices, subdivided_faces, vertex_colors)."""
+    import numpy as np
+    from . import mesh_utils as mu
+    L = _lib.lib()
+    dev = _dev(atlas_img)
+    A = atlas_inpainted_mask.shape[1]
+    to_np = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    sv, sf, su, sfu = to_np(vertices), to_np(faces), to_np(uvs), to_np(face_uv_idx)
+    tif = to_np(to_inpaint_face_id).astype(np.int64)
+    for _ in range(2):                      # unproject.py:111-114: the same index list both rounds (not re-mapped) -- kept
+        sv, sf, su, sfu = mu.subdivide_with_uv(sv, sf, sfu, su, face_index=tif)
+    V = len(sv)
+    vert_uvs = torch.from_numpy(mu.vertex_uv_table(V, sf, sfu, su)).to(dev)
+    rowptr, colidx = mu.neighbour_csr(V, sf)
+    rowptr_d, colidx_d = torch.from_numpy(rowptr).to(dev), torch.from_numpy(colidx).to(dev)
+    atlas = atlas_img.float().contiguous().clone()
+    mask = as_u8(atlas_inpainted_mask.contiguous()).clone()
+    texel = torch.empty((V, 2), dtype=torch.int32, device=dev)
+    colors = torch.empty((V, 3), device=dev)
+    count = torch.empty((V,), device=dev)
+    check(L.pdhip_vertex_texel_fetch(ptr(vert_uvs), V, ptr(atlas), ptr(mask), A, ptr(texel), ptr(colors), ptr(count), stream()),
+          'pdhip_vertex_texel_fetch')
+    invalid_np = np.nonzero(count.cpu().numpy() == 0)[0].astype(np.int32)
+    IV = len(invalid_np)
+    invalid = torch.from_numpy(invalid_np).to(dev) if IV else torch.zeros((1,), dtype=torch.int32, device=dev)
+    tmp = torch.empty((max(IV, 1) * 4,), device=dev)
+    colored = torch.zeros((1,), dtype=torch.int32, device=dev)
+    total, rounds, stage = V - IV, 0, "uncolored"
+    while stage == "uncolored" or rounds > 0:            # unproject.py:159-178 (one host sync per round, as the reference)
+        check(L.pdhip_neighbor_diffuse_round(ptr(rowptr_d), ptr(colidx_d), V, ptr(invalid), IV, ptr(colors), ptr(count), ptr(tmp),
+                                             ptr(colored), stream()), 'pdhip_neighbor_diffuse_round')
+        new_total = (V - IV) + int(colored.item())
+        if new_total > total:
+            total, rounds = new_total, rounds + 1
+        else:
+            stage, rounds = "colored", rounds - 1
+        if rounds > 10000:
+            break
+    if not use_atlas:
+        return torch.from_numpy(sv).to(dev), torch.from_numpy(sf).to(dev).long(), colors
+    owner = torch.empty((A * A,), dtype=torch.int32, device=dev)
+    check(L.pdhip_scatter_vertex_colors(ptr(texel), ptr(colors), V, ptr(atlas), ptr(mask), ptr(owner), A, stream()),
+          'pdhip_scatter_vertex_colors')
+    return nearest_fill(atlas.unsqueeze(0), mask.unsqueeze(0), 'HWC')[0]

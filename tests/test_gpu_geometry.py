@@ -381,3 +381,67 @@ def test_optimize_color_vs_oracle(pd, use_shr, iters):
         assert np.isfinite(N_(im)).all() and N_(im).min() >= 0 and N_(im).max() <= 1
     untouched = np.abs(oa.numpy()[0] - atlas0).max(0) == 0          # texels no view samples stay exactly as they were
     assert untouched.any() and np.array_equal(N_(a)[0][:, untouched], atlas0[:, untouched])
+
+
+@pytest.mark.parametrize("name", ["neighbor_small.npz", "neighbor_seam.npz"])
+def test_8f2_neighbor_completion_vs_oracle_and_reference_golden(name):
+    """complete_unseen_by='neighbor' through the C ABI: bit-exact against the oracle (same float32 op order, same tie rules),
+    and against the imported reference's outputs (1e-6; nearest-fill ties excepted)."""
+    from oracle import neighbor as onb
+    from pointdreamer_amd import unproject as up
+    g = load_golden(name)
+    o = onb.paint_invisible_areas_by_neighbors(g['vertices'], g['faces'], g['uvs'], g['face_uv_idx'], g['to_inpaint_face_id'],
+                                               g['atlas'], g['painted'], return_intermediates=True)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    atlas = up.paint_invisible_areas_by_neighbors(T(g['vertices']), T(g['faces']), T(g['uvs']), T(g['face_uv_idx']),
+                                                  g['to_inpaint_face_id'], T(g['atlas']), T(g['painted']), use_atlas=True)
+    out = atlas.cpu().numpy()
+    assert np.array_equal(out, o['atlas'])
+    sv, sf, vc = up.paint_invisible_areas_by_neighbors(T(g['vertices']), T(g['faces']), T(g['uvs']), T(g['face_uv_idx']),
+                                                       g['to_inpaint_face_id'], T(g['atlas']), T(g['painted']), use_atlas=False)
+    assert np.array_equal(vc.cpu().numpy(), o['vert_colors'])
+    assert np.array_equal(sf.cpu().numpy(), g['ref_sub_faces']) and np.array_equal(sv.cpu().numpy(), g['ref_sub_vertices'])
+    assert np.abs(vc.cpu().numpy() - g['ref_vert_colors']).max() <= 1e-6
+    m = g['ref_mask_before_fill'] > 0
+    assert np.abs(out[m] - g['ref_atlas'][m]).max() <= 1e-6
+    # unpainted-face marking (demo.py:180-181)
+    A = g['painted'].shape[0]
+    rng = np.random.default_rng(3)
+    fid = rng.integers(-1, 50, (1, A, A)).astype(np.int64)
+    painted = rng.uniform(0, 1, (A, A)) > 0.3
+    ids = up.unpainted_face_ids(T(fid), T(painted), 50)
+    ref = np.unique(fid[0][~painted]); ref = ref[ref > -1]
+    assert np.array_equal(ids, ref)
+
+
+def test_8f2_pipeline_neighbor_branch_vs_oracle(pd):
+    """colorize_one_mesh(complete_unseen_by='neighbor') on a shape with a large never-seen area (3 views of a sphere): the
+    pipeline's atlas equals unproject (no projection completion) -> oracle neighbour completion of the same tensors."""
+    from oracle import neighbor as onb
+    syn, ou, up = pd['syn'], pd['ou'], pd['up']
+    from pointdreamer_amd import pipeline
+    stacks, slices, A, V, R, r = 16, 32, 256, 3, 256, 128
+    verts, faces, lut = syn.uv_sphere(stacks, slices)
+    uvs, fuv = syn.uv_sphere_uvs(stacks, slices, A, gutter=2)
+    gb_pos, mask, fid = syn.latlong_atlas(A, stacks, slices, gutter=2, lut=lut)
+    xyz, rgb = syn.sphere_points(4000, seed=9)
+    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(V, 1.6, R, device=DEV)
+    xat = dict(gb_pos=T(gb_pos), mask=T(mask), per_atlas_pixel_face_id=T(fid), uvs=T(uvs), mesh_tex_idx=T(fuv))
+    cam_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    kw = dict(view_num=V, res=r, cam_res=R, point_validation_by_o3d=False, texture_gen_method='nearest', point_size=1,
+              edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None,
+              edge_dilate_kernels=[21])
+    fn = T(syn.face_normals(verts, faces))
+    out = pipeline.colorize_one_mesh(T(xyz), T(rgb), T(verts), T(faces), fn, xat, cam_info, complete_unseen_by='neighbor',
+                                     return_intermediates=True, **kw)
+    painted = N_(out['painted'])
+    m = mask[0, :, :, 0]
+    assert (m & ~painted).mean() > 0.05                       # a real unseen area
+    ref_run = pipeline.colorize_one_mesh(T(xyz), T(rgb), T(verts), T(faces), fn, xat, cam_info, complete_unseen_by='unproject',
+                                         return_intermediates=True, **kw)
+    # the pre-completion atlas: painted texels are the same in both runs; unpainted ones are zero before completion
+    atlas0 = np.where(painted[..., None], N_(ref_run['atlas']), 0.0).astype(np.float32)
+    tif = np.unique(fid[0][~painted]); tif = tif[tif > -1]
+    o = onb.paint_invisible_areas_by_neighbors(verts, faces, uvs, fuv, tif, atlas0, painted)
+    assert np.array_equal(N_(out['atlas']), o)
+    assert np.array_equal(N_(out['atlas'])[painted], atlas0[painted])

@@ -8,6 +8,8 @@ copied; the stubs carry no reference logic except two stand-ins for third-party 
   * torchvision.transforms.Resize -> F.interpolate(bilinear, align_corners=False, antialias=False)
     (what torchvision 0.15/0.16 does for tensors), bool tensors resized via float then `!= 0`;
   * kaolin.metrics.pointcloud.sided_distance -> exact brute force (first minimum).
+  * kaolin.ops.mesh.uniform_laplacian, trimesh.grouping.unique_rows, trimesh.geometry.faces_to_edges -> restatements of
+    their published behaviour (used by paint_invisible_areas_by_neighbors / subdivide_with_uv).
 """
 import os
 import sys
@@ -109,6 +111,43 @@ def install():
     kal = sys.modules['kaolin']
     if isinstance(kal, _Stub):
         kal.metrics.pointcloud.sided_distance = sided_distance
+
+        def uniform_laplacian(num_vertices, faces):
+            """kaolin.ops.mesh.uniform_laplacian (kaolin 0.15 docs): dense [V,V], row i = 1/deg(i) on the (unique) neighbours of
+            vertex i, -1 on the diagonal, rows of isolated vertices 0."""
+            f = faces.reshape(-1, 3).long()
+            e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+            e = torch.cat([e, e.flip(1)], 0).unique(dim=0)
+            adj = torch.zeros((num_vertices, num_vertices), dtype=torch.float32, device=faces.device)
+            adj[e[:, 0], e[:, 1]] = 1.0
+            adj[torch.arange(num_vertices), torch.arange(num_vertices)] = 0.0
+            L = adj / adj.sum(1, keepdim=True)
+            L[torch.arange(num_vertices), torch.arange(num_vertices)] = -1.0
+            L[torch.isnan(L)] = 0.0
+            return L
+        kal.ops.mesh.uniform_laplacian = uniform_laplacian
+    tg = sys.modules.get('trimesh.grouping')
+    if isinstance(tg, _Stub):
+        import numpy as np
+
+        def unique_rows(data, digits=None, keep_order=False):
+            """trimesh.grouping.unique_rows for small non-negative integer rows (trimesh 4.x: rows are bit-packed into one int64,
+            column j shifted by j*floor(64/ncols), then np.unique(return_index, return_inverse))."""
+            d = np.asanyarray(data).astype(np.int64)
+            prec = 64 // d.shape[1]
+            assert np.abs(d).max() < 2 ** (prec - 1)
+            h = np.zeros(len(d), np.int64)
+            for off, col in enumerate(d.T):
+                h ^= col << (off * prec)
+            _, unique, inverse = np.unique(h, return_index=True, return_inverse=True)
+            return unique, inverse
+
+        def faces_to_edges(faces, return_index=False):
+            """trimesh.geometry.faces_to_edges: (n,3) faces -> (3n,2) edges (0-1, 1-2, 2-0 per face)."""
+            f = np.asanyarray(faces)
+            return f[:, [0, 1, 1, 2, 2, 0]].reshape((-1, 2))
+        tg.unique_rows = unique_rows
+        sys.modules['trimesh.geometry'].faces_to_edges = faces_to_edges
 
 
 def import_reference():
