@@ -223,6 +223,19 @@ int pdhip_neighbor_diffuse_round(const int32_t* rowptr /*[V+1]*/, const int32_t*
 int pdhip_scatter_vertex_colors(const int32_t* texel, const float* colors, int V, float* atlas, uint8_t* mask,
                                 int32_t* owner_ws /*[A*A]*/, int A, void* stream);
 
+/* ---- I/O edges in native code (host functions; no device work except pdhip_chw_f32_to_hwc_u8).
+ * PLY (utils/other_utils.py:155-163): vertex element with x,y,z and red,green,blue, binary_little_endian or ascii. */
+long long pdhip_io_ply_count(const char* path);                 /* number of vertices, -1 on error */
+int pdhip_io_read_ply_xyzrgb(const char* path, float* xyz /*[n,3] host*/, uint8_t* rgb /*[n,3] host*/, long long n);
+/* OBJ + MTL, byte-identical to savemeshtes2 (models/get3d/get3d_utils/utils_3d.py:27-64). Host arrays (coordinates as
+ * double: `%f` of a float32 value is printed from its exact double). */
+int pdhip_io_write_obj_mtl(const char* obj_path, const char* mtl_path, const char* texture_stem, const double* points, long long P,
+                           const double* tcoords, long long T, const int64_t* faces, const int64_t* facetex, long long F);
+/* 8-bit RGB / RGBA PNG (utils/utils_2d.py:351-399 save path); hwc: host [H,W,channels] */
+int pdhip_io_write_png(const char* path, const uint8_t* hwc, int H, int W, int channels, int zlib_level);
+/* device: out[h,w,c] = uint8(clip(img[c,h,w] * 255, 0, 255)) -- the conversion the reference does on the host before saving */
+int pdhip_chw_f32_to_hwc_u8(const float* img, int C, int H, int W, uint8_t* out, void* stream);
+
 /* Output head of the UNet on its own (models/DDNM/guided_diffusion/unet.py:613-617): GroupNorm(32) -> SiLU -> conv3x3 in
  * float32-equivalent arithmetic.  x: f16 NHWC [N,H,W,C] (C in {32,64,128,256}); w_oihw f32 [Cout][C][3][3], Cout 3 or 6;
  * y f32 NCHW [N,Cout,H,W]; ws: pdhip_unet_head_ws_floats() device floats. */

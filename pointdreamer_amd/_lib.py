@@ -40,6 +40,11 @@ _SIGS = {
     'pdhip_view_select_blend': (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp, i32, vp, i32,
                                           vp, vp, vp, vp]),
     'pdhip_compact_texels': (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_io_ply_count': (C.c_longlong, [C.c_char_p]),
+    'pdhip_io_read_ply_xyzrgb': (C.c_int, [C.c_char_p, vp, vp, C.c_longlong]),
+    'pdhip_io_write_obj_mtl': (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, vp, C.c_longlong, vp, C.c_longlong, vp, vp, C.c_longlong]),
+    'pdhip_io_write_png': (C.c_int, [C.c_char_p, vp, i32, i32, i32, i32]),
+    'pdhip_chw_f32_to_hwc_u8': (C.c_int, [vp, i32, i32, i32, vp, vp]),
     'pdhip_mark_unpainted_faces': (C.c_int, [vp, vp, i32, i32, vp, vp]),
     'pdhip_vertex_texel_fetch': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, vp]),
     'pdhip_neighbor_diffuse_round': (C.c_int, [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),

@@ -95,12 +95,11 @@ def save_textured_mesh(vertices, uvs, faces, mesh_tex_idx, atlas_img, mask, outp
     """demo.py:264-307."""
     io_utils.savemeshtes2(vertices.cpu().numpy(), uvs.cpu().numpy(), faces.cpu().numpy(), mesh_tex_idx.cpu().numpy(),
                           os.path.join(output_root_path, 'models', 'model_normalized.obj'))
-    img = np.asarray(atlas_img.cpu().numpy(), dtype=np.float32) * 255.0
-    img = img.clip(0, 255).astype(np.uint8)
-    PIL.Image.fromarray(np.ascontiguousarray(img[::-1, :, :]), 'RGB').save(os.path.join(output_root_path, 'models', 'model_normalized.png'))
-    cat_mask = (mask[0].long() * 255).cpu().numpy().astype(np.uint8)
-    rgba = np.concatenate([img, cat_mask], axis=-1)
-    PIL.Image.fromarray(np.ascontiguousarray(rgba[::-1, :, :]), 'RGBA').save(os.path.join(output_root_path, 'others', 'atlas_wo_background.png'))
+    # atlas [A,A,3] -> flipped vertically, uint8(clip(x*255)), PNG (device conversion + native encoder)
+    io_utils.save_CHW_RGB_img(atlas_img.flip(0).permute(2, 0, 1), os.path.join(output_root_path, 'models', 'model_normalized.png'))
+    # others/atlas_wo_background.png: the atlas with the chart mask as alpha (demo.py:296-303)
+    rgba = torch.cat([atlas_img.float(), mask[0].to(atlas_img.device).float()], dim=-1)
+    io_utils.save_CHW_RGBA_img(rgba.flip(0).permute(2, 0, 1), os.path.join(output_root_path, 'others', 'atlas_wo_background.png'))
 
 
 def recon_one_textured_mesh(cfg, inpainter, camera_info, pc_file, name, device, logger):

@@ -1,28 +1,51 @@
-"""I/O edges of the texturing path (row O1 + PLY input), formats identical to the reference:
+"""I/O edges of the texturing path (row O1 + PLY input, SURVEY 8f-4), formats identical to the reference:
 utils/utils_2d.py:351-399 (PNG save/load, uint8 truncation), models/get3d/get3d_utils/utils_3d.py:27-64
 (OBJ/MTL), utils/other_utils.py:122-163 (binary little-endian PLY x,y,z f32 + red,green,blue u8).
-Pure numpy / PIL; no plyfile / trimesh dependency.
+The per-shape edges -- PLY read, OBJ/MTL write, PNG encode, float -> uint8 conversion -- run in native code
+(`csrc/io_native.hip` behind `pdhip_io_*`); the rarely used ones (PNG load, OBJ load, PLY write) are numpy / PIL.
 """
 import os
+import ctypes as C
 import numpy as np
-import PIL.Image
 import torch
 
+from . import _lib
 
-def _to_u8_hwc(img_chw):
-    img = np.asarray(img_chw, np.float32).transpose(1, 2, 0) * 255.0      # works on a copy (the reference scales in place)
-    return np.ascontiguousarray(img.clip(0, 255).astype(np.uint8))
+
+def _u8_hwc(img, channels):
+    """uint8 [H,W,C] host array of a CHW float image in [0,1]: `(img * 255).clip(0, 255).astype(uint8)` (utils_2d.py:351-372).
+    GPU tensors are converted on the device so only H*W*C bytes cross PCIe."""
+    if torch.is_tensor(img) and img.is_cuda:
+        L = _lib.lib()
+        img = img.float().contiguous()
+        Cn, H, W = img.shape
+        out = torch.empty((H, W, Cn), dtype=torch.uint8, device=img.device)
+        _lib.check(L.pdhip_chw_f32_to_hwc_u8(_lib.ptr(img), Cn, H, W, _lib.ptr(out), _lib.stream()), 'pdhip_chw_f32_to_hwc_u8')
+        arr = out.cpu().numpy()
+    else:
+        a = img.detach().cpu().numpy() if torch.is_tensor(img) else np.asarray(img)
+        arr = np.ascontiguousarray((a.astype(np.float32).transpose(1, 2, 0) * 255.0).clip(0, 255).astype(np.uint8))
+    assert arr.shape[2] == channels, f"expected {channels} channels, got {arr.shape[2]}"
+    return arr
+
+
+def _save_png(img, file_name, channels):
+    L = _lib.lib()
+    arr = _u8_hwc(img, channels)
+    _lib.check(L.pdhip_io_write_png(os.fspath(file_name).encode(), arr.ctypes.data_as(C.c_void_p), arr.shape[0], arr.shape[1],
+                                    channels, 1), 'pdhip_io_write_png')
 
 
 def save_CHW_RGB_img(img, file_name):
-    PIL.Image.fromarray(_to_u8_hwc(img), 'RGB').save(file_name)
+    _save_png(img, file_name, 3)
 
 
 def save_CHW_RGBA_img(img, file_name):
-    PIL.Image.fromarray(_to_u8_hwc(img), 'RGBA').save(file_name)
+    _save_png(img, file_name, 4)
 
 
 def load_CHW_RGB_img(file_name):
+    import PIL.Image
     im = PIL.Image.open(file_name)
     if im.mode != 'RGB':
         im = im.convert('RGB')
@@ -31,40 +54,15 @@ def load_CHW_RGB_img(file_name):
 
 
 def read_ply_xyzrgb(path):
-    """Binary-LE or ASCII PLY with vertex properties x,y,z (float) and red,green,blue (uchar)."""
-    with open(path, 'rb') as f:
-        header = []
-        while True:
-            line = f.readline()
-            if not line:
-                raise ValueError("bad PLY header")
-            header.append(line.decode('ascii', 'replace').strip())
-            if header[-1] == 'end_header':
-                break
-        fmt = [h for h in header if h.startswith('format')][0].split()[1]
-        n = 0
-        props = []
-        in_vertex = False
-        for h in header:
-            t = h.split()
-            if t[:1] == ['element']:
-                in_vertex = t[1] == 'vertex'
-                if in_vertex:
-                    n = int(t[2])
-            elif t[:1] == ['property'] and in_vertex:
-                props.append((t[2], t[1]))
-        np_t = {'float': '<f4', 'float32': '<f4', 'double': '<f8', 'float64': '<f8', 'uchar': 'u1', 'uint8': 'u1',
-                'int': '<i4', 'int32': '<i4', 'uint': '<u4', 'short': '<i2', 'ushort': '<u2', 'char': 'i1'}
-        if fmt == 'binary_little_endian':
-            dt = np.dtype([(name, np_t[ty]) for name, ty in props])
-            data = np.frombuffer(f.read(dt.itemsize * n), dtype=dt, count=n)
-        elif fmt == 'ascii':
-            rows = np.loadtxt(f, max_rows=n, ndmin=2)
-            data = {name: rows[:, i] for i, (name, _) in enumerate(props)}
-        else:
-            raise ValueError(f"unsupported PLY format {fmt}")
-    xyz = np.stack([data['x'], data['y'], data['z']], -1)
-    rgb = np.stack([data['red'], data['green'], data['blue']], -1)
+    """Binary-LE or ASCII PLY with vertex properties x,y,z and red,green,blue -> (xyz float32 [n,3], rgb uint8 [n,3])."""
+    L = _lib.lib()
+    p = os.fspath(path).encode()
+    n = L.pdhip_io_ply_count(p)
+    if n < 0:
+        raise _lib.PdhipError(L.pdhip_last_error().decode())
+    xyz = np.empty((n, 3), np.float32)
+    rgb = np.empty((n, 3), np.uint8)
+    _lib.check(L.pdhip_io_read_ply_xyzrgb(p, xyz.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p), n), 'pdhip_io_read_ply_xyzrgb')
     return xyz, rgb
 
 
@@ -99,17 +97,14 @@ def load_obj_mesh(path):
 
 
 def savemeshtes2(pointnp_px3, tcoords_px2, facenp_fx3, facetex_fx3, fname):
-    """utils_3d.py:27-64, byte-identical text output."""
+    """utils_3d.py:27-64, byte-identical text output (native formatter)."""
+    L = _lib.lib()
     fol, na = os.path.split(fname)
     na, _ = os.path.splitext(na)
-    with open(os.path.join(fol, 'model_normalized.mtl'), 'w') as fid:
-        fid.write('newmtl material_0\nKd 1 1 1\nKa 0 0 0\nKs 0.4 0.4 0.4\nNs 10\nillum 2\nmap_Kd %s.png\n' % na)
-    out = ['mtllib %s.mtl\n' % na]
-    out += ['v %f %f %f\n' % (p[0], p[1], p[2]) for p in pointnp_px3]
-    out += ['vt %f %f\n' % (p[0], p[1]) for p in tcoords_px2]
-    out.append('usemtl material_0\n')
-    f1 = np.asarray(facenp_fx3) + 1
-    f2 = np.asarray(facetex_fx3) + 1
-    out += ['f %d/%d %d/%d %d/%d\n' % (a[0], b[0], a[1], b[1], a[2], b[2]) for a, b in zip(f1, f2)]
-    with open(fname, 'w') as fid:
-        fid.write(''.join(out))
+    pts = np.ascontiguousarray(np.asarray(pointnp_px3)[:, :3], np.float64)
+    tcs = np.ascontiguousarray(np.asarray(tcoords_px2)[:, :2], np.float64)
+    f1 = np.ascontiguousarray(facenp_fx3, np.int64)
+    f2 = np.ascontiguousarray(facetex_fx3, np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _lib.check(L.pdhip_io_write_obj_mtl(os.fspath(fname).encode(), os.path.join(fol, 'model_normalized.mtl').encode(), na.encode(),
+                                        vp(pts), len(pts), vp(tcs), len(tcs), vp(f1), vp(f2), len(f1)), 'pdhip_io_write_obj_mtl')

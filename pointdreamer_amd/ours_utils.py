@@ -134,9 +134,9 @@ def get_sparse_images(point_pixels, colors, point_validation, hard_masks, save_p
         os.makedirs(save_path, exist_ok=True)
         for i in range(V):
             save_mask = (m0[i][0] * m2[i][0]).unsqueeze(0)
-            io_utils.save_CHW_RGBA_img(torch.cat([sparse[i], save_mask]).cpu().numpy(), os.path.join(save_path, f'{i}_sparse.png'))
-            io_utils.save_CHW_RGB_img(m0[i].cpu().numpy(), os.path.join(save_path, f'{i}_mask0.png'))
-            io_utils.save_CHW_RGB_img(m2[i].cpu().numpy(), os.path.join(save_path, f'{i}_mask2.png'))
+            io_utils.save_CHW_RGBA_img(torch.cat([sparse[i], save_mask]), os.path.join(save_path, f'{i}_sparse.png'))
+            io_utils.save_CHW_RGB_img(m0[i], os.path.join(save_path, f'{i}_mask0.png'))
+            io_utils.save_CHW_RGB_img(m2[i], os.path.join(save_path, f'{i}_mask2.png'))
     return sparse, m0, m2, sf
 
 
@@ -185,7 +185,7 @@ def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpai
             os.makedirs(save_path, exist_ok=True)
             for i in range(view_num):
                 rgba = torch.cat([out[i], hard_mask0s[i][0].unsqueeze(0)])
-                io_utils.save_CHW_RGBA_img(rgba.cpu().numpy(), os.path.join(save_path, f'{i}_inpainted.png'))
+                io_utils.save_CHW_RGBA_img(rgba, os.path.join(save_path, f'{i}_inpainted.png'))
         return out
     if method != 'nearest':
         raise NotImplementedError(f"texture_gen_method={method!r} is not built (DDNM_inpaint | nearest)")
@@ -194,5 +194,5 @@ def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpai
     if save_path is not None:
         os.makedirs(save_path, exist_ok=True)
         for i in range(view_num):
-            io_utils.save_CHW_RGB_img(out[i].cpu().numpy(), os.path.join(save_path, f'{i}_inpainted.png'))
+            io_utils.save_CHW_RGB_img(out[i], os.path.join(save_path, f'{i}_inpainted.png'))
     return out

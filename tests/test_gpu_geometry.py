@@ -445,3 +445,15 @@ def test_8f2_pipeline_neighbor_branch_vs_oracle(pd):
     o = onb.paint_invisible_areas_by_neighbors(verts, faces, uvs, fuv, tif, atlas0, painted)
     assert np.array_equal(N_(out['atlas']), o)
     assert np.array_equal(N_(out['atlas'])[painted], atlas0[painted])
+
+
+def test_8f4_device_u8_conversion_and_native_png(tmp_path):
+    """pdhip_chw_f32_to_hwc_u8 = (img * 255).clip(0, 255).astype(uint8) with CHW -> HWC; PNG written from a GPU tensor."""
+    import PIL.Image
+    from pointdreamer_amd import io_utils
+    rng = np.random.default_rng(4)
+    img = rng.uniform(-0.2, 1.2, (4, 65, 130)).astype(np.float32)
+    img[0, 0, :4] = [0.999, 1.0, 0.0, 254.5 / 255]
+    p = str(tmp_path / 'g.png')
+    io_utils.save_CHW_RGBA_img(T(img), p)
+    assert np.array_equal(np.array(PIL.Image.open(p)), (img.transpose(1, 2, 0) * 255).clip(0, 255).astype(np.uint8))

@@ -52,3 +52,48 @@ def test_obj_mtl_text_format(tmp_path):
     assert mtl == ['newmtl material_0', 'Kd 1 1 1', 'Ka 0 0 0', 'Ks 0.4 0.4 0.4', 'Ns 10', 'illum 2', 'map_Kd model_normalized.png']
     vv, ff = io_utils.load_obj_mesh(p)
     assert np.allclose(vv, v) and np.array_equal(ff, f)
+
+
+def test_native_obj_writer_is_byte_identical_to_python_percent_f(tmp_path):
+    """8f-4: the native OBJ writer against the reference's own formatting expression (`'%f' % numpy_float32`)."""
+    rng = np.random.default_rng(1)
+    v = (rng.standard_normal((500, 3)) * 10 ** rng.uniform(-6, 3, (500, 1))).astype(np.float32)
+    vt = rng.uniform(0, 1, (700, 2)).astype(np.float32)
+    f = rng.integers(0, 500, (900, 3))
+    ft = rng.integers(0, 700, (900, 3))
+    p = str(tmp_path / 'm.obj')
+    io_utils.savemeshtes2(v, vt, f, ft, p)
+    exp = ['mtllib m.mtl\n'] + ['v %f %f %f\n' % (q[0], q[1], q[2]) for q in v] + ['vt %f %f\n' % (q[0], q[1]) for q in vt]
+    exp += ['usemtl material_0\n'] + ['f %d/%d %d/%d %d/%d\n' % (a[0], b[0], a[1], b[1], a[2], b[2]) for a, b in zip(f + 1, ft + 1)]
+    assert open(p).read() == ''.join(exp)
+
+
+def test_native_png_encoder_decodes_to_the_same_pixels(tmp_path):
+    rng = np.random.default_rng(2)
+    for ch, mode in ((3, 'RGB'), (4, 'RGBA')):
+        img = rng.uniform(-0.1, 1.1, (ch, 37, 53)).astype(np.float32)
+        p = str(tmp_path / f'r{ch}.png')
+        (io_utils.save_CHW_RGB_img if ch == 3 else io_utils.save_CHW_RGBA_img)(img, p)
+        im = PIL.Image.open(p)
+        assert im.mode == mode and im.size == (53, 37)
+        assert np.array_equal(np.array(im), (img.transpose(1, 2, 0) * 255).clip(0, 255).astype(np.uint8))
+
+
+def test_native_ply_reader_ascii_and_extra_properties(tmp_path):
+    p = str(tmp_path / 'a.ply')
+    with open(p, 'w') as f:
+        f.write("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                "property float nx\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nelement face 0\n"
+                "property list uchar int vertex_indices\nend_header\n0 0.5 1 9 255 0 7\n-1.25 2 3 9 1 2 3\n4 5 6.5 9 10 20 30\n")
+    xyz, rgb = io_utils.read_ply_xyzrgb(p)
+    assert np.array_equal(xyz, np.array([[0, 0.5, 1], [-1.25, 2, 3], [4, 5, 6.5]], np.float32))
+    assert np.array_equal(rgb, np.array([[255, 0, 7], [1, 2, 3], [10, 20, 30]], np.uint8))
+    # binary with a double-typed coordinate and a leading extra property
+    q = str(tmp_path / 'b.ply')
+    v = np.zeros(2, dtype=[('s', '<i2'), ('x', '<f8'), ('y', '<f4'), ('z', '<f4'), ('red', 'u1'), ('green', 'u1'), ('blue', 'u1')])
+    v['s'], v['x'], v['y'], v['z'], v['red'], v['green'], v['blue'] = [7, 8], [0.25, -3.5], [1, 2], [3, 4], [9, 8], [7, 6], [5, 4]
+    with open(q, 'wb') as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty short s\nproperty double x\nproperty float y\n"
+                b"property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" + v.tobytes())
+    xyz, rgb = io_utils.read_ply_xyzrgb(q)
+    assert np.array_equal(xyz, np.array([[0.25, 1, 3], [-3.5, 2, 4]], np.float32)) and np.array_equal(rgb, np.array([[9, 7, 5], [8, 6, 4]], np.uint8))
