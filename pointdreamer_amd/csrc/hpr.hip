@@ -9,6 +9,11 @@
 // reduction.  One wavefront owns 16 query points: all 64 lanes stream the flipped cloud once per round (coalesced f64
 // SoA, L2-resident: 24 N bytes per view) and evaluate the 16 search directions against every point (48 f64 FMAs per
 // 24 bytes), the 16 GJK states live in lanes 0-15.  Work: ~10 rounds x N^2 x 3 FMA per view (f64 vector rate bound).
+// Two levels: the queries are first tested against a COARSE support set -- the KC extreme points of the flipped cloud in KC
+// Fibonacci-sphere directions (one streaming pass).  conv(subset) is inside conv(cloud), so "origin enclosed" there is already
+// the final answer (hidden); only the queries the coarse hull cannot enclose (the visible ones and a thin shell) pay for
+// full-cloud support scans.  30 k points x 8 views: 88 -> 53 ms for all points, 48 -> 23 ms behind the depth-test skip mask
+// (KC = 1024 measured best of 512..8192).
 // qhull's facet-merging tolerances are not reproduced (PARITY UNPINNED, open3d absent): points within ~1e-9 of a hull
 // facet may be classified differently; tests bound the disagreement with scipy's qhull.
 #include "common.h"
@@ -16,6 +21,8 @@ using namespace pdhip;
 
 #define QPW 16                 // query points per wavefront
 #define GJK_MAX_ROUNDS 64
+#define GJK_COARSE_ROUNDS 32
+#define HPR_KC 1024            // coarse support set size
 
 struct d3 { double x, y, z; };
 __device__ __forceinline__ d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -53,14 +60,24 @@ __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __re
     }
 }
 
+// COARSE: support set = the KC extreme points (coords cs[v][3][KC], original indices cidx[v][KC]); hidden is final, everything
+// else is appended to list2 / count2 for the full pass.  !COARSE: support set = the whole flipped cloud, final answer.
+template <bool COARSE>
 __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
-                                                 const int* __restrict__ list, uint8_t* __restrict__ vis) {
+                                                 const int* __restrict__ list, uint8_t* __restrict__ vis,
+                                                 const double* __restrict__ cs, const int* __restrict__ cidx, int KC,
+                                                 int* __restrict__ count2, int* __restrict__ list2) {
     __shared__ double s_dir[4][QPW][3];
     __shared__ int s_q[4][QPW];
     const int v = blockIdx.y;
-    const double* fx = flipped + (size_t)v * 3 * N;
-    const double* fy = fx + N;
-    const double* fz = fy + N;
+    const double* qfx = flipped + (size_t)v * 3 * N;          // the queries' own coordinates
+    const double* qfy = qfx + N;
+    const double* qfz = qfy + N;
+    const double* fx = COARSE ? cs + (size_t)v * 3 * KC : qfx;      // the support set
+    const double* fy = fx + (COARSE ? KC : N);
+    const double* fz = fy + (COARSE ? KC : N);
+    const int* sidx = COARSE ? cidx + (size_t)v * KC : nullptr;
+    const int NS = COARSE ? KC : N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = (blockIdx.x * 4 + wave) * QPW;
     const int nq = count[v];
@@ -77,10 +94,10 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
     int dim = 0;                   // simplex size; phases: 0 -> fetch c, 1 -> fetch b, >= 2 -> main loop
     int state = owner ? 0 : 2;     // 0 running, 1 visible (origin outside), 2 hidden / not a query
     if (owner) {
-        pi = {fx[q], fy[q], fz[q]};
+        pi = {qfx[q], qfy[q], qfz[q]};
         dir = pi;                  // start looking straight out along the point's own ray
     }
-    for (int round = 0; round < GJK_MAX_ROUNDS; ++round) {
+    for (int round = 0; round < (COARSE ? GJK_COARSE_ROUNDS : GJK_MAX_ROUNDS); ++round) {
         if (__ballot(state == 0) == 0ull) break;
         if (lane < QPW) { s_dir[wave][lane][0] = dir.x; s_dir[wave][lane][1] = dir.y; s_dir[wave][lane][2] = dir.z; }
         __builtin_amdgcn_wave_barrier();
@@ -92,12 +109,13 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
             best[k] = -1.0e300; bi[k] = 0x7fffffff;
         }
         // ---- support scan: every lane streams points j = lane, lane+64, ...
-        for (int j = lane; j < N; j += 64) {
+        for (int j = lane; j < NS; j += 64) {
             const double x = fx[j], y = fy[j], z = fz[j];
+            const int jo = COARSE ? sidx[j] : j;                     // index in the cloud
 #pragma unroll
             for (int k = 0; k < QPW; ++k) {
                 double val = dx[k] * x + dy[k] * y + dz[k] * z;
-                if (j == qk[k]) val = -1.0e300;                     // S_i excludes the point itself
+                if (jo == qk[k]) val = -1.0e300;                    // S_i excludes the point itself
                 if (val > best[k]) { best[k] = val; bi[k] = j; }
             }
         }
@@ -118,7 +136,7 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
         if (state == 0) {
             // support point of S_i in direction dir: best flipped point, or the origin of the flipped space (value 0)
             d3 a;
-            if (myv > 0.0 && myi < N) a = d3{fx[myi], fy[myi], fz[myi]} - pi;
+            if (myv > 0.0 && myi < NS) a = d3{fx[myi], fy[myi], fz[myi]} - pi;
             else a = neg(pi);
             if (dim == 0) {                       // first vertex
                 sc = a; dir = neg(a); dim = 1;
@@ -157,28 +175,98 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
             }
         }
     }
-    if (owner) vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
+    if (!COARSE) {
+        if (owner) vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
+    } else {
+        if (owner && state == 2) vis[(size_t)v * N + q] = 0;         // enclosed by the coarse hull: hidden, final
+        const bool again = owner && state != 2;                      // outside the coarse hull or undecided: full pass
+        const unsigned long long bal = __ballot(again);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&count2[v], __popcll(bal));
+        base = __shfl(base, 0);
+        if (again) list2[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = q;
+    }
 }
 
-static size_t flipped_bytes(int V, int N) { return (((size_t)V * 3 * (size_t)(N > 0 ? N : 1) * sizeof(double)) + 255) & ~(size_t)255; }
-extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) { return flipped_bytes(V, N) + (size_t)V * ((size_t)N + 64) * sizeof(int); }
+// coarse support set: the extreme point of the flipped cloud in each of KC Fibonacci-sphere directions (ties: smallest index)
+__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, int KC, double* __restrict__ cs,
+                                                      int* __restrict__ cidx) {
+    const int v = blockIdx.y;
+    const double* fx = flipped + (size_t)v * 3 * N;
+    const double* fy = fx + N;
+    const double* fz = fy + N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k0 = (blockIdx.x * 4 + wave) * QPW;
+    if (k0 >= KC) return;
+    double dx[QPW], dy[QPW], dz[QPW], best[QPW];
+    int bi[QPW];
+#pragma unroll
+    for (int k = 0; k < QPW; ++k) {
+        const int kk = min(k0 + k, KC - 1);
+        const double z = 1.0 - (2.0 * kk + 1.0) / KC, r = sqrt(fmax(0.0, 1.0 - z * z)), phi = kk * 2.399963229728653;
+        dx[k] = r * cos(phi); dy[k] = r * sin(phi); dz[k] = z;
+        best[k] = -1.0e300; bi[k] = 0x7fffffff;
+    }
+    for (int j = lane; j < N; j += 64) {
+        const double x = fx[j], y = fy[j], z = fz[j];
+#pragma unroll
+        for (int k = 0; k < QPW; ++k) {
+            const double val = dx[k] * x + dy[k] * y + dz[k] * z;
+            if (val > best[k]) { best[k] = val; bi[k] = j; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QPW; ++k) {
+        double b = best[k];
+        int id = bi[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(b, off);
+            const int oi = __shfl_xor(id, off);
+            if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
+        }
+        if (lane == 0 && k0 + k < KC) {
+            double* c = cs + (size_t)v * 3 * KC;
+            c[k0 + k] = fx[id]; c[KC + k0 + k] = fy[id]; c[2 * (size_t)KC + k0 + k] = fz[id];
+            cidx[(size_t)v * KC + k0 + k] = id;
+        }
+    }
+}
+
+static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t flipped_bytes(int V, int N) { return a256((size_t)V * 3 * (size_t)(N > 0 ? N : 1) * sizeof(double)); }
+static size_t lists_bytes(int V, int N) { return a256((size_t)V * ((size_t)N + 64) * sizeof(int)); }
+extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
+    return flipped_bytes(V, N) + 2 * lists_bytes(V, N) + a256((size_t)V * 3 * HPR_KC * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(int));
+}
 
 extern "C" int pdhip_hidden_point_removal(const float* points, int N, const double* eyes_dev, int V, double radius,
                                           const uint8_t* skip, uint8_t* visibility, void* ws, void* stream) {
     PD_REQUIRE(V > 0 && N >= 0, "pdhip_hidden_point_removal: bad sizes");
     if (N == 0) return PDHIP_OK;
     PD_REQUIRE(points && eyes_dev && visibility && ws, "pdhip_hidden_point_removal: null pointer");
+    PD_REQUIRE(V <= 64, "pdhip_hidden_point_removal: at most 64 views");
     hipStream_t s = as_stream(stream);
-    double* flipped = reinterpret_cast<double*>(ws);
+    char* p = reinterpret_cast<char*>(ws);
+    double* flipped = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
+    int* count = reinterpret_cast<int*>(p); int* list = count + 64; p += lists_bytes(V, N);
+    int* count2 = reinterpret_cast<int*>(p); int* list2 = count2 + 64; p += lists_bytes(V, N);
+    double* cs = reinterpret_cast<double*>(p); p += a256((size_t)V * 3 * HPR_KC * sizeof(double));
+    int* cidx = reinterpret_cast<int*>(p);
     dim3 gf(min(cdiv(N, 256), 256), V);
     k_hpr_flip<<<gf, 256, 0, s>>>(points, N, eyes_dev, radius, flipped);
-    int* count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + flipped_bytes(V, N));
-    int* list = count + 64;
     PD_HIP(hipMemsetAsync(count, 0, 64 * sizeof(int), s));
-    PD_REQUIRE(V <= 64, "pdhip_hidden_point_removal: at most 64 views");
+    PD_HIP(hipMemsetAsync(count2, 0, 64 * sizeof(int), s));
     k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);
     dim3 gg(cdiv(N, 4 * QPW), V);
-    k_hpr_gjk<<<gg, 256, 0, s>>>(flipped, N, count, list, visibility);
+    if (N > 4 * HPR_KC) {            // the coarse level pays off only when the cloud is much larger than the coarse set
+        dim3 ge(cdiv(HPR_KC, 4 * QPW), V);
+        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, HPR_KC, cs, cidx);
+        k_hpr_gjk<true><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, cs, cidx, HPR_KC, count2, list2);
+        k_hpr_gjk<false><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, nullptr, nullptr, 0, nullptr, nullptr);
+    } else {
+        k_hpr_gjk<false><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, nullptr, nullptr, 0, nullptr, nullptr);
+    }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
