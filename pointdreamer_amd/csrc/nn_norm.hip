@@ -144,14 +144,14 @@ template <int RES, bool OUT_F32, bool FILM>
 __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ film, long long film_stride, int H, int W,
-                                                  int C, int silu, void* __restrict__ Yv, const half_t* __restrict__ XB, int Ca) {
+                                                  int C, int silu, void* __restrict__ Yv, const half_t* __restrict__ XB, int Ca, int iters) {
     const int opp = C >> 3, cg = C / 32;
     const int pps = max(1, 256 / opp);
     const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
     const int n = blockIdx.y;
     const int sub = threadIdx.x / opp;
     if (sub >= pps) return;
-    const int p_begin = blockIdx.x * (pps * GNA_ITERS), p_end = min(Ho * Wo, p_begin + pps * GNA_ITERS);
+    const int p_begin = blockIdx.x * (pps * iters), p_end = min(Ho * Wo, p_begin + pps * iters);
     for (int oc = threadIdx.x - sub * opp; oc < opp; oc += 256) {
         const int c0 = oc * 8;
         // input of a never-materialised channel concat: channels [0, Ca) live in X (pixel stride Ca), the rest in XB
@@ -252,12 +252,16 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     PD_REQUIRE(film == nullptr || resample == 0, "gn_apply: FiLM only without resampling");
     const int Ho = resample == 1 ? H / 2 : (resample == 2 ? H * 2 : H), Wo = resample == 1 ? W / 2 : (resample == 2 ? W * 2 : W);
     const int opp = C >> 3, pps = max(1, 256 / opp);
-    dim3 grid(cdiv((long long)Ho * Wo, pps * GNA_ITERS), N);
-    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
-    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
-    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
-    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
-    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca);
+    // pixels per thread: 32 on the big tensors (constants amortised), fewer on the small ones so that the grid still fills
+    // the chip (a 64-pixel 8x8 level with 32 pixels per thread is 8 workgroups walking a serial latency chain)
+    int iters = GNA_ITERS;
+    while (iters > 1 && (long long)cdiv((long long)Ho * Wo, pps * iters) * N < 2048) iters >>= 1;
+    dim3 grid(cdiv((long long)Ho * Wo, pps * iters), N);
+    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
+    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
+    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
+    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
+    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
