@@ -121,15 +121,25 @@ def recon_one_textured_mesh(cfg, inpainter, camera_info, pc_file, name, device, 
     geo_path = pc_file.replace('.ply', '_untextured_mesh.obj')
     xatlas_file = os.path.join(out, 'geo', f'xatlas_{cfg.xatlas_texture_res}.pth')
     if os.path.exists(geo_path):
-        v, f = io_utils.load_obj_mesh(geo_path)
+        v, f, vt, ft = io_utils.load_obj_mesh(geo_path, with_uv=True)
         vertices = torch.from_numpy(v).to(device)
         faces = torch.from_numpy(f).to(device)
         vertices -= (vmax + vmin) / 2.
         vertices /= (vmax - vmin).max()
-        if not os.path.exists(xatlas_file):
-            raise FileNotFoundError(f"{xatlas_file} not found: UV unwrapping (xatlas + UV rasterisation, "
-                                    "models/get3d/extract_texture_map.py:42-64) is upstream of this build; provide the cached dict")
-        xatlas_dict = {k: (t.to(device) if torch.is_tensor(t) else t) for k, t in torch.load(xatlas_file).items()}
+        if os.path.exists(xatlas_file):
+            xatlas_dict = {k: (t.to(device) if torch.is_tensor(t) else t) for k, t in torch.load(xatlas_file).items()}
+        elif vt is not None:
+            # the mesh carries its UV parametrisation (`vt` + `f v/vt`): run the atlas producer (the rasterise + interpolate half of
+            # xatlas_uvmap_w_face_id, extract_texture_map.py:48-64) and cache the dict in the reference's wire format (demo.py:445-448)
+            from .extract_texture_map import uvmap_w_face_id
+            uvs, tex_idx, gb_pos, amask, fid = uvmap_w_face_id(vertices, faces, torch.from_numpy(vt).to(device),
+                                                               torch.from_numpy(ft).to(device), cfg.xatlas_texture_res)
+            xatlas_dict = dict(uvs=uvs, mesh_tex_idx=tex_idx, gb_pos=gb_pos, mask=amask, per_atlas_pixel_face_id=fid)
+            torch.save({k: t.cpu() for k, t in xatlas_dict.items()}, xatlas_file)
+            logger.info(f'UV atlas rasterised from the mesh\'s own vt/f records -> {xatlas_file}')
+        else:
+            raise FileNotFoundError(f"{xatlas_file} not found and {geo_path} has no vt / f v/vt records: the chart parametrisation "
+                                    "(xatlas.parametrize, CPU third-party) is upstream of this build; provide either")
         logger.info('Existing geometry + xatlas data loaded')
     else:
         vertices, faces, xatlas_dict = standin_geometry(xyz, cfg.xatlas_texture_res, device, logger)

@@ -79,9 +79,11 @@ def save_colored_pc_ply(coords, colors, path):
         f.write(v.tobytes())
 
 
-def load_obj_mesh(path):
-    """Vertices / triangle faces of an OBJ (what kal.io.obj.import_mesh provides at demo.py:395)."""
-    vs, fs = [], []
+def load_obj_mesh(path, with_uv=False):
+    """Vertices / triangle faces of an OBJ (what kal.io.obj.import_mesh provides at demo.py:395).  with_uv=True also returns
+    the `vt` table and the per-corner texture indices (None, None when the file has no complete `f v/vt` records)."""
+    vs, fs, vts, fts = [], [], [], []
+    has_uv = True
     with open(path) as f:
         for line in f:
             t = line.split()
@@ -89,11 +91,22 @@ def load_obj_mesh(path):
                 continue
             if t[0] == 'v':
                 vs.append([float(x) for x in t[1:4]])
+            elif t[0] == 'vt':
+                vts.append([float(x) for x in t[1:3]])
             elif t[0] == 'f':
-                idx = [int(x.split('/')[0]) for x in t[1:]]
+                parts = [x.split('/') for x in t[1:]]
+                idx = [int(p[0]) for p in parts]
+                tix = [int(p[1]) if len(p) > 1 and p[1] else 0 for p in parts]
+                has_uv &= all(tix)
                 for k in range(1, len(idx) - 1):
                     fs.append([idx[0] - 1, idx[k] - 1, idx[k + 1] - 1])
-    return np.array(vs, np.float32), np.array(fs, np.int64)
+                    fts.append([tix[0] - 1, tix[k] - 1, tix[k + 1] - 1])
+    v, f = np.array(vs, np.float32), np.array(fs, np.int64)
+    if not with_uv:
+        return v, f
+    if has_uv and vts:
+        return v, f, np.array(vts, np.float32), np.array(fts, np.int64)
+    return v, f, None, None
 
 
 def savemeshtes2(pointnp_px3, tcoords_px2, facenp_fx3, facetex_fx3, fname):

@@ -46,3 +46,29 @@ def test_demo_cli_outputs(tmp_path, config, extra):
         # colours come from the cloud: the nearest atlas must correlate with the analytic colour field
         sp = np.array(PIL.Image.open(os.path.join(out, "others/0_sparse.png")))
         assert sp.shape == (256, 256, 4) and (sp[..., 3] > 0).mean() > 0.05
+
+
+def test_demo_with_supplied_mesh_obj_builds_and_caches_the_atlas(tmp_path):
+    """demo.py:391-399 hook: `<pc>_untextured_mesh.obj` next to the PLY.  The OBJ carries vt / f v/vt records, so the atlas
+    producer (8f-3) rasterises the UV atlas and caches geo/xatlas_<res>.pth in the reference's wire format; a second run loads it."""
+    import torch
+    from pointdreamer_amd import demo, synthetic, io_utils
+    pc = str(tmp_path / 'ball.ply')
+    _write_cloud(pc)
+    verts, faces, _ = synthetic.uv_sphere(24, 48)
+    uvs, fuv = synthetic.uv_sphere_uvs(24, 48, 512, gutter=2)
+    io_utils.savemeshtes2(verts, uvs, faces, fuv, str(tmp_path / 'ball_untextured_mesh.obj'))
+    args = ["--config", os.path.join(ROOT, "configs", "nearest.yaml"), "--pc_file", pc, "--set", f"output_path={tmp_path / 'out'}",
+            "xatlas_texture_res=512", "point_validation_by_o3d=False"]
+    out = demo.main(args)[0]
+    cache = os.path.join(out, "geo", "xatlas_512.pth")
+    assert os.path.exists(cache)
+    d = torch.load(cache)
+    assert set(d) == {"uvs", "mesh_tex_idx", "gb_pos", "mask", "per_atlas_pixel_face_id"}
+    assert tuple(d["gb_pos"].shape) == (1, 512, 512, 3) and tuple(d["mask"].shape) == (1, 512, 512, 1)
+    assert 0.5 < d["mask"].float().mean() < 1.0
+    a1 = np.array(PIL.Image.open(os.path.join(out, "models/model_normalized.png")))
+    assert a1.std() > 5
+    out2 = demo.main(args)[0]                                   # second run: cached dict
+    a2 = np.array(PIL.Image.open(os.path.join(out2, "models/model_normalized.png")))
+    assert np.array_equal(a1, a2)
