@@ -16,9 +16,14 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 // taps: 1 (1x1 conv / linear over pixels) or 9 (3x3, pad 1).  Cin % 32 == 0.
 // 3x3 convolution with an LDS-resident activation halo (nn_conv_halo.hip): 512-pixel x 128-channel tiles, W in {64,128,256}
 bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad);
-bool conv_uses_halo(int N, int H, int W, int Cin, int Cout_pad, int taps);   // conv_igemm's routing decision (nn_gemm.hip)
+int conv3x3_halo_splits(int N, int H, int W, int Cin, int Cout, int Cout_pad, size_t splitk_ws_floats);   // 1 direct, >1 split, 0 = do not use
+bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats);   // conv_igemm's routing (nn_gemm.hip)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
-                 int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused);
+                 int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
+                 float* splitk_ws, size_t splitk_ws_floats);
+// fixed-order sum of split-K partials [splits][M][Cout] f32 + bias (+ residual) -> f16 Y, optional GroupNorm octet partials
+int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
+                  float* gn_part, int hw, hipStream_t s);
 extern int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
 extern float* g_dbg_splitk_ws; extern size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
                                                       const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                       half_t* __restrict__ Y, int N, int H, int Cin, int Cout, int n_tiles,
                                                       int total_tiles, const half_t* __restrict__ zero_page,
-                                                      float* __restrict__ gn_part) {
+                                                      float* __restrict__ gn_part, int splits, float* __restrict__ partial) {
     constexpr int W = 1 << WLOG, BMT = 512, BNT = 128, TM = 8, ROWB = 64, NWAVES = 8;
     constexpr int RT = BMT / W, HW2 = W + 2, HP = (RT + 2) * HW2;     // tile rows, halo row length, halo pixels
     constexpr int NPA = (HP + 15) / 16, PA = (NPA + 7) / 8;           // 1 KiB halo pieces per chunk, per wave
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     constexpr int RPW = W >= 128 ? 1 : 128 / W;                       // image rows inside one wave's 128 pixels
     constexpr int FPR = TM / RPW;                                     // A fragments per such row
     constexpr int CS_LD = BNT + 8;
-    static_assert(PA <= 9 && RPW <= 2, "halo schedule: at most one halo piece per wave per tap, W >= 64");
+    static_assert(PA <= 9 && RPW <= 4, "halo schedule: at most one halo piece per wave per tap, W >= 32");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps the piece / stage arithmetic on the scalar unit
@@ -55,7 +55,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     const int m0 = (tile / n_tiles) * BMT, n0 = (tile % n_tiles) * BNT;
     const int HWp = H << WLOG;
     const int img = m0 / HWp, ty0 = (m0 - img * HWp) >> WLOG;
-    const int K = 9 * Cin, NC = Cin >> 5;
+    const int K = 9 * Cin;
+    // split over the channel chunks (small-M layers): blockIdx.y owns chunks [cb, cb + NC) and writes an f32 partial tile
+    const int NCT = Cin >> 5;
+    const int cb = (int)((long long)NCT * blockIdx.y / splits), NC = (int)((long long)NCT * (blockIdx.y + 1) / splits) - cb;
 
     // ---- loader role.  Halo piece slot t of this wave = piece min(8 t + wave, NPA - 1) (the tail slots of the last waves
     // re-load the last piece: every wave issues the same number of LDS-DMA instructions, which keeps the vmcnt counts static).
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         return ok ? (const void*)(X + off) : (const void*)zero_page;
     };
     const int brow = wave * 16 + (lane >> 2);
-    const half_t* bp = Wt + (size_t)(n0 + brow) * K + (((lane & 3) ^ swz_b(brow)) << 3);   // next weight slice to stage
+    const half_t* bp = Wt + (size_t)(n0 + brow) * K + cb * 32 + (((lane & 3) ^ swz_b(brow)) << 3);   // next weight slice to stage
     char* const ah_dst = smem;                                        // + buf * AH_BYTES + piece * 1024
     char* const b_dst = smem + 2 * AH_BYTES + wave * 1024;            // + stage * B_BYTES
 
@@ -98,13 +101,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
 
     // ---- prologue: halo of chunk 0, weight slices 0 and 1
 #pragma unroll
-    for (int t = 0; t < PA; ++t) glds16h(halo_src(t, 0), ah_dst + min(t * 8 + wave, NPA - 1) * 1024);
+    for (int t = 0; t < PA; ++t) glds16h(halo_src(t, cb), ah_dst + min(t * 8 + wave, NPA - 1) * 1024);
     glds16h(bp, b_dst);
     bp += Cin;
     glds16h(bp, b_dst + B_BYTES);
     bp += Cin;
     if (PA == 9) {                                                    // keeps the issue order of the steady state (see HL_VMN)
-        glds16h(halo_src(PA - 1, 0), ah_dst + min((PA - 1) * 8 + wave, NPA - 1) * 1024);
+        glds16h(halo_src(PA - 1, cb), ah_dst + min((PA - 1) * 8 + wave, NPA - 1) * 1024);
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         const int hpv = hp0;
         const uint32_t a0 = HL_AADDR(0, -HW2 - 1, 0);
         HL_DSR(bf[0][0], b_frag, 0); HL_DSR(bf[0][1], b_frag, 16 * ROWB); HL_DSR(bf[0][2], b_frag, 32 * ROWB); HL_DSR(bf[0][3], b_frag, 48 * ROWB);
-        HL_DSR(ar[0], a0, 0); HL_DSR(ar[1], a0, 1024); HL_DSR(ar[2], a0, 2048);
+        HL_DSR(ar[0], a0, 0); HL_DSR(ar[1], a0, 1024);
+        if constexpr (FPR > 2) { HL_DSR(ar[2], a0, 2048); } else { const uint32_t a1 = HL_AADDR(0, -HW2 - 1, 1); HL_DSR(ar[2], a1, 0); }
     }
 
     int bs = 0;                                                       // weight stage of the current step (s mod 3)
@@ -124,12 +128,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         // piece T of chunk c+1 after group 1.  Hand-over in front of group 5: counted vmcnt (weight slice s+1 landed -- issued
         // after it: the previous step's halo piece, this step's weight and halo pieces), drain of my LDS reads, barrier.
 #define HL_VMN(T) (1 + ((T) < PA ? 1 : 0) + ((((T) + 8) % 9) < PA ? 1 : 0))
-#define HL_RDA(slot, base0, base1, i)                                                                                 \
-    { if constexpr ((i) < FPR) HL_DSR(ar[slot], base0, (i) * 1024); else HL_DSR(ar[slot], base1, ((i) - FPR) * 1024); }
 #define HL_GROUP(P, T, g)                                                                                              \
     {                                                                                                                 \
-        if constexpr (RPW == 2 && (g) >= 1 && (g) <= 4) a_ad1 = HL_AADDR(ab, (T / 3 - 1) * HW2 + (T % 3 - 1), 1);     \
-        if constexpr ((g) + 3 < TM) HL_RDA(((g) + 3) & 3, a_ad0, a_ad1, (g) + 3)                                       \
+        if constexpr ((g) + 3 < TM) {                                 /* A fragment g+3: row (g+3)/FPR of the wave's pixels */ \
+            if constexpr (RPW > 1 && ((g) == 0 || ((g) + 3) % FPR == 0 || RPW == 2))                                  \
+                a_cur = HL_AADDR(ab, (T / 3 - 1) * HW2 + (T % 3 - 1), ((g) + 3) / FPR);                               \
+            HL_DSR(ar[((g) + 3) & 3], a_cur, (((g) + 3) % FPR) * 1024);                                               \
+        }                                                                                                             \
         if constexpr ((g) == 5) {                                                                                     \
             if (more) {                                                                                               \
                 asm volatile("s_waitcnt vmcnt(%3) lgkmcnt(0)" : "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]) : "n"(HL_VMN(T)) : "memory"); \
@@ -146,7 +151,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         } else if constexpr ((g) == 6) {                                                                              \
             if (more) HL_DSR(ar[1], a_nx0, 1024);                                                                     \
         } else if constexpr ((g) == 7) {                                                                              \
-            if (more) HL_DSR(ar[2], a_nx0, 2048);                                                                     \
+            if (more) {                                                                                               \
+                if constexpr (FPR == 2) a_nx0 = HL_AADDR(abn, dyn_ * HW2 + dxn_, 1);                                  \
+                HL_DSR(ar[2], a_nx0, (2 % FPR) * 1024);                                                               \
+            }                                                                                                         \
         } else {                                                                                                      \
             asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ar[(g) & 3]));                                                 \
             if constexpr ((g) == 0) asm volatile("" : "+v"(bf[bc][0]), "+v"(bf[bc][1]), "+v"(bf[bc][2]), "+v"(bf[bc][3])); \
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
             } else glds16h(zero_page, b_dst + st2 * B_BYTES);         /* past the end: harmless load, static counts */   \
         }                                                                                                             \
         if constexpr ((g) == 1 && (T) < PA) {                         /* halo piece T of chunk c + 1 */                 \
-            glds16h(halo_src(T, min(c + 1, NC - 1)), ah_dst + (ab ^ 1) * AH_BYTES + min((T) * 8 + wave, NPA - 1) * 1024); \
+            glds16h(halo_src(T, cb + min(c + 1, NC - 1)), ah_dst + (ab ^ 1) * AH_BYTES + min((T) * 8 + wave, NPA - 1) * 1024); \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
@@ -174,8 +182,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         const bool more = s + 1 < S;                                                                                  \
         int hpv = hp0;                                                                                                \
         asm volatile("" : "+v"(hpv));                                 /* keeps the per-tap addresses out of loop-invariant registers */ \
-        const uint32_t a_ad0 = HL_AADDR(ab, dy_ * HW2 + dx_, 0);                                                      \
-        uint32_t a_ad1 = a_ad0;                                       /* W = 64: second image row, computed after group 0 */ \
+        uint32_t a_cur = HL_AADDR(ab, dy_ * HW2 + dx_, 0);            /* row base of the fragment being read; later rows are computed at first use */ \
         const int abn = (T) == 8 ? (ab ^ 1) : ab;                                                                     \
         uint32_t a_nx0 = 0;                                           /* computed at the hand-over (short live range) */ \
         HL_GROUP(P, T, 0) HL_GROUP(P, T, 1) HL_GROUP(P, T, 2) HL_GROUP(P, T, 3)                                        \
@@ -188,7 +195,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
 #undef HL_CHUNK
 #undef HL_STEP
 #undef HL_GROUP
-#undef HL_RDA
 #undef HL_VMN
     }
 #undef HL_AADDR
@@ -196,6 +202,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the harmless tail re-loads must land before the LDS is reused
     __syncthreads();
 
+    if (partial != nullptr) {                              // split over chunks: raw f32 partial tile, reduced by splitk_reduce()
+        const long long M = (long long)N * HWp;
+        float* P = partial + (size_t)blockIdx.y * (size_t)M * Cout;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const long long m = (long long)m0 + wm * TM * 16 + i * 16 + (lane & 15);
+                if (n < Cout) *reinterpret_cast<float4_t*>(P + (size_t)m * Cout + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     // ---- epilogue (as k_conv_igemm: transposed accumulator tile -> f16 -> LDS -> coalesced rows, residual, GN partials)
     half_t* Cs = reinterpret_cast<half_t*>(smem);
 #pragma unroll
@@ -252,35 +272,62 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
 
 template <int WLOG>
 int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
-                int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part) {
+                int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int splits, float* partial) {
     constexpr int W = 1 << WLOG, RT = 512 / W, HP = (RT + 2) * (W + 2), NPA = (HP + 15) / 16;
     const size_t smem = std::max<size_t>((size_t)2 * NPA * 1024 + 3 * 8192, (size_t)512 * (128 + 8) * 2);
     auto kern = k_conv3x3_halo<WLOG>;
     PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int n_tiles = Cout_pad / 128;
     const int total = (int)(((long long)N * H * W) / 512) * n_tiles;
-    kern<<<total, 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part);
+    kern<<<dim3(total, splits), 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part, splits, partial);
     return PDHIP_OK;
 }
 
 }  // namespace
 
 bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad) {
-    return (W == 64 || W == 128 || W == 256) && ((long long)H * W) % 512 == 0 && Cin % 32 == 0 && Cout_pad % 128 == 0 &&
+    return (W == 32 || W == 64 || W == 128 || W == 256) && ((long long)H * W) % 512 == 0 && Cin % 32 == 0 && Cout_pad % 128 == 0 &&
            (long long)N * H * W * Cin <= 0x7fffffffLL;
 }
 
-// gn_part (optional): fused GroupNorm octet partials, chunks = H*W / 512 per image (returned through gn_fused)
+// split factor over the 32-channel chunks when the tile count alone would leave CUs idle (0 = this layer should not use the
+// halo kernel at all: too few tiles even with the largest useful split)
+int conv3x3_halo_splits(int N, int H, int W, int Cin, int Cout, int Cout_pad, size_t splitk_ws_floats) {
+    const long long M = (long long)N * H * W;
+    const long long tiles = (M / 512) * (Cout_pad / 128);
+    if (tiles >= 256) return 1;
+    const int nct = Cin / 32;
+    int splits = (int)std::min<long long>(std::min<long long>(256 / tiles, nct / 2), 8);
+    while (splits > 1 && (size_t)splits * (size_t)M * Cout > splitk_ws_floats) --splits;
+    if (splits < 2 || tiles * splits < 128) return 0;
+    return splits;
+}
+
+// gn_part (optional): fused GroupNorm octet partials; chunks per image returned through gn_fused (H*W/512 from the direct
+// epilogue, H*W/16 from the split reduce)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
-                 int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused) {
+                 int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
+                 float* splitk_ws, size_t splitk_ws_floats) {
     PD_REQUIRE(conv3x3_halo_eligible(N, H, W, Cin, Cout_pad), "conv3x3_halo: unsupported geometry (N=%d H=%d W=%d Cin=%d)", N, H, W, Cin);
-    if (gn_fused) *gn_fused = gn_part ? (int)(((long long)H * W) / 512) : 0;
+    int splits = conv3x3_halo_splits(N, H, W, Cin, Cout, Cout_pad, splitk_ws ? splitk_ws_floats : 0);
+    if (splits < 1) splits = 1;
+    if (g_force_splits >= 1 && splitk_ws != nullptr)            // tuning / test hook
+        splits = (int)std::min<size_t>(std::min(g_force_splits, Cin / 32), splitk_ws_floats / ((size_t)N * H * W * Cout));
+    if (splits < 1) splits = 1;
+    float* partial = splits > 1 ? splitk_ws : nullptr;
+    const bool fuse_sk = splits > 1 && gn_part != nullptr && (H * W) % 16 == 0;
+    if (gn_fused) *gn_fused = gn_part ? (splits > 1 ? (fuse_sk ? (H * W) / 16 : 0) : (int)(((long long)H * W) / 512)) : 0;
+    float* gnp = splits > 1 ? nullptr : gn_part;
+#define HL_LAUNCH(WL) launch_halo<WL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial)
     int rc;
-    if (W == 256) rc = launch_halo<8>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part);
-    else if (W == 128) rc = launch_halo<7>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part);
-    else rc = launch_halo<6>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part);
+    if (W == 256) rc = HL_LAUNCH(8);
+    else if (W == 128) rc = HL_LAUNCH(7);
+    else if (W == 64) rc = HL_LAUNCH(6);
+    else rc = HL_LAUNCH(5);
+#undef HL_LAUNCH
     if (rc) return rc;
     PD_LAUNCH_CHECK();
+    if (splits > 1) return splitk_reduce(partial, splits, (long long)N * H * W, Cout, bias, residual, Y, fuse_sk ? gn_part : nullptr, H * W, s);
     return PDHIP_OK;
 }
 

@@ -549,10 +549,21 @@ static int launch_conv(dim3 grid, size_t smem, hipStream_t s, const half_t* X, c
 
 // does conv_igemm route this layer to the halo-resident kernel? (tuning hook: tile geometry 32 forces it, any other forced
 // geometry / K-step / stage count disables it)
-bool conv_uses_halo(int N, int H, int W, int Cin, int Cout_pad, int taps) {
+bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats) {
     if (taps != 9 || !conv3x3_halo_eligible(N, H, W, Cin, Cout_pad)) return false;
     if (g_force_wmw == 32) return true;
-    return g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && ((long long)N * H * W / 512) * (Cout_pad / 128) >= 256;
+    // automatic use only when the tiles alone fill the chip: with the chunk split (small-M layers) the halo kernel measures
+    // no better than the 128x128 split-K path (tools/bench_splitk.py: 54 vs 51 us at 32x32 / 512 -> 512)
+    return g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0 &&
+           conv3x3_halo_splits(N, H, W, Cin, Cout, Cout_pad, 0) == 1;
+}
+
+int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
+                  float* gn_part, int hw, hipStream_t s) {
+    dim3 gr((unsigned)((M + SK_ROWS - 1) / SK_ROWS), (unsigned)(((Cout >> 3) + 63) / 64));
+    k_splitk_reduce<<<gr, 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y, gn_part, hw);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
 }
 
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
@@ -567,8 +578,9 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const long long M = (long long)N * H * W;
     // large-image 3x3 layers: halo-resident kernel (2.1x less L2 -> LDS traffic per flop) once it fills the chip
     // (tuning hook: tile geometry 32 forces it, any other forced geometry disables it)
-    if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout_pad, taps))
-        return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused);
+    if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0))
+        return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused, splitk_ws,
+                            splitk_ws_floats);
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
     // tile geometry: 256x256 (wave tile 128x64: 25 % fewer LDS reads per MFMA, half the L2 traffic) once it still yields
     // at least one workgroup per CU; 128x128 otherwise
@@ -625,8 +637,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
 #undef ARGS
     if (rc) return rc;
     if (splits > 1) {
-        dim3 gr((unsigned)((M + SK_ROWS - 1) / SK_ROWS), (unsigned)(((Cout >> 3) + 63) / 64));
-        k_splitk_reduce<<<gr, 256, 0, s>>>(partial, splits, M, Cout, bias, residual, Y, fuse_sk ? gn_part : nullptr, H * W);
+        return splitk_reduce(partial, splits, M, Cout, bias, residual, Y, fuse_sk ? gn_part : nullptr, H * W, s);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

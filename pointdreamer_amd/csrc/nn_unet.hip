@@ -163,7 +163,8 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
     // profile hook (bench.py roofline): the dominant kernel only -- the halo-resident 3x3 conv
-    const bool prof = x.p2 == nullptr && conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout_pad, w.taps);
+    const bool prof = x.p2 == nullptr && conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats) &&
+                      conv3x3_halo_splits(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, c.u->splitk_floats) == 1;
     if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
     int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,

@@ -278,14 +278,18 @@ def test_philox_normal_stream(nn):
     assert abs((a ** 4).mean().item() - 3.0) < 0.1
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,res", [(2, 8, 64, 64, 128, False), (1, 16, 64, 96, 192, True), (1, 4, 128, 32, 128, False),
-                                              (2, 8, 128, 64, 256, True), (1, 2, 256, 64, 128, False), (1, 6, 256, 32, 256, True),
-                                              (1, 8, 256, 160, 128, False)])
-def test_conv3x3_halo_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, res):
-    """The halo-resident 3x3 kernel (nn_conv_halo.hip; W = 64 / 128 / 256, 512-pixel tiles): image borders, tile borders
-    inside an image, several images, odd / single channel-chunk counts, residual."""
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res,splits", [
+    (2, 8, 64, 64, 128, False, 0), (1, 16, 64, 96, 192, True, 0), (1, 4, 128, 32, 128, False, 0), (2, 8, 128, 64, 256, True, 0),
+    (1, 2, 256, 64, 128, False, 0), (1, 6, 256, 32, 256, True, 0), (1, 8, 256, 160, 128, False, 0),
+    (2, 32, 32, 96, 128, True, 0), (1, 16, 32, 64, 256, False, 2), (2, 32, 32, 160, 128, True, 3), (1, 16, 64, 128, 128, True, 4)])
+def test_conv3x3_halo_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, res, splits):
+    """The halo-resident 3x3 kernel (nn_conv_halo.hip; W = 32 / 64 / 128 / 256, 512-pixel tiles): image borders, tile borders
+    inside an image, several images, odd / single channel-chunk counts, residual, and the split over channel chunks (f32
+    partials + fixed-order reduce) used by small-M layers."""
     L = nn['L']
     old = L.pdhip_debug_set_conv_tile(32)
+    ws = torch.empty((max(splits, 1) * N * H * W * Cout,), device=DEV)
+    L.pdhip_debug_set_conv_splitk(_ptr(ws), ws.numel(), splits)
     try:
         g = torch.Generator().manual_seed(N * 1000 + H * W + Cin + Cout)
         x = torch.randn((N, Cin, H, W), generator=g).half().float()
@@ -299,6 +303,7 @@ def test_conv3x3_halo_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, res):
         assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
     finally:
         L.pdhip_debug_set_conv_tile(old)
+        L.pdhip_debug_set_conv_splitk(None, 0, 0)
 
 
 @pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4),

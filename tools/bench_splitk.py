@@ -22,7 +22,7 @@ for (N, H, W, Cin, Cout, taps) in SHAPES:
     y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev)
     fl = 2.0 * N * H * W * Cout * taps * Cin
     print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} taps{taps} ({fl/1e9:6.1f} GFLOP)")
-    for geo in (2, 8):
+    for geo in (2, 8, 32):
         row = []
         for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
             L.pdhip_debug_set_conv_tile(geo); L.pdhip_debug_set_conv_splitk(P(ws), ws.numel(), sp)
