@@ -64,8 +64,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     // re-load the last piece: every wave issues the same number of LDS-DMA instructions, which keeps the vmcnt counts static).
     // The source address of a piece is recomputed when it is issued (~20 VALU ops behind 32 MFMAs) rather than kept in 9
     // registers: the kernel sits at the 256-VGPR limit of two waves per SIMD.
+    // Byte offset of this lane's 16 bytes of halo piece slot t at chunk 0 (~0u = zero page: outside the image / past the halo).
+    // Slots < PA_TAB keep it in a register (4 VALU ops to form the source pointer), the rest recompute it when issued (~20):
+    // the kernel sits at the 256-VGPR limit of two waves per SIMD, and VALU work next to the MFMAs is not free here either.
+    constexpr int PA_TAB = PA > 6 ? 6 : PA;
     const int cq = lane & 3;
-    auto halo_src = [&](int t, int chunk) -> const void* {
+    auto halo_off = [&](int t) -> uint32_t {
         const int pi = min(t * 8 + wave, NPA - 1);
         int lq = lane >> 2;
         asm volatile("" : "+v"(lq));                                  // recompute here, every time (no loop-invariant hoisting)
@@ -73,8 +77,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         const int hy = hp / HW2, hx = hp - hy * HW2;
         const int y = ty0 - 1 + hy, x = hx - 1;
         const bool ok = (hp < HP) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
-        const int off = ((((img * H + y) << WLOG) + x) * Cin) + chunk * 32 + ((cq ^ swz_a(hp)) << 3);   // < 2^31 (host check)
-        return ok ? (const void*)(X + off) : (const void*)zero_page;
+        return ok ? (uint32_t)((((((img * H + y) << WLOG) + x) * Cin) + ((cq ^ swz_a(hp)) << 3)) * 2) : ~0u;   // < 2^32 (host check)
+    };
+    uint32_t aoff[PA_TAB];
+#pragma unroll
+    for (int t = 0; t < PA_TAB; ++t) aoff[t] = halo_off(t);
+    const char* const Xb = reinterpret_cast<const char*>(X);
+    auto halo_src = [&](int t, int chunk) -> const void* {
+        const uint32_t off = t < PA_TAB ? aoff[t < PA_TAB ? t : 0] : halo_off(t);
+        return off == ~0u ? (const void*)zero_page : (const void*)(Xb + off + (uint32_t)chunk * 64u);
     };
     const int brow = wave * 16 + (lane >> 2);
     const half_t* bp = Wt + (size_t)(n0 + brow) * K + cb * 32 + (((lane & 3) ^ swz_b(brow)) << 3);   // next weight slice to stage
@@ -287,7 +298,7 @@ int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half
 
 bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad) {
     return (W == 32 || W == 64 || W == 128 || W == 256) && ((long long)H * W) % 512 == 0 && Cin % 32 == 0 && Cout_pad % 128 == 0 &&
-           (long long)N * H * W * Cin <= 0x7fffffffLL;
+           (long long)N * H * W * Cin * 2 <= 0xfffffff0LL;
 }
 
 // split factor over the 32-channel chunks when the tile count alone would leave CUs idle (0 = this layer should not use the
