@@ -132,6 +132,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     }
 
     int bs = 0;                                                       // weight stage of the current step (s mod 3)
+    uint32_t a_carry;                                                 // row-0 fragment base of the step about to start
+    { const int hpv = hp0; a_carry = HL_AADDR(0, -HW2 - 1, 0); }
     const int S = 9 * NC;
     for (int c0 = 0; c0 < NC; c0 += 2) {                              // two chunks per trip: buffer / register-set parities static
         // One step = (chunk c, tap T): 8 groups of 4 MFMAs.  Reads: A fragment g+3 at group g (ring of 4), the next step's
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
                 asm volatile("" ::: "memory");                                                                        \
                 const uint32_t b_nx = b_frag + (bs == 2 ? 0 : bs + 1) * B_BYTES;                                      \
                 a_nx0 = HL_AADDR(abn, dyn_ * HW2 + dxn_, 0);                                                          \
+                a_carry = a_nx0;                                                                                      \
                 HL_DSR(bf[bn][0], b_nx, 0); HL_DSR(bf[bn][1], b_nx, 16 * ROWB);                                       \
                 HL_DSR(bf[bn][2], b_nx, 32 * ROWB); HL_DSR(bf[bn][3], b_nx, 48 * ROWB);                               \
                 HL_DSR(ar[0], a_nx0, 0);                                                                              \
@@ -186,14 +189,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     }
 #define HL_STEP(P, T)                                                                                                 \
     {                                                                                                                 \
-        constexpr int dy_ = (T) / 3 - 1, dx_ = (T) % 3 - 1, tn_ = ((T) + 1) % 9;                                      \
+        constexpr int tn_ = ((T) + 1) % 9;                                                                            \
         constexpr int dyn_ = tn_ / 3 - 1, dxn_ = tn_ % 3 - 1;                                                         \
         constexpr int ab = (P), bc = ((P) + (T)) & 1, bn = bc ^ 1;    /* halo buffer; fragment register set of this / next step */ \
         const int s = c * 9 + (T);                                                                                    \
         const bool more = s + 1 < S;                                                                                  \
         int hpv = hp0;                                                                                                \
         asm volatile("" : "+v"(hpv));                                 /* keeps the per-tap addresses out of loop-invariant registers */ \
-        uint32_t a_cur = HL_AADDR(ab, dy_ * HW2 + dx_, 0);            /* row base of the fragment being read; later rows are computed at first use */ \
+        uint32_t a_cur = a_carry;                                     /* row-0 base of this tap (formed at the previous hand-over); later rows at first use */ \
         const int abn = (T) == 8 ? (ab ^ 1) : ab;                                                                     \
         uint32_t a_nx0 = 0;                                           /* computed at the hand-over (short live range) */ \
         HL_GROUP(P, T, 0) HL_GROUP(P, T, 1) HL_GROUP(P, T, 2) HL_GROUP(P, T, 3)                                        \
