@@ -73,6 +73,9 @@ def main():
     ap.add_argument('--parallel', default='shapes', choices=['shapes', 'views'])
     ap.add_argument('--ddnm-steps', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shapes-per-step', type=int, default=1,
+                    help='independent shapes textured per step on each GPU, their views batched through the UNet together '
+                         '(BASELINE configs[4] style; default 1 = configs[2])')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -101,7 +104,8 @@ def main():
     camera_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
     xatlas = dict(gb_pos=g['gb_pos'], mask=g['mask'], per_atlas_pixel_face_id=g['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
     inpainter = None
-    views_here = V if args.parallel == 'shapes' else len(pdist.shard_range(V, rank, world))
+    SPS = max(1, args.shapes_per_step) if args.parallel == 'shapes' else 1
+    views_here = V * SPS if args.parallel == 'shapes' else len(pdist.shard_range(V, rank, world))
     if args.workload == 'ddnm':
         inpainter = di.Inpainter(dev, ckpt_path=None, allow_random_weights=True, max_batch=views_here)
         inpainter.n_steps = args.ddnm_steps
@@ -110,7 +114,18 @@ def main():
                edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None,
                edge_dilate_kernels=[21], complete_unseen_by='unproject', inpainter=inpainter)
 
+    extra = []
+    for k in range(1, SPS):                      # further independent shapes of this rank (same mesh / atlas, different clouds)
+        sk = synthetic.make_shape(30000, A, seed=1000 * k + rank)
+        extra.append(dict(coords=T(sk['points']), colors=T(sk['colors'])))
+    batch = [dict(coords=g['points'], colors=g['colors'], vertices=g['vertices'], faces=g['faces'], f_normals=g['f_normals'], xatlas=xatlas)]
+    batch += [dict(coords=e['coords'], colors=e['colors'], vertices=g['vertices'], faces=g['faces'], f_normals=g['f_normals'], xatlas=xatlas)
+              for e in extra]
+
     def step():
+        if SPS > 1:
+            return pipeline.colorize_meshes_batched(batch, camera_info, **{k: v for k, v in cfg.items()
+                                                                          if k not in ('optimize_from', 'complete_unseen_by')})
         if args.parallel == 'views' and world > 1:
             return pdist.colorize_one_mesh_view_parallel(g['points'], g['colors'], g['vertices'], g['faces'], g['f_normals'],
                                                          xatlas, camera_info, rank=rank, world=world, **cfg)
@@ -136,7 +151,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    shapes = args.steps * (world if args.parallel == 'shapes' else 1)
+    shapes = args.steps * (world * SPS if args.parallel == 'shapes' else 1)
     value = shapes / dt * 3600.0
 
     roofline = None
@@ -163,9 +178,9 @@ def main():
                    dtype="f16 (f32 accumulate; f32 GroupNorm/softmax statistics, f32 geometry)", data="synthetic",
                    config=dict(workload=f"configs[2]: synthetic 30k-point sphere shape, 8x256^2 views, texture_gen_method="
                                         f"'{method}' ({args.ddnm_steps} DDNM steps, 552.8M-param guided-diffusion UNet, random-init weights), "
-                                        f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, hidden-point removal on (device)",
+                                        f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, hidden-point removal on (device)" + (f"; {SPS} independent shapes per step, their views batched through the UNet together" if SPS > 1 else ""),
                                parallelism=f"{args.parallel}-parallel x{world}", views_per_unet_batch=views_here,
-                               shapes_per_step=world if args.parallel == 'shapes' else 1),
+                               shapes_per_step=world * SPS if args.parallel == 'shapes' else 1),
                    roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -76,3 +76,30 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
                     view_ids=view_ids, painted=painted, shrinked=shrinked, visibility=vis,
                     point_validation=point_validation, scale_factors=scale_factors, mesh_depths=mesh_depths)
     return vertices, xatlas_dict.get('uvs'), faces, xatlas_dict.get('mesh_tex_idx'), atlas, mask
+
+
+def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpainter=None, texture_gen_method='DDNM_inpaint',
+                            point_size=1, edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82,
+                            edge_dilate_kernels=(21,), point_validation_by_o3d=True, hidden_point_removal_radius=100, **unused):
+    """Several independent shapes in one pass (BASELINE configs[4]: a batch of shapes per GPU): the projection / sparse-image
+    stage runs per shape, the views of ALL shapes go through the inpainter together (one UNet batch of len(shapes) * V views --
+    the 8x8 .. 32x32 levels of the UNet fill the chip better), the unprojection runs per shape.
+    `shapes`: list of dicts with coords, colors, vertices, faces, f_normals, xatlas (gb_pos, mask, per_atlas_pixel_face_id).
+    Same stages and results as colorize_one_mesh(complete_unseen_by='unproject', optimize_from=None); returns the atlases."""
+    from .dist import _project_stage
+    with torch.no_grad():
+        prs = [_project_stage(sh['coords'], sh['colors'], sh['vertices'], sh['faces'], camera_info, view_num, res, cam_res, point_size,
+                              edge_point_size, crop_img, crop_padding, mask_ratio_thresh, point_validation_by_o3d,
+                              hidden_point_removal_radius) for sh in shapes]
+        cat = lambda k: torch.cat([pr[k] for pr in prs], 0).contiguous()
+        inpainted = ou.get_inpainted_images(cat('sparse'), cat('mask0'), cat('mask2'), None, inpainter, view_num * len(shapes),
+                                            method=texture_gen_method)
+        atlases = []
+        for i, (sh, pr) in enumerate(zip(shapes, prs)):
+            xat = sh['xatlas']
+            atlas, _, _, _, _ = up.unproject_dense(
+                inpainted[i * view_num:(i + 1) * view_num].contiguous(), sh['f_normals'], res, camera_info['cams'], cam_res,
+                camera_info['base_dirs'], xat['gb_pos'], xat['mask'], xat['per_atlas_pixel_face_id'], pr['uv_centers'],
+                pr['uv_scales'], pr['padding'], pr['scale_factors'], pr['mesh_depths'], list(edge_dilate_kernels), True)
+            atlases.append(up.dilate_atlas(atlas, xat['mask']))
+    return atlases

@@ -457,3 +457,26 @@ def test_8f4_device_u8_conversion_and_native_png(tmp_path):
     p = str(tmp_path / 'g.png')
     io_utils.save_CHW_RGBA_img(T(img), p)
     assert np.array_equal(np.array(PIL.Image.open(p)), (img.transpose(1, 2, 0) * 255).clip(0, 255).astype(np.uint8))
+
+
+def test_batched_shapes_equal_one_by_one(pd):
+    """colorize_meshes_batched (BASELINE configs[4]: several shapes per pass, views batched through the inpainter together) gives
+    exactly the atlases of colorize_one_mesh shape by shape ('nearest' inpainting: deterministic)."""
+    from pointdreamer_amd import pipeline
+    syn = pd['syn']
+    stacks, slices, A, V, R, r = 16, 32, 256, 4, 256, 128
+    verts, faces, lut = syn.uv_sphere(stacks, slices)
+    gb_pos, mask, fid = syn.latlong_atlas(A, stacks, slices, gutter=2, lut=lut)
+    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(V, 1.6, R, device=DEV)
+    xat = dict(gb_pos=T(gb_pos), mask=T(mask), per_atlas_pixel_face_id=T(fid), uvs=None, mesh_tex_idx=None)
+    cam_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    fn = T(syn.face_normals(verts, faces))
+    kw = dict(view_num=V, res=r, cam_res=R, point_validation_by_o3d=True, texture_gen_method='nearest', point_size=1,
+              edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, edge_dilate_kernels=[21])
+    clouds = [syn.sphere_points(3000, seed=s) for s in (1, 2, 3)]
+    shapes = [dict(coords=T(x), colors=T(c), vertices=T(verts), faces=T(faces), f_normals=fn, xatlas=xat) for x, c in clouds]
+    got = pipeline.colorize_meshes_batched(shapes, cam_info, **kw)
+    for (x, c), atlas in zip(clouds, got):
+        one = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, complete_unseen_by='unproject',
+                                         optimize_from=None, return_intermediates=True, **kw)
+        assert np.array_equal(N_(atlas), N_(one['atlas']))

@@ -2,6 +2,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/final_tests.log
 python bench.py 2> gpurun_out/final_bench.err | tail -1 > gpurun_out/final_bench.json
+python bench.py --shapes-per-step 2 --no-cpu-baseline 2> gpurun_out/final_bench2.err | tail -1 > gpurun_out/final_bench_2shapes.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_final
 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_final -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --ddnm-steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_final.log 2>&1
