@@ -50,6 +50,9 @@ struct pdhip_unet {
     char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
     float *stats = nullptr, *gn_ws = nullptr; size_t gn_ws_floats = 0;
     float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr;
+    // DDNM sampler: the embeddings of all (<= 100) schedule steps, computed in ONE pass over the 180 MB of emb_layers weights
+    // and kept until the weights change (every image of a sampling step shares t, so the per-step forward reads one row)
+    float *steps_t = nullptr, *steps_silu = nullptr, *steps_tmp = nullptr, *steps_emb = nullptr; int steps_cached = 0;
     half_t* head_wz = nullptr;                   // output-head weights as f16 hi/lo pairs (nn_head.hip)
     float *t_dev = nullptr;
     float* splitk_ws = nullptr; size_t splitk_floats = 0;
@@ -135,7 +138,7 @@ half_t* arena_take(pdhip_unet* u, size_t halfs) {
     return p;
 }
 
-struct Ctx { pdhip_unet* u; int N; hipStream_t s; bool dry; };
+struct Ctx { pdhip_unet* u; int N; hipStream_t s; bool dry; const float* film_base; long long film_stride; };
 
 int prof_begin(Ctx& c, double flops) {
     Prof& p = c.u->prof;
@@ -202,9 +205,9 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
         if (!c.dry) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
     }
     PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
-    const float* film = c.dry ? nullptr : c.u->emb_all + rb.emb_off;
+    const float* film = c.dry ? nullptr : c.film_base + rb.emb_off;
     if (!c.dry) PD_REQUIRE(rb.have_ew && rb.have_eb, "unet: emb_layers of %s not loaded", rb.name.c_str());
-    PD_TRY(run_gn(c, h1, rb.n2, film, c.u->emb_rows, 1, 0, &h2));
+    PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
     sk = xr;
     if (rb.has_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
     return run_conv(c, h2, rb.c2, sk.p, out, true);
@@ -246,10 +249,12 @@ int run_blocks(Ctx& c, std::vector<Block>& blocks, Act* h, const float* x_nchw) 
 }
 
 // the whole forward; dry = sizing pass (no launches)
-int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* out, hipStream_t s, bool dry) {
-    Ctx c{u, N, s, dry};
+// shared_emb: one precomputed row of ResBlock embeddings [emb_rows] used by every image (t is then ignored), or nullptr
+int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* out, hipStream_t s, bool dry,
+                 const float* shared_emb = nullptr) {
+    Ctx c{u, N, s, dry, shared_emb ? shared_emb : u->emb_all, shared_emb ? 0 : u->emb_rows};
     u->arena_off = 0;
-    if (!dry) {
+    if (!dry && shared_emb == nullptr) {
         PD_REQUIRE(u->have_te[0] && u->have_te[1] && u->have_te[2] && u->have_te[3], "unet: time_embed not loaded");
         PD_TRY(timestep_mlp(t, N, u->mc, u->te_w0, u->te_b0, u->te_w2, u->te_b2, u->emb_silu, u->emb_tmp, s));
         PD_TRY(gemv_rows(u->emb_w, u->emb_b, u->emb_silu, u->emb_all, (int)u->emb_rows, u->ted, N, s));
@@ -408,6 +413,8 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     chk(dalloc(u, &u->stats, (size_t)max_batch * 64)); chk(dalloc(u, &u->gn_ws, u->gn_ws_floats));
     chk(dalloc(u, &u->emb_silu, (size_t)max_batch * u->ted)); chk(dalloc(u, &u->emb_tmp, (size_t)max_batch * (u->mc + u->ted)));
     chk(dalloc(u, &u->emb_all, (size_t)max_batch * emb_rows));
+    chk(dalloc(u, &u->steps_t, 128)); chk(dalloc(u, &u->steps_silu, (size_t)100 * u->ted));
+    chk(dalloc(u, &u->steps_tmp, (size_t)100 * (u->mc + u->ted))); chk(dalloc(u, &u->steps_emb, (size_t)100 * emb_rows));
     { float* wz = nullptr; chk(dalloc(u, &wz, (size_t)64 * u->final_ch)); u->head_wz = reinterpret_cast<half_t*>(wz); }
     chk(dalloc(u, &u->t_dev, (size_t)max_batch));
     u->splitk_floats = (size_t)16 * 384 * 128 * 128;               // 16 splits x (< 384 tiles of 128x128) f32
@@ -468,6 +475,7 @@ extern "C" int pdhip_unet_num_tensors(const pdhip_unet* u) {
 extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const void* data, int is_f16, const int64_t* shape,
                                       int ndim, void* stream) {
     PD_REQUIRE(u && name_c && data && shape && ndim >= 1 && ndim <= 4, "pdhip_unet_load_tensor: bad arguments");
+    u->steps_cached = 0;                         // any weight change invalidates the sampler's per-step embedding table
     hipStream_t s = as_stream(stream);
     const std::string name(name_c);
     long long numel = 1;
@@ -646,9 +654,18 @@ extern "C" int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const 
     PD_TRY(ddnm_prepare(masked_imgs, masks, u->sy, N, HW, s));
     if (x_T) PD_HIP(hipMemcpyAsync(u->sx, x_T, n3 * sizeof(float), hipMemcpyDeviceToDevice, s));
     else PD_TRY(philox_normal(u->sx, n3, seed, 0, s));
+    if (u->steps_cached != n_steps) {            // embeddings of every schedule step, one pass over the emb_layers weights
+        PD_REQUIRE(u->have_te[0] && u->have_te[1] && u->have_te[2] && u->have_te[3], "unet: time_embed not loaded");
+        float th[100];
+        for (int k = 0; k < n_steps; ++k) th[k] = (float)sched.t[k];
+        PD_HIP(hipMemcpyAsync(u->steps_t, th, n_steps * sizeof(float), hipMemcpyHostToDevice, s));
+        PD_HIP(hipStreamSynchronize(s));         // `th` is a stack buffer
+        PD_TRY(timestep_mlp(u->steps_t, n_steps, u->mc, u->te_w0, u->te_b0, u->te_w2, u->te_b2, u->steps_silu, u->steps_tmp, s));
+        PD_TRY(gemv_rows(u->emb_w, u->emb_b, u->steps_silu, u->steps_emb, (int)u->emb_rows, u->ted, n_steps, s));
+        u->steps_cached = n_steps;
+    }
     for (int k = 0; k < n_steps; ++k) {
-        k_fill<<<1, 64, 0, s>>>(u->t_dev, (float)sched.t[k], N);
-        PD_TRY(forward_impl(u, u->sx, u->t_dev, N, u->set_, s, false));
+        PD_TRY(forward_impl(u, u->sx, nullptr, N, u->set_, s, false, u->steps_emb + (size_t)k * u->emb_rows));
         PD_TRY(ddnm_update(u->sx, u->set_, u->out_ch, u->sy, masks, eps_tape ? eps_tape + (size_t)k * n3 : nullptr, seed,
                            (unsigned long long)k + 1, sched.co[k], N, HW, s));
     }

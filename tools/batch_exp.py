@@ -2,7 +2,7 @@ import sys, time, torch
 sys.path.insert(0, '/root/repo')
 import pointdreamer_amd.ddnm_inpainting as di
 dev = torch.device('cuda', 0)
-for B in (8, 16, 24):
+for B in (int(sys.argv[1]),) if len(sys.argv) > 1 else (8, 16):
     inp = di.Inpainter(dev, ckpt_path=None, allow_random_weights=True, max_batch=B)
     inp.n_steps = 10
     x = torch.rand((B, 3, 256, 256), device=dev); m = (torch.rand((B, 256, 256), device=dev) > 0.7)
