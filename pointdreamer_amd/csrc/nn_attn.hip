@@ -119,11 +119,173 @@ __global__ __launch_bounds__(256) void k_attention(const half_t* __restrict__ qk
     (void)heads;
 }
 
-int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStream_t s) {
+// ------------------------------------------------------------------------------------------------
+// T >= 128: transposed formulation.  S^T = K Q^T puts one QUERY in every lane column (lane & 15) and 4 consecutive keys in its
+// registers, so (i) the online-softmax statistics are per lane (2 shuffle steps over the 4 key groups instead of 4 over 16
+// columns, and the rescale factor is a per-lane scalar), (ii) P^T is ALREADY the B operand of O^T = V^T P^T: the PV k-slots are
+// permuted to the keys a lane holds (key order inside a sum is free), no LDS round trip for P, (iii) V^T rows (one d, keys
+// contiguous) are what the A operand wants -- V is transposed once per attention block by k_transpose_v (8 MB at 32x32,
+// ~5 us) instead of with scalar LDS writes in every workgroup.  32 queries per wave (2 column tiles), K / V^T chunks of 64 keys
+// double-buffered in LDS by LDS-DMA (16-byte slot swizzle slot ^ ((row >> 1) & 7) on the 128-byte rows).
+__global__ __launch_bounds__(256) void k_transpose_v(const half_t* __restrict__ qkv, half_t* __restrict__ vt, int T, int C, int D) {
+    __shared__ half_t tile[64][66];
+    const int n = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 64;
+    const half_t* src = qkv + ((size_t)n * T + t0) * 3 * C + (size_t)h * 3 * D + 2 * D;
+    for (int i = threadIdx.x; i < 64 * D; i += 256) {
+        const int t = i / D, d = i - t * D;
+        tile[t][d] = src[(size_t)t * 3 * C + d];
+    }
+    __syncthreads();
+    half_t* dst = vt + (((size_t)n * (C / D) + h) * D) * T + t0;
+    for (int i = threadIdx.x; i < 64 * D; i += 256) {
+        const int d = i / 64, t = i - d * 64;
+        dst[(size_t)d * T + t] = tile[t][d];
+    }
+}
+
+typedef __attribute__((address_space(3))) void lds_void_a;
+typedef const __attribute__((address_space(1))) void gbl_void_a;
+__device__ __forceinline__ void glds16a(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_void_a*)g, (lds_void_a*)l, 16, 0, 0); }
+
+__global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict__ qkv, const half_t* __restrict__ vt,
+                                                       half_t* __restrict__ out, int T, int C, float scale2) {
+    constexpr int D = 64, KCH = 64;
+    __shared__ __attribute__((aligned(16))) char lds[2][2][KCH * 128];      // [buffer][K | Vt][64 rows x 128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int heads = C / D;
+    const float scale2l = scale2 * 1.4426950408889634f;            // softmax in the log2 domain: exp(x) = 2^(x log2 e)
+    const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const size_t row_stride = (size_t)3 * C;
+    const half_t* base = qkv + (size_t)n * T * row_stride + (size_t)h * 3 * D;
+    const half_t* vbase = vt + (((size_t)n * heads + h) * D) * T;
+    // Q fragments (B operand): column = query r16 of tile qt, k = d chunk ks*32 + 8 g4
+    half8 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qb * 128 + wave * 32 + qt * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const half8*>(base + (size_t)q * row_stride + ks * 32 + g4 * 8);
+    }
+    float4_t o[2][4];
+    float mrun[2], lrun[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        mrun[qt] = -INFINITY; lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    // loader: wave w stages rows 16 w .. 16 w + 15 of the K chunk and of the V^T chunk (2 + 2 pieces of 8 rows x 128 B)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = wave * 16 + p * 8 + lrow;                                   // key (K) / d (V^T)
+            const int sl = lslot ^ ((row >> 1) & 7);                                    // source slot landing in physical slot lslot
+            glds16a(base + (size_t)(k0 + row) * row_stride + D + sl * 8, &lds[buf][0][(wave * 16 + p * 8) * 128]);
+            glds16a(vbase + (size_t)row * T + k0 + sl * 8, &lds[buf][1][(wave * 16 + p * 8) * 128]);
+        }
+    };
+    stage(0, 0);
+    const int nch = T / KCH;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = ch & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // chunk `ch` landed for every wave; chunk ch-1 is fully consumed
+        if (ch + 1 < nch) stage(buf ^ 1, (ch + 1) * KCH);         // restage the buffer read in iteration ch-1 (one barrier per chunk)
+        const char* Kb = lds[buf][0];
+        const char* Vb = lds[buf][1];
+        // K fragments (A operand of S^T): row = key 16 kt + r16, slot ks*4 + g4
+        half8 kf[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int row = kt * 16 + r16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kf[kt][ks] = *reinterpret_cast<const half8*>(Kb + row * 128 + (((ks * 4 + g4) ^ ((row >> 1) & 7)) << 4));
+        }
+        half8 pf[2][2];                                            // [query tile][k-step of 32 keys]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float4_t st[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                st[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[qt][ks], st[kt], 0, 0, 0);
+            }
+            // this lane: query r16 of the tile, keys 16 kt + 4 g4 + r
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][r] *= scale2l; mx = fmaxf(mx, st[kt][r]); }   // log2 domain
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - mnew); sum += st[kt][r]; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            lrun[qt] = lrun[qt] * alpha + sum;
+            mrun[qt] = mnew;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pf[qt][u][r] = (half_t)st[2 * u][r]; pf[qt][u][4 + r] = (half_t)st[2 * u + 1][r]; }
+        }
+        // O^T += V^T P^T: A = V^T fragment (row d = 16 dt + r16; k-slots = keys 32u + 4 g4 + {0..3} and 32u + 16 + 4 g4 + {0..3})
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int row = dt * 16 + r16;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const half4 v0 = *reinterpret_cast<const half4*>(Vb + row * 128 + (((4 * u + (g4 >> 1)) ^ sw) << 4) + (g4 & 1) * 8);
+                const half4 v1 = *reinterpret_cast<const half4*>(Vb + row * 128 + (((4 * u + 2 + (g4 >> 1)) ^ sw) << 4) + (g4 & 1) * 8);
+                half8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+    // normalise and store: lane = query r16 of each tile, d = 16 dt + 4 g4 + r (8-byte packed stores)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = qb * 128 + wave * 32 + qt * 16 + r16;
+        const float inv = 1.0f / lrun[qt];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (half_t)(o[qt][dt][r] * inv);
+            *reinterpret_cast<half4*>(out + ((size_t)n * T + q) * C + h * D + dt * 16 + g4 * 4) = hv;
+        }
+    }
+}
+
+// vt_ws: N*T*C halfs of workspace for the transposed V (only used when T >= 128 and D == 64); may be null -> the 64-query kernel
+int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStream_t s, half_t* vt_ws) {
     PD_REQUIRE(D == 64 || D == 32, "attention: head dim must be 32 or 64 (got %d)", D);
     PD_REQUIRE(C % D == 0 && T % QT == 0, "attention: need C %% D == 0 and T %% 64 == 0 (T=%d C=%d)", T, C);
-    dim3 g(T / QT, C / D, N);
     const float scale2 = 1.0f / sqrtf((float)D);
+    if (vt_ws != nullptr && D == 64 && T % 128 == 0) {
+        k_transpose_v<<<dim3(T / 64, C / D, N), 256, 0, s>>>(qkv, vt_ws, T, C, D);
+        k_attention_t64<<<dim3(T / 128, C / D, N), 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
+        PD_LAUNCH_CHECK();
+        return PDHIP_OK;
+    }
+    dim3 g(T / QT, C / D, N);
     if (D == 64) k_attention<64><<<g, 256, 0, s>>>(qkv, out, T, C, scale2);
     else k_attention<32><<<g, 256, 0, s>>>(qkv, out, T, C, scale2);
     PD_LAUNCH_CHECK();

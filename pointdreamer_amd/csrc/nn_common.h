@@ -47,7 +47,7 @@ int resample2x(const half_t* X, int N, int H, int W, int C, int mode, half_t* Y,
 int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long pixels, half_t* Y, hipStream_t s);
 
 // ---- attention (nn_attn.hip): QKVAttentionLegacy on qkv [N,T,3C] f16 (per head h: q|k|v at channel h*3*D), out [N,T,C].
-int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStream_t s);
+int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStream_t s, half_t* vt_ws = nullptr);   // vt_ws: N*T*C halfs (transposed V)
 
 // ---- small dense ops (nn_misc.hip)
 int conv_in_3x3(const float* x_nchw, const half_t* Wt /*[Cout_pad][32] k=(ky*3+kx)*3+c, k>=27 zero*/, const float* bias, half_t* Y,

@@ -219,7 +219,8 @@ int run_att(Ctx& c, const Act& x, AttB& ab, Act* out) {
     PD_TRY(run_conv(c, xn, ab.qkv, nullptr, &qkv));
     a = x;
     a.p = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);
-    if (!c.dry) PD_TRY(attention(qkv.p, a.p, c.N, x.H * x.W, x.C, c.u->head, c.s));
+    half_t* vt = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);      // transposed V of the T >= 128 attention kernel
+    if (!c.dry) PD_TRY(attention(qkv.p, a.p, c.N, x.H * x.W, x.C, c.u->head, c.s, vt));
     return run_conv(c, a, ab.proj, x.p, out, true);
 }
 
@@ -723,9 +724,9 @@ extern "C" int pdhip_unet_head_f32(const void* x, const float* gamma, const floa
     PD_TRY(head_pack(wp, Cout, C, wz, s));
     return head_gn_silu_conv3x3((const half_t*)x, stats, gamma, beta, wz, bias, y_nchw, N, H, W, C, Cout, s);
 }
-extern "C" int pdhip_attention_f16(const void* qkv, void* out, int N, int T, int C, int head_dim, void* stream) {
+extern "C" int pdhip_attention_f16(const void* qkv, void* out, int N, int T, int C, int head_dim, void* vt_ws, void* stream) {
     PD_REQUIRE(qkv && out, "pdhip_attention_f16: null argument");
-    return attention((const half_t*)qkv, (half_t*)out, N, T, C, head_dim, as_stream(stream));
+    return attention((const half_t*)qkv, (half_t*)out, N, T, C, head_dim, as_stream(stream), (half_t*)vt_ws);
 }
 extern "C" int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream) {
     PD_REQUIRE(out && n > 0, "pdhip_philox_normal: bad arguments");

@@ -139,7 +139,7 @@ def test_output_head_f32_equivalent_vs_torch(nn, N, H, W, Cc, Cout):
     assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("N,T,Cc,D", [(1, 64, 128, 64), (2, 256, 128, 32), (1, 1024, 512, 64), (2, 64, 1024, 64)])
+@pytest.mark.parametrize("N,T,Cc,D", [(1, 64, 128, 64), (2, 256, 128, 32), (1, 1024, 512, 64), (2, 64, 1024, 64), (2, 256, 128, 64), (3, 128, 64, 64)])
 def test_attention_vs_torch(nn, N, T, Cc, D):
     L = nn['L']
     g = torch.Generator().manual_seed(T + Cc)
@@ -152,9 +152,14 @@ def test_attention_vs_torch(nn, N, T, Cc, D):
     # a spiked key row forces a large running-max jump in the online softmax (rare-branch test)
     qd = qkv.permute(0, 2, 1).contiguous().half().to(DEV)
     out = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
-    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _stream()) == 0, L.pdhip_last_error()
+    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, None, _stream()) == 0, L.pdhip_last_error()
+    out2 = torch.empty_like(out)                          # transposed-V kernel (T % 128 == 0, D == 64), same reference
+    vt = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
+    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out2), N, T, Cc, D, _ptr(vt), _stream()) == 0, L.pdhip_last_error()
     o = out.float().cpu().permute(0, 2, 1)
     assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
+    o2 = out2.float().cpu().permute(0, 2, 1)
+    assert (o2 - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
 
 
 def test_attention_online_softmax_rescale_branch(nn):
@@ -169,9 +174,13 @@ def test_attention_online_softmax_rescale_branch(nn):
     ref = torch.einsum("bts,bcs->bct", w, v)
     qd = qkv.permute(0, 2, 1).contiguous().half().to(DEV)
     out = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
-    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _stream()) == 0
+    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, None, _stream()) == 0
     o = out.float().cpu().permute(0, 2, 1)
     assert w[0, 17, 200] > 0.5
+    assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
+    vt = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)      # the transposed-V kernel takes the same late jump
+    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _ptr(vt), _stream()) == 0
+    o = out.float().cpu().permute(0, 2, 1)
     assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
 
 
