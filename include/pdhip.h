@@ -198,8 +198,9 @@ int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* mask
 /* stand-alone operators of the engine (NHWC f16); also the unit-test surface of the kernels */
 /* tuning / test hook: force the conv K-step (32 or 64; 0 = automatic); returns the previous value */
 int pdhip_debug_set_conv_bk(int bk);
-int pdhip_debug_set_conv_tile(int m_waves);     /* 2 = 128x128 tile / 4 waves, 4 = 256x128 tile / 8 waves; 0 = automatic */
-int pdhip_debug_set_conv_stages(int stages);   /* 2..4 LDS pipeline stages; 0 = automatic */
+int pdhip_debug_set_conv_tile(int geometry);    /* 2 = 128x128 tile / 4 waves, 4 = 256x128 / 8 waves, 8 = 256x256 / 8 waves (wave tile 128x64),
+                                                 * 16 = 256x128 / 4 waves, 32 = halo-resident 3x3 kernel (512x128); 0 = automatic */
+int pdhip_debug_set_conv_stages(int stages);   /* 2..4 LDS pipeline stages, 12 = 2 stages + hand-scheduled fragment loop; 0 = automatic */
 int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int splits); /* split-K workspace for pdhip_conv2d_nhwc_f16 + forced factor (0 = automatic) */
 int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed /*[Cout][taps*Cin] f16*/, void* stream);
 int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*Cin]*/, const float* bias, const void* residual,

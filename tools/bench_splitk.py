@@ -10,6 +10,11 @@ P = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [(8, 64, 64, 512, 512, 9), (8, 32, 32, 512, 512, 9), (8, 32, 32, 1024, 512, 9), (8, 16, 16, 1024, 1024, 9), (8, 16, 16, 2048, 1024, 9),
           (8, 8, 8, 1024, 1024, 9), (8, 8, 8, 2048, 1024, 9), (8, 32, 32, 512, 1536, 1), (8, 32, 32, 512, 512, 1),
           (8, 16, 16, 1024, 3072, 1), (8, 16, 16, 1024, 1024, 1), (8, 8, 8, 1024, 3072, 1), (8, 8, 8, 1024, 1024, 1)]
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument('--custom', type=int, nargs='*', default=None); ap.add_argument('--geos', type=int, nargs='*', default=[2, 8])
+a = ap.parse_args()
+if a.custom:
+    SHAPES = [tuple(a.custom[i:i + 6]) for i in range(0, len(a.custom), 6)]
 dev = 'cuda:0'
 zp = torch.zeros(128, dtype=torch.float16, device=dev)
 ws = torch.empty(16 * 384 * 128 * 128, dtype=torch.float32, device=dev)
