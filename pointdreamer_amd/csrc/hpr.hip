@@ -47,16 +47,24 @@ __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* _
 // queries that still need the hull test: all points, or only those a cheaper test (`skip`) has not already accepted
 __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __restrict__ count, int* __restrict__ list,
                               uint8_t* __restrict__ vis) {
-    const int v = blockIdx.y;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        const bool sk = skip != nullptr && skip[(size_t)v * N + i];
-        const unsigned long long bal = __ballot(!sk);
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&count[v], __popcll(bal));
-        base = __shfl(base, 0);
-        if (!sk) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        else vis[(size_t)v * N + i] = 1;
+    // one returning atomic per 256-thread block (a returning atomic on one address costs ~100 ns; per wave it serialised to 45 us)
+    __shared__ int s_wcnt[4], s_base;
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < N;
+        const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
+        const bool q = in && !sk;
+        const unsigned long long bal = __ballot(q);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = atomicAdd(&count[v], s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        if (q) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        else if (sk) vis[(size_t)v * N + i] = 1;
+        __syncthreads();
     }
 }
 
@@ -189,27 +197,31 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
 __global__ void k_hpr_build(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside,
                             const uint8_t* __restrict__ skip, double* __restrict__ ss, int* __restrict__ sidx, int* __restrict__ scount,
                             int* __restrict__ count2, int* __restrict__ list2) {
-    const int v = blockIdx.y, lane = threadIdx.x & 63;
+    __shared__ int s_o[4], s_q[4], s_bo, s_bq;
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* f = flipped + (size_t)v * 3 * N;
     double* so = ss + (size_t)v * 3 * N;
-    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < N; i0 += gridDim.x * blockDim.x) {
-        const int i = i0 + lane;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
         const bool out = i < N && outside[(size_t)v * N + i];
         const bool qry = out && !(skip != nullptr && skip[(size_t)v * N + i]);
-        unsigned long long bal = __ballot(out);
-        int base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&scount[v], __popcll(bal));
-        base = __shfl(base, 0);
+        const unsigned long long bo = __ballot(out), bq = __ballot(qry);
+        if (lane == 0) { s_o[wave] = __popcll(bo); s_q[wave] = __popcll(bq); }
+        __syncthreads();
+        if (threadIdx.x == 0) {                                       // one returning atomic per block and counter
+            s_bo = atomicAdd(&scount[v], s_o[0] + s_o[1] + s_o[2] + s_o[3]);
+            s_bq = atomicAdd(&count2[v], s_q[0] + s_q[1] + s_q[2] + s_q[3]);
+        }
+        __syncthreads();
+        int baseo = s_bo, baseq = s_bq;
+        for (int w = 0; w < wave; ++w) { baseo += s_o[w]; baseq += s_q[w]; }
         if (out) {
-            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            const int pos = baseo + __popcll(bo & ((1ull << lane) - 1ull));
             so[pos] = f[i]; so[N + pos] = f[N + i]; so[2 * (size_t)N + pos] = f[2 * (size_t)N + i];
             sidx[(size_t)v * N + pos] = i;
         }
-        bal = __ballot(qry);
-        base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&count2[v], __popcll(bal));
-        base = __shfl(base, 0);
-        if (qry) list2[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        if (qry) list2[(size_t)v * N + baseq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
     }
 }
 

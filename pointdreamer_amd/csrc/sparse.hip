@@ -56,17 +56,30 @@ __global__ void k_sparse_counts(const uint8_t* __restrict__ hard, const uint8_t*
                                 float thresh_f, float one_minus_thresh_f, ViewParams* __restrict__ params,
                                 uint32_t* __restrict__ counts) {
     const int v = blockIdx.x;
-    __shared__ uint32_t s_fg[4], s_va[4];
+    __shared__ uint32_t s_fg[16], s_va[16];
     uint32_t fg = 0, va = 0;
-    for (int i = threadIdx.x; i < res * res; i += blockDim.x) fg += hard[(size_t)v * res * res + i] ? 1 : 0;
+    const size_t hb = (size_t)v * res * res;
+    const int rr = res * res;
+    if ((rr & 15) == 0 && ((reinterpret_cast<uintptr_t>(hard) + hb) & 15) == 0) {      // 16 mask bytes per load
+        const uint4* h4 = reinterpret_cast<const uint4*>(hard + hb);
+        for (int i = threadIdx.x; i < rr / 16; i += blockDim.x) {
+            const uint4 q = h4[i];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                fg += ((w[k] & 0xffu) != 0) + ((w[k] & 0xff00u) != 0) + ((w[k] & 0xff0000u) != 0) + ((w[k] & 0xff000000u) != 0);
+        }
+    } else {
+        for (int i = threadIdx.x; i < rr; i += blockDim.x) fg += hard[hb + i] ? 1 : 0;
+    }
     for (int i = threadIdx.x; i < N; i += blockDim.x) va += valid[(size_t)v * N + i] ? 1 : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { fg += __shfl_xor(fg, off); va += __shfl_xor(va, off); }
     if ((threadIdx.x & 63) == 0) { s_fg[threadIdx.x >> 6] = fg; s_va[threadIdx.x >> 6] = va; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        fg = s_fg[0] + s_fg[1] + s_fg[2] + s_fg[3];
-        va = s_va[0] + s_va[1] + s_va[2] + s_va[3];
+        fg = 0; va = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { fg += s_fg[k]; va += s_va[k]; }
         counts[2 * v] = fg; counts[2 * v + 1] = va;
         ViewParams p;
         p.scale = 1.0f; p.after_res = res; p.pad = 0; p.rescaled = 0;
@@ -297,7 +310,7 @@ extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colo
     SparseWs w = carve(ws, V, N, res, nullptr);
     const float thr = (float)mask_ratio_thresh;
     const float omt = (float)(1.0 - mask_ratio_thresh);
-    k_sparse_counts<<<V, 256, 0, s>>>(hard_masks, validation, N, res, thr, omt, w.params, w.counts);
+    k_sparse_counts<<<V, 1024, 0, s>>>(hard_masks, validation, N, res, thr, omt, w.params, w.counts);
     dim3 gm(min(cdiv((long long)res * res, 256), 256), V);
     k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB, w.minidx);
     if (N > 0) {
