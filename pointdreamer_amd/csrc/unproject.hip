@@ -102,6 +102,76 @@ __global__ void k_nbf_dilate_v_shrink(const uint8_t* __restrict__ tmp, const uin
     }
 }
 
+// ---- bit-packed NBF (A % 64 == 0): 64 texels per 64-bit word.
+// k_pack_bits: bytes -> bits by wave ballot.  k_nbf_bits: per (view, 32-row band) the Scharr edge test becomes ~20 bitwise ops
+// per 64 texels (on binary images gx != 0  <=>  a12 != a10  or  a02 + a22 != a00 + a20, and likewise gy -- the +-10 term cannot be
+// cancelled by the two +-3 terms), the (2r+1)-wide OR dilation is word shifts with carries from the neighbouring words, the
+// vertical one an OR over 2r+1 LDS rows; the result is expanded back to the byte mask the ABI hands out.
+// 8 MB of visibility in, 8 MB out, everything in between stays in 1 MB of L2-resident bitmaps.
+__global__ void k_pack_bits(const uint8_t* __restrict__ in, long long nwords, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, nw = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long w = wave; w < nwords; w += nw) {
+        const unsigned long long b = __ballot(in[w * 64 + lane] != 0);
+        if (lane == 0) out[w] = b;
+    }
+}
+
+#define NBF_RB 32
+__device__ __forceinline__ unsigned long long nbf_word(const unsigned long long* __restrict__ bits, int A, int W64, int y, int w) {
+    return (y >= 0 && y < A && w >= 0 && w < W64) ? bits[(size_t)y * W64 + w] : 0ull;
+}
+// Scharr response != 0 for the 64 texels of word w in row y (zero padding)
+__device__ __forceinline__ unsigned long long nbf_edge_word(const unsigned long long* __restrict__ bits, int A, int W64, int y, int w) {
+    unsigned long long up[3], mid[3], dn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        up[k] = nbf_word(bits, A, W64, y - 1, w - 1 + k);
+        mid[k] = nbf_word(bits, A, W64, y, w - 1 + k);
+        dn[k] = nbf_word(bits, A, W64, y + 1, w - 1 + k);
+    }
+    // column x-1 / x+1 aligned to bit position x
+    const unsigned long long a00 = (up[1] << 1) | (up[0] >> 63), a02 = (up[1] >> 1) | (up[2] << 63), a01 = up[1];
+    const unsigned long long a10 = (mid[1] << 1) | (mid[0] >> 63), a12 = (mid[1] >> 1) | (mid[2] << 63);
+    const unsigned long long a20 = (dn[1] << 1) | (dn[0] >> 63), a22 = (dn[1] >> 1) | (dn[2] << 63), a21 = dn[1];
+    // gx = 3 (a02 - a00) + 10 (a12 - a10) + 3 (a22 - a20);  gy = 3 (a20 - a00) + 10 (a21 - a01) + 3 (a22 - a02)
+    const unsigned long long gx = (a12 ^ a10) | ((a02 ^ a22) ^ (a00 ^ a20)) | ((a02 & a22) ^ (a00 & a20));
+    const unsigned long long gy = (a21 ^ a01) | ((a20 ^ a22) ^ (a00 ^ a02)) | ((a20 & a22) ^ (a00 & a02));
+    return gx | gy;
+}
+
+__global__ __launch_bounds__(256) void k_nbf_bits(const unsigned long long* __restrict__ visb, const unsigned long long* __restrict__ maskb,
+                                                  int A, int r, uint8_t* __restrict__ out) {
+    extern __shared__ unsigned long long s_nbf[];           // [rows][W64] edges, then [rows][W64] horizontally dilated
+    const int W64 = A >> 6, v = blockIdx.y, y0 = blockIdx.x * NBF_RB;
+    const int rows = NBF_RB + 2 * r;
+    unsigned long long* e = s_nbf;
+    unsigned long long* h = s_nbf + (size_t)rows * W64;
+    const unsigned long long* vb = visb + (size_t)v * A * W64;
+    for (int i = threadIdx.x; i < rows * W64; i += blockDim.x) {
+        const int row = i / W64, w = i - row * W64, y = y0 - r + row;
+        e[i] = (y >= 0 && y < A) ? (nbf_edge_word(vb, A, W64, y, w) & ~nbf_edge_word(maskb, A, W64, y, w)) : 0ull;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * W64; i += blockDim.x) {
+        const int row = i / W64, w = i - row * W64;
+        const unsigned long long c = e[i], lft = w > 0 ? e[i - 1] : 0ull, rgt = w + 1 < W64 ? e[i + 1] : 0ull;
+        unsigned long long acc = c;
+        for (int k = 1; k <= r; ++k) acc |= (c << k) | (lft >> (64 - k)) | (c >> k) | (rgt << (64 - k));
+        h[i] = acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < NBF_RB * W64; i += 4) {
+        const int yy = i / W64, w = i - yy * W64, y = y0 + yy;
+        if (y >= A) break;
+        unsigned long long border = 0ull;
+        for (int k = 0; k <= 2 * r; ++k) border |= h[(size_t)(yy + k) * W64 + w];
+        const unsigned long long keep = vb[(size_t)y * W64 + w] & ~border;
+        out[((size_t)v * A + y) * A + (size_t)w * 64 + lane] = (uint8_t)((keep >> lane) & 1ull);
+    }
+}
+
 extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, int V, int A, const int32_t* kernels,
                                 int K, uint8_t* out, uint8_t* ws, void* stream) {
     PD_REQUIRE(V > 0 && A > 0 && K > 0 && kernels, "pdhip_nbf_shrink: bad sizes");
@@ -118,6 +188,28 @@ extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, 
     uint8_t* edges = ws;
     uint8_t* tmp = ws + n;
     dim3 g(min(cdiv((long long)A * A, 256), 2048), V);
+    bool bits_ok = (A % 64 == 0) && A <= 4096 && V >= 2;            // bitmaps live in the byte workspace: (V + 1) A^2 / 8 <= 2 V A^2
+    for (int k = 0; k < K; ++k) bits_ok = bits_ok && (kernels[k] - 1) / 2 < 64 && (size_t)(NBF_RB + kernels[k] - 1) * (A / 64) * 16 <= 64 * 1024;
+    if (bits_ok) {
+        unsigned long long* visb = reinterpret_cast<unsigned long long*>(ws);
+        unsigned long long* maskb = visb + (size_t)V * A * (A / 64);
+        const long long vw = (long long)V * A * (A / 64), mw = (long long)A * (A / 64);
+        k_pack_bits<<<min(cdiv(vw * 64, 256), 4096), 256, 0, s>>>(visibility, vw, visb);
+        k_pack_bits<<<min(cdiv(mw * 64, 256), 4096), 256, 0, s>>>(mask, mw, maskb);
+        for (int k = 0; k < K; ++k) {
+            int same = -1;
+            for (int j = 0; j < k; ++j) if (kernels[j] == kernels[k]) { same = j; break; }
+            if (same >= 0) {
+                PD_HIP(hipMemcpyAsync(out + (size_t)k * n, out + (size_t)same * n, n, hipMemcpyDeviceToDevice, s));
+                continue;
+            }
+            const int r = (kernels[k] - 1) / 2;
+            const size_t smem = (size_t)2 * (NBF_RB + 2 * r) * (A / 64) * sizeof(unsigned long long);
+            k_nbf_bits<<<dim3(cdiv(A, NBF_RB), V), 256, smem, s>>>(visb, maskb, A, r, out + (size_t)k * n);
+        }
+        PD_LAUNCH_CHECK();
+        return PDHIP_OK;
+    }
     k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges);
     for (int k = 0; k < K; ++k) {
         int same = -1;                              // the reference's list repetition yields identical levels: copy them
