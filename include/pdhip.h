@@ -47,11 +47,14 @@ int pdhip_project_points(const float* cam_params, int V, const float* vertices, 
                          uint32_t* minmax_ws, void* stream);
 
 /* ---- P2: the nvdiffrast.rasterize call at ours_utils.py:142-147 (also extract_texture_map.py:57).
- *      zkey_ws: V*R*R uint64 scratch.  Outputs hard_masks[V,R,R] u8, face_idxs[V,R,R] i64 (-1 empty),
+ *      zkey_ws: V*R*R uint64 scratch (z keys of the atomic path / face setups of the LDS-tiled path).  Outputs hard_masks[V,R,R] u8, face_idxs[V,R,R] i64 (-1 empty),
  *      depths[V,R,R] f32 (0 empty). */
 int pdhip_raster_mesh(const float* pos /*[V,Vn,4]*/, int V, int Vn, const int32_t* faces /*[F,3]*/, int F,
                       int R, uint64_t* zkey_ws, uint8_t* hard_masks, int64_t* face_idxs, float* depths,
                       void* stream);
+/* tuning / test hook: 0 = automatic (LDS-tiled rasteriser up to 65 536 faces), 1 = force the global 64-bit atomicMin path;
+ * both produce identical images.  Returns the previous value. */
+int pdhip_debug_set_raster_path(int path);
 
 /* ---- nvdiffrast contract pieces used by the UV-atlas producer (models/get3d/extract_texture_map.py:57-63) and by
  *      optimize_color (pointdreamer/ours_utils.py:1700-1705): barycentrics (u,v) of triangle vertices 0 and 1 at each covered

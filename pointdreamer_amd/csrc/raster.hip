@@ -2,7 +2,10 @@
 // pointdreamer/ours_utils.py:142-147).  Exact rules are the build's own (oracle/project.py header):
 // 1/256-pixel snapped vertices, int64 edge functions at pixel centres, watertight tie rule,
 // float64 depth interpolation, nearest z wins with ties to the smaller face id.
-// One 64-bit atomicMin per covered pixel on a (z-order, face) key; HBM/L2-atomic bound.
+// Default path: LDS-tiled -- per-(view, face) setup once, 32x32-pixel tiles bin the faces whose bounding box touches them
+// (ballot compaction into LDS) and every thread resolves its 4 pixels against the binned faces in registers: no global
+// atomics, no z-key buffer, outputs written once.  Meshes with more than 65 536 faces fall back to one 64-bit atomicMin per
+// covered pixel on a (z-order, face) key.  Both give identical images (min over the same keys).
 // Compiled with -ffp-contract=off.
 #include "common.h"
 using namespace pdhip;
@@ -85,6 +88,182 @@ __global__ void k_raster_faces(const float* __restrict__ pos, int Vn, const int3
     }
 }
 
+// ---- LDS-tiled path
+struct __attribute__((aligned(16))) FaceSetup {
+    int x0, y0, x1, y1;            // snapped vertices (1/256 px), winding made positive
+    int x2, y2, jmin, jmax;        // pixel bounding box (columns), empty (jmin > jmax) for culled / degenerate faces
+    int imin, imax, inc, pad;      // rows; bit k of inc = tie rule of edge k
+    double z0, z1;
+    double z2, darea;
+};
+
+__global__ void k_raster_setup(const float* __restrict__ pos, int Vn, const int32_t* __restrict__ faces, int F, int R,
+                               FaceSetup* __restrict__ setup, short4* __restrict__ bbox) {
+    const int v = blockIdx.y;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    FaceSetup fs;
+    fs.x0 = fs.y0 = fs.x1 = fs.y1 = fs.x2 = fs.y2 = 0; fs.jmin = 1; fs.jmax = 0; fs.imin = 1; fs.imax = 0; fs.inc = 0; fs.pad = 0;
+    fs.z0 = fs.z1 = fs.z2 = 0.0; fs.darea = 1.0;
+    const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)v * Vn;
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    if ((unsigned)i0 < (unsigned)Vn && (unsigned)i1 < (unsigned)Vn && (unsigned)i2 < (unsigned)Vn) {
+        const float4 a = P[i0], b = P[i1], c = P[i2];
+        long long x0 = snap_fix(a.x, R), y0 = snap_fix(a.y, R);
+        long long x1 = snap_fix(b.x, R), y1 = snap_fix(b.y, R);
+        long long x2 = snap_fix(c.x, R), y2 = snap_fix(c.y, R);
+        double z0 = (double)a.z, z1 = (double)b.z, z2 = (double)c.z;
+        long long area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
+        if (area != 0) {
+            if (area < 0) {
+                long long t;
+                t = x1; x1 = x2; x2 = t;
+                t = y1; y1 = y2; y2 = t;
+                double tz = z1; z1 = z2; z2 = tz;
+                area = -area;
+            }
+            const long long minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
+            const long long miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
+            fs.jmin = (int)max(0ll, -floor_div(-(minx - 128), SUBPIX));
+            fs.jmax = (int)min((long long)R - 1, floor_div(maxx - 128, SUBPIX));
+            fs.imin = (int)max(0ll, -floor_div(-(miny - 128), SUBPIX));
+            fs.imax = (int)min((long long)R - 1, floor_div(maxy - 128, SUBPIX));
+            const long long dx0 = x2 - x1, dy0 = y2 - y1, dx1 = x0 - x2, dy1 = y0 - y2, dx2 = x1 - x0, dy2 = y1 - y0;
+            fs.inc = (((dy0 > 0) || (dy0 == 0 && dx0 > 0)) ? 1 : 0) | (((dy1 > 0) || (dy1 == 0 && dx1 > 0)) ? 2 : 0) |
+                     (((dy2 > 0) || (dy2 == 0 && dx2 > 0)) ? 4 : 0);
+            fs.x0 = (int)x0; fs.y0 = (int)y0; fs.x1 = (int)x1; fs.y1 = (int)y1; fs.x2 = (int)x2; fs.y2 = (int)y2;
+            fs.z0 = z0; fs.z1 = z1; fs.z2 = z2; fs.darea = (double)area;
+            if (fs.imin > fs.imax) { fs.jmin = 1; fs.jmax = 0; }
+        }
+    }
+    setup[(size_t)v * F + f] = fs;
+    bbox[(size_t)v * F + f] = make_short4((short)fs.jmin, (short)fs.jmax, (short)fs.imin, (short)fs.imax);
+}
+
+#define RT 64                      // tile edge (pixels); the tile's z-key buffer lives in LDS
+#define RT_BATCH 256               // faces staged in LDS per resolve batch
+struct __attribute__((aligned(16))) FaceTile {     // one face clipped to one tile; edge functions as exact doubles (|E| < 2^52)
+    double e0, e1, e2;             // edge functions at pixel (j0, i0)
+    double ax0, ax1, ax2;          // step per +1 pixel column
+    double ay0, ay1, ay2;          // step per +1 pixel row
+    double z0, z1, z2, darea;
+    int j0, j1, i0, i1, inc, fidx;
+};
+// One workgroup per (view, 64x64 tile).  The faces whose bounding box touches the tile are compacted into an LDS list
+// (ballot + per-wave counts); one thread per listed face turns its setup into tile-local edge functions (exact: all values
+// are integers below 2^52 held in doubles), then every wave takes faces off the list and covers the clipped bounding box in
+// 8x8 lane blocks, stepping the edge functions by additions and depth-testing with 64-bit LDS atomicMin on the same
+// (z-order, face) key as the fallback path.
+__global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restrict__ setup, const short4* __restrict__ bbox, int F,
+                                                       int R, uint8_t* __restrict__ hard, int64_t* __restrict__ fid,
+                                                       float* __restrict__ depth) {
+    __shared__ unsigned long long s_z[RT * RT];
+    __shared__ int s_list[2048];
+    __shared__ FaceTile s_ft[RT_BATCH];
+    __shared__ int s_wcnt[16];
+    const int v = blockIdx.y, tiles_x = (R + RT - 1) / RT;
+    const int tx0 = (blockIdx.x % tiles_x) * RT, ty0 = (blockIdx.x / tiles_x) * RT;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const FaceSetup* S = setup + (size_t)v * F;
+    const short4* B = bbox + (size_t)v * F;
+    for (int k = t; k < RT * RT; k += 1024) s_z[k] = ~0ull;
+    int count = 0;                                                   // faces waiting in s_list (block-uniform)
+    const double lx = (double)(lane & 7), ly = (double)(lane >> 3);
+
+    auto resolve = [&](int n) {                                      // rasterise faces s_list[0 .. n) into s_z
+        for (int b0 = 0; b0 < n; b0 += RT_BATCH) {
+            const int nb = min(RT_BATCH, n - b0);
+            if (t < nb) {
+                const int f = s_list[b0 + t];
+                const FaceSetup q = S[f];
+                FaceTile ft;
+                ft.j0 = max(q.jmin, tx0); ft.j1 = min(q.jmax, tx0 + RT - 1);
+                ft.i0 = max(q.imin, ty0); ft.i1 = min(q.imax, ty0 + RT - 1);
+                ft.inc = q.inc; ft.fidx = f;
+                const long long x0 = q.x0, y0 = q.y0, x1 = q.x1, y1 = q.y1, x2 = q.x2, y2 = q.y2;
+                const long long dx0 = x2 - x1, dy0 = y2 - y1, dx1 = x0 - x2, dy1 = y0 - y2, dx2 = x1 - x0, dy2 = y1 - y0;
+                const long long px = (long long)ft.j0 * SUBPIX + 128, py = (long long)ft.i0 * SUBPIX + 128;
+                ft.e0 = (double)(dx0 * (py - y1) - dy0 * (px - x1));
+                ft.e1 = (double)(dx1 * (py - y2) - dy1 * (px - x2));
+                ft.e2 = (double)(dx2 * (py - y0) - dy2 * (px - x0));
+                ft.ax0 = (double)(-dy0 * SUBPIX); ft.ax1 = (double)(-dy1 * SUBPIX); ft.ax2 = (double)(-dy2 * SUBPIX);
+                ft.ay0 = (double)(dx0 * SUBPIX); ft.ay1 = (double)(dx1 * SUBPIX); ft.ay2 = (double)(dx2 * SUBPIX);
+                ft.z0 = q.z0; ft.z1 = q.z1; ft.z2 = q.z2; ft.darea = q.darea;
+                s_ft[t] = ft;
+            }
+            __syncthreads();
+            for (int k = wave; k < nb; k += 16) {
+                const FaceTile& q = s_ft[k];
+                const int j0 = __builtin_amdgcn_readfirstlane(q.j0), j1 = __builtin_amdgcn_readfirstlane(q.j1);
+                const int i0 = __builtin_amdgcn_readfirstlane(q.i0), i1 = __builtin_amdgcn_readfirstlane(q.i1);
+                const int nbx = (j1 - j0 + 8) >> 3, nby = (i1 - i0 + 8) >> 3;
+                const int inc = q.inc, fidx = q.fidx;
+                const double ax0 = q.ax0, ax1 = q.ax1, ax2 = q.ax2, ay0 = q.ay0, ay1 = q.ay1, ay2 = q.ay2;
+                const double z0 = q.z0, z1 = q.z1, z2 = q.z2, darea = q.darea;
+                double r0 = fma(ly, ay0, fma(lx, ax0, q.e0));        // exact: integers below 2^52
+                double r1 = fma(ly, ay1, fma(lx, ax1, q.e1));
+                double r2 = fma(ly, ay2, fma(lx, ax2, q.e2));
+                const double sx0 = 8.0 * ax0, sx1 = 8.0 * ax1, sx2 = 8.0 * ax2;
+                const double sy0 = 8.0 * ay0, sy1 = 8.0 * ay1, sy2 = 8.0 * ay2;
+                const bool t0 = inc & 1, t1 = inc & 2, t2 = inc & 4;
+                for (int by = 0; by < nby; ++by) {
+                    double E0 = r0, E1 = r1, E2 = r2;
+                    const int i = i0 + by * 8 + (lane >> 3);
+                    for (int bx = 0; bx < nbx; ++bx) {
+                        const int j = j0 + bx * 8 + (lane & 7);
+                        const bool in = j <= j1 && i <= i1 && (E0 > 0.0 || (E0 == 0.0 && t0)) && (E1 > 0.0 || (E1 == 0.0 && t1)) &&
+                                        (E2 > 0.0 || (E2 == 0.0 && t2));
+                        if (in) {
+                            const double zd = (E0 * z0 + E1 * z1) + E2 * z2;
+                            const float z = (float)(zd / darea);
+                            if (z >= -1.0f && z <= 1.0f)
+                                atomicMin(&s_z[(i - ty0) * RT + (j - tx0)], ((unsigned long long)f2ord(z) << 32) | (uint32_t)fidx);
+                        }
+                        E0 += sx0; E1 += sx1; E2 += sx2;
+                    }
+                    r0 += sy0; r1 += sy1; r2 += sy2;
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    for (int base = 0; base < F; base += 1024) {
+        const int f = base + t;
+        bool ov = false;
+        if (f < F) {
+            const short4 bb = B[f];                                            // (jmin, jmax, imin, imax)
+            ov = bb.x <= bb.y && bb.y >= tx0 && bb.x < tx0 + RT && bb.w >= ty0 && bb.z < ty0 + RT;
+        }
+        const unsigned long long bal = __ballot(ov);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = count, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = s_wcnt[w];
+            off += w < wave ? c : 0;
+            tot += c;
+        }
+        if (ov) s_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = f;
+        count += tot;
+        __syncthreads();
+        if (count >= 1024) { resolve(count); count = 0; }
+    }
+    if (count > 0) resolve(count);
+    __syncthreads();
+    for (int k = t; k < RT * RT; k += 1024) {
+        const int i = ty0 + (k >> 6), j = tx0 + (k & 63);
+        if (i >= R || j >= R) continue;
+        const size_t o = ((size_t)v * R + i) * R + j;
+        const unsigned long long key = s_z[k];
+        const bool hit = key != ~0ull;
+        hard[o] = hit ? 1 : 0;
+        fid[o] = hit ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
+        depth[o] = hit ? ord2f((uint32_t)(key >> 32)) : 0.0f;
+    }
+}
+
 __global__ void k_raster_resolve(const uint64_t* __restrict__ zkey, long long n, uint8_t* __restrict__ hard,
                                  int64_t* __restrict__ fid, float* __restrict__ depth) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -96,6 +275,9 @@ __global__ void k_raster_resolve(const uint64_t* __restrict__ zkey, long long n,
     }
 }
 
+static int g_raster_path = 0;                    // 0 automatic, 1 force the global-atomic fallback
+extern "C" int pdhip_debug_set_raster_path(int path) { int old = g_raster_path; g_raster_path = path; return old; }
+
 extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t* faces, int F, int R,
                                  uint64_t* zkey_ws, uint8_t* hard_masks, int64_t* face_idxs, float* depths,
                                  void* stream) {
@@ -103,6 +285,16 @@ extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t*
     PD_REQUIRE(pos && (F == 0 || faces) && zkey_ws && hard_masks && face_idxs && depths, "pdhip_raster_mesh: null pointer");
     hipStream_t s = as_stream(stream);
     long long n = (long long)V * R * R;
+    // LDS-tiled path: the face setups live in the z-key workspace (V*R*R*8 bytes >= V*F*80 bytes)
+    if (g_raster_path != 1 && F > 0 && F <= 65536 && R <= 32767 && (size_t)V * F * (sizeof(FaceSetup) + sizeof(short4)) <= (size_t)n * sizeof(uint64_t)) {
+        FaceSetup* setup = reinterpret_cast<FaceSetup*>(zkey_ws);
+        short4* bbox = reinterpret_cast<short4*>(setup + (size_t)V * F);
+        k_raster_setup<<<dim3(cdiv(F, 256), V), 256, 0, s>>>(pos, Vn, faces, F, R, setup, bbox);
+        const int tiles = cdiv(R, RT) * cdiv(R, RT);
+        k_raster_tiles<<<dim3(tiles, V), 1024, 0, s>>>(setup, bbox, F, R, hard_masks, face_idxs, depths);
+        PD_LAUNCH_CHECK();
+        return PDHIP_OK;
+    }
     k_raster_init<<<min(cdiv(n, 256), 4096), 256, 0, s>>>(zkey_ws, n);
     if (F > 0) {
         dim3 g(cdiv(F, 64), V);

@@ -51,7 +51,7 @@ def test_camera_params_match_oracle(pd):
         assert np.array_equal(N_(c.transform(T(pts))), o.transform(pts))
 
 
-@pytest.mark.parametrize("n_points,stacks,slices,V,R", [(2000, 12, 24, 3, 128), (30000, 50, 100, 8, 512)])
+@pytest.mark.parametrize("n_points,stacks,slices,V,R", [(2000, 12, 24, 3, 128), (2000, 9, 14, 2, 100), (30000, 50, 100, 8, 512)])
 def test_p1_p2_project_and_raster_vs_oracle(pd, n_points, stacks, slices, V, R):
     syn = pd['syn']
     verts, faces, _ = syn.uv_sphere(stacks, slices)
@@ -73,6 +73,15 @@ def test_p1_p2_project_and_raster_vs_oracle(pd, n_points, stacks, slices, V, R):
     # properties
     assert hard.any() and (~hard).any()
     assert np.array_equal(N_(hard), N_(fidx) >= 0)
+    # the global-atomic fallback (meshes above 65 536 faces) draws the same images as the LDS-tiled path
+    from pointdreamer_amd import _lib
+    L = _lib.lib()
+    old = L.pdhip_debug_set_raster_path(1)
+    try:
+        h2, f2, d2 = pd['ou'].get_rendered_hard_mask_and_face_idx_batch(cams, T(verts), T(faces), T(xyz), None, True, 0.05)[:3]
+    finally:
+        L.pdhip_debug_set_raster_path(old)
+    assert np.array_equal(N_(h2), oh) and np.array_equal(N_(f2), of) and np.array_equal(N_(d2), od)
     assert (N_(depth)[~N_(hard)] == 0).all()
     # non-rescale branch
     out2 = pd['ou'].get_rendered_hard_mask_and_face_idx_batch(cams, T(verts), T(faces), T(xyz), None, False, 0.05)
