@@ -73,9 +73,10 @@ def main():
     ap.add_argument('--parallel', default='shapes', choices=['shapes', 'views'])
     ap.add_argument('--ddnm-steps', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--shapes-per-step', type=int, default=1,
-                    help='independent shapes textured per step on each GPU, their views batched through the UNet together '
-                         '(BASELINE configs[4] style; default 1 = configs[2])')
+    ap.add_argument('--shapes-per-step', type=int, default=4,
+                    help='independent shapes textured per step on each GPU, their 8-view sets batched through the UNet together '
+                         '(BASELINE configs[4] style).  Measured on one MI355X: 1 -> 1670, 2 -> 1836, 4 -> 1939, 8 -> 1953 '
+                         'shapes/hour; 1 = one shape at a time (configs[2], lowest latency)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [[], ["--shapes-per-step", "2"], ["--workload", "nearest"]])
+@pytest.mark.parametrize("extra", [[], ["--shapes-per-step", "1"], ["--workload", "nearest"]])
 def test_bench_prints_one_json_line_with_the_contract_fields(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--ddnm-steps", "2", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -28,4 +28,4 @@ def test_bench_prints_one_json_line_with_the_contract_fields(extra):
         assert k in r, k
     if "nearest" not in extra:
         assert r["bound"] == "mfma" and r["achieved"] > 100 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-        assert d["config"]["shapes_per_step"] == (2 if "--shapes-per-step" in extra else 1)
+        assert d["config"]["shapes_per_step"] == (1 if "--shapes-per-step" in extra else 4)
