@@ -14,6 +14,7 @@
 // the register-pipelined fragment schedule of nn_gemm.hip (inline-asm ds_read_b128, counted waits) with 8 groups per step.
 // Halo row = 64 B (32 channels); 16-byte slot swizzle s(hp) = 2 * ((hp >> 2) & 1): conflict-free ds_read_b128 for ANY
 // start pixel (the tap shift moves the 16-pixel fragment window by +-1), mirrored on the LDS-DMA source address.
+#include <type_traits>
 #include "nn_common.h"
 using namespace pdhip;
 namespace pdnn {
@@ -231,43 +232,66 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         return;
     }
     // ---- epilogue (as k_conv_igemm: transposed accumulator tile -> f16 -> LDS -> coalesced rows, residual, GN partials)
+#ifdef PD_LAB_NOEPI                                        // (lab builds only: how much of a tile is the epilogue)
+    if (m0 != -12345) { if (acc[0][0][0] == 123.456f) Y[0] = (half_t)1.f; return; }
+#endif
     half_t* Cs = reinterpret_cast<half_t*>(smem);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
-        float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr && n0 + nl < Cout) bv = *reinterpret_cast<const float4_t*>(bias + n0 + nl);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ml = wm * TM * 16 + i * 16 + (lane & 15);
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
-            *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
-        }
-    }
-    __syncthreads();
     constexpr int CT = BNT / 8;                            // column threads (one channel octet each)
     constexpr int RPP = NWAVES * 64 / CT;                  // rows per pass
     const int col8 = (tid % CT) * 8;
+    // Bias first, then (residual convs) every residual row of this thread in one batch: the main loop's registers are dead
+    // here, and the HBM latency of the batch runs under the accumulator staging instead of once per output row.  The body is
+    // instantiated per case so that the compiler's wait counts stay exact (no conservative vmcnt(0) at a join).
     float gs = 0.f, gq = 0.f;
-#pragma unroll 4
-    for (int p = 0; p < BMT / RPP; ++p) {
-        const int row = p * RPP + tid / CT;
-        const long long m = (long long)m0 + row;
-        if (n0 + col8 < Cout) {
+    auto epilogue = [&](auto has_res) {
+        constexpr bool RES = decltype(has_res)::value;
+        float4_t bvs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+            bvs[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && n0 + nl < Cout) bvs[j] = *reinterpret_cast<const float4_t*>(bias + n0 + nl);
+        }
+        const bool col_ok = n0 + col8 < Cout;
+        const half_t* rp = residual + (size_t)((long long)m0 + tid / CT) * Cout + (col_ok ? n0 + col8 : 0);
+        half8 rres[RES ? BMT / RPP : 1];
+        if (RES) {
+#pragma unroll
+            for (int p = 0; p < BMT / RPP; ++p) rres[p] = *reinterpret_cast<const half8*>(rp + (size_t)p * RPP * Cout);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + (lane >> 4) * 4;
+            const float4_t bv = bvs[j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * TM * 16 + i * 16 + (lane & 15);
+                half4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
+                *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < BMT / RPP; ++p) {
+            const int row = p * RPP + tid / CT;
+            const long long m = (long long)m0 + row;
             half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
             const size_t o = (size_t)m * Cout + n0 + col8;
-            if (residual != nullptr) {
-                const half8 rv = *reinterpret_cast<const half8*>(residual + o);
+            if (RES) {
+                const half8 rv = rres[p];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
-            *reinterpret_cast<half8*>(Y + o) = v;
+            if (col_ok) {
+                *reinterpret_cast<half8*>(Y + o) = v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
+            }
         }
-    }
+    };
+    if (residual != nullptr) epilogue(std::true_type{}); else epilogue(std::false_type{});
     if (gn_part != nullptr) {                              // [img][chunk][Cout/8][2], chunk = 512-pixel tile of the image
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser(); ap.add_argument('--cfg', nargs='*', default=['64
 ap.add_argument('--custom', type=int, nargs='*', default=None, help='extra shapes as N H W Cin Cout taps ...')
 ap.add_argument('--zeros', action='store_true', help='zero activations and weights (DVFS reference)')
 ap.add_argument('--stamps', action='store_true', help='lab_stamp build: print per-phase cycle averages of the last launch')
+ap.add_argument('--res', action='store_true', help='pass a residual tensor (the out_layers conv of a ResBlock)')
 ap.add_argument('--lib', default=None, help='alternative libpdhip.so (lab builds)')
 a = ap.parse_args()
 if a.lib:
@@ -34,17 +35,19 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
         x.zero_(); w.zero_()
     y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev)
     fl = 2.0 * N * H * W * Cout * taps * Cin
+    rt = torch.randn((N, H, W, Cout), device=dev).half() if a.res else None
+    rs = P(rt) if a.res else None
     res = []
     for cfg in a.cfg:
         bk, st, wm = (int(v) for v in cfg.split('x'))
         L.pdhip_debug_set_conv_bk(bk); L.pdhip_debug_set_conv_stages(st); L.pdhip_debug_set_conv_tile(wm)
         for _ in range(3):
-            L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), None, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), None)
+            L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), rs, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), None)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), None, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), rs, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         res.append(f"{cfg}: {fl/ms/1e9:6.0f}")
