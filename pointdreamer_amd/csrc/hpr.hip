@@ -23,7 +23,16 @@ using namespace pdhip;
 #define GJK_MAX_ROUNDS 64
 #define GJK_COARSE_ROUNDS 32
 #define HPR_KC 1024            // coarse support set size
+#define HPR_NARROW_BELOW 4096   // query lists shorter than this (per view) run 4 queries per wavefront instead of 16
 
+#ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
+__device__ unsigned long long g_hpr_stats[2][4];              // [pass][waves, wave rounds, queries, query rounds]
+extern "C" int pdhip_lab_hpr_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hpr_stats), sizeof(g_hpr_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 struct d3 { double x, y, z; };
 __device__ __forceinline__ d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ d3 neg(d3 a) { return {-a.x, -a.y, -a.z}; }
@@ -69,15 +78,17 @@ __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __re
 }
 
 // Support set = ss[v][3][scap] (first `ns` entries valid) with original cloud indices sidx[v][scap].
+// Q = queries per wavefront (16 when there are enough queries to fill the chip; 4 for short lists, where the kernel time is the
+// longest wave's rounds x scan length and a narrower wave scans 4x faster).
 // COARSE: every point of the cloud is a query (ns = scap = KC extreme points); writes outside[v][q] = origin not enclosed.
 // !COARSE: queries from list / count, support set = the points outside the coarse hull (ns = scount[v]); writes vis.
-template <bool COARSE>
+template <bool COARSE, int Q>
 __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                  const int* __restrict__ list, uint8_t* __restrict__ vis,
                                                  const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
-                                                 const int* __restrict__ scount, uint8_t* __restrict__ outside) {
-    __shared__ double s_dir[4][QPW][3];
-    __shared__ int s_q[4][QPW];
+                                                 const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi) {
+    __shared__ double s_dir[4][Q][3];
+    __shared__ int s_q[4][Q];
     const int v = blockIdx.y;
     const double* qfx = flipped + (size_t)v * 3 * N;          // the queries' own coordinates
     const double* qfy = qfx + N;
@@ -88,17 +99,20 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
     const int* sidx = sidx_all + (size_t)v * scap;
     const int NS = COARSE ? scap : scount[v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = (blockIdx.x * 4 + wave) * QPW;
+    const int q0 = (blockIdx.x * 4 + wave) * Q;
     const int nq = COARSE ? N : count[v];
-    if (q0 >= nq) return;
-    const bool owner = lane < QPW && q0 + lane < nq;
+    if (q0 >= nq || nq < q_lo || nq >= q_hi) return;        // (q_lo, q_hi: which launch geometry serves this view's query count)
+    bool owner = lane < Q && q0 + lane < nq;
     const int q = owner ? (COARSE ? q0 + lane : list[(size_t)v * N + q0 + lane]) : -1;
-    if (lane < QPW) s_q[wave][lane] = q;
+    // coarse pass: a point of the coarse set itself is an extreme point of the cloud -- a certain hull vertex, marked 2 by
+    // k_hpr_extremes, never queried (so no query of this pass is a member of its own support set)
+    if (COARSE && owner && outside[(size_t)v * N + q] == 2) owner = false;
+    if (lane < Q) s_q[wave][lane] = q;
     __builtin_amdgcn_wave_barrier();
-    int qk[QPW];
+    int qk[Q];
 #pragma unroll
-    for (int k = 0; k < QPW; ++k) qk[k] = s_q[wave][k];
-    // ---- per-query GJK state (meaningful in lanes < QPW)
+    for (int k = 0; k < Q; ++k) qk[k] = s_q[wave][k];
+    // ---- per-query GJK state (meaningful in lanes < Q)
     d3 pi = {0, 0, 0}, sa = {0, 0, 0}, sb = {0, 0, 0}, sc = {0, 0, 0}, sd = {0, 0, 0}, dir = {0, 0, 1};
     int dim = 0;                   // simplex size; phases: 0 -> fetch c, 1 -> fetch b, >= 2 -> main loop
     int state = owner ? 0 : 2;     // 0 running, 1 visible (origin outside), 2 hidden / not a query
@@ -106,39 +120,60 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
         pi = {qfx[q], qfy[q], qfz[q]};
         dir = pi;                  // start looking straight out along the point's own ray
     }
+#ifdef PD_HPR_STATS
+    int my_rounds = 0, wave_rounds = 0;
+#endif
     for (int round = 0; round < (COARSE ? GJK_COARSE_ROUNDS : GJK_MAX_ROUNDS); ++round) {
         if (__ballot(state == 0) == 0ull) break;
-        if (lane < QPW) { s_dir[wave][lane][0] = dir.x; s_dir[wave][lane][1] = dir.y; s_dir[wave][lane][2] = dir.z; }
+#ifdef PD_HPR_STATS
+        ++wave_rounds; if (state == 0) ++my_rounds;
+#endif
+        if (lane < Q) { s_dir[wave][lane][0] = dir.x; s_dir[wave][lane][1] = dir.y; s_dir[wave][lane][2] = dir.z; }
         __builtin_amdgcn_wave_barrier();
-        double dx[QPW], dy[QPW], dz[QPW], best[QPW];
-        int bi[QPW], bo[QPW];                                        // position in the support set / original index
+        double dx[Q], dy[Q], dz[Q], best[Q];
+        int bi[Q];                                                 // position in the support set
 #pragma unroll
-        for (int k = 0; k < QPW; ++k) {
+        for (int k = 0; k < Q; ++k) {
             dx[k] = s_dir[wave][k][0]; dy[k] = s_dir[wave][k][1]; dz[k] = s_dir[wave][k][2];
-            best[k] = -1.0e300; bi[k] = 0x7fffffff; bo[k] = 0x7fffffff;
+            best[k] = -1.0e300; bi[k] = 0x7fffffff;
         }
-        // ---- support scan: every lane streams points j = lane, lane+64, ...
+        // ---- support scan: every lane streams points j = lane, lane+64, ...  The support set is in ascending cloud order, a
+        // lane keeps its FIRST maximum and the butterfly prefers the smaller position: equal values resolve to the smallest
+        // cloud index without an index compare per pair (8 VALU per pair instead of 15).
+        // (the next point is requested before the current one is evaluated: two waves per SIMD do not hide an L2 round trip)
+        double nx = 0.0, ny = 0.0, nz = 0.0;
+        int njo = -1;
+        if (lane < NS) { nx = fx[lane]; ny = fy[lane]; nz = fz[lane]; if (!COARSE) njo = sidx[lane]; }
         for (int j = lane; j < NS; j += 64) {
-            const double x = fx[j], y = fy[j], z = fz[j];
-            const int jo = sidx[j];                                  // index in the cloud (self-exclusion, tie-break)
+            const double x = nx, y = ny, z = nz;
+            const int jo = njo;
+            const int jn = j + 64;
+            if (jn < NS) { nx = fx[jn]; ny = fy[jn]; nz = fz[jn]; if (!COARSE) njo = sidx[jn]; }
+            if (COARSE) {
 #pragma unroll
-            for (int k = 0; k < QPW; ++k) {
-                double val = dx[k] * x + dy[k] * y + dz[k] * z;
-                if (jo == qk[k]) val = -1.0e300;                    // S_i excludes the point itself
-                if (val > best[k] || (val == best[k] && jo < bo[k])) { best[k] = val; bi[k] = j; bo[k] = jo; }
+                for (int k = 0; k < Q; ++k) {
+                    const double val = dx[k] * x + dy[k] * y + dz[k] * z;
+                    if (val > best[k]) { best[k] = val; bi[k] = j; }
+                }
+            } else {                                                 // jo = index in the cloud: S_i excludes the point itself
+#pragma unroll
+                for (int k = 0; k < Q; ++k) {
+                    const double val = dx[k] * x + dy[k] * y + dz[k] * z;
+                    if ((val > best[k]) & (jo != qk[k])) { best[k] = val; bi[k] = j; }
+                }
             }
         }
         double myv = -1.0e300;
         int myi = 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < QPW; ++k) {
+        for (int k = 0; k < Q; ++k) {
             double b = best[k];
-            int id = bi[k], io = bo[k];
+            int id = bi[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double ob = __shfl_xor(b, off);
-                const int oi = __shfl_xor(id, off), oo = __shfl_xor(io, off);
-                if (ob > b || (ob == b && oo < io)) { b = ob; id = oi; io = oo; }
+                const int oi = __shfl_xor(id, off);
+                if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
             }
             if (lane == k) { myv = b; myi = id; }
         }
@@ -184,50 +219,61 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
             }
         }
     }
+#ifdef PD_HPR_STATS
+    if (lane == 0) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][0], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][1], (unsigned long long)wave_rounds); }
+    if (owner) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][2], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][3], (unsigned long long)my_rounds); }
+#endif
     if (!COARSE) {
         if (owner) vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
     } else {
         if (owner) outside[(size_t)v * N + q] = state != 2;           // 0: enclosed by the coarse hull (hidden, and never a support point)
+                                                                      // (entries marked 2 -- coarse-set members -- are left alone)
     }
 }
 
 // second-level inputs: the support set = all points outside the coarse hull (coordinates + original index), and the query list =
-// those of them that no cheaper test accepted.  Wave-compacted with one atomic per wave (order across waves is a race; the
-// support argmax breaks ties on the ORIGINAL index, so the result does not depend on it).
-__global__ void k_hpr_build(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside,
-                            const uint8_t* __restrict__ skip, double* __restrict__ ss, int* __restrict__ sidx, int* __restrict__ scount,
-                            int* __restrict__ count2, int* __restrict__ list2) {
-    __shared__ int s_o[4], s_q[4], s_bo, s_bq;
-    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// those of them that no cheaper test accepted.  One workgroup per view walks the cloud in order (ballot ranks + a running
+// offset): both lists come out in ascending cloud order, which is what lets the support scan drop its index tie-break.
+// Members of the coarse set (outside == 2) are certain hull vertices: marked visible here, supports but never queries.
+__global__ __launch_bounds__(1024) void k_hpr_build(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside,
+                                                    const uint8_t* __restrict__ skip, double* __restrict__ ss, int* __restrict__ sidx,
+                                                    int* __restrict__ scount, int* __restrict__ count2, int* __restrict__ list2,
+                                                    uint8_t* __restrict__ vis) {
+    __shared__ int s_o[16], s_q[16];
+    const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* f = flipped + (size_t)v * 3 * N;
     double* so = ss + (size_t)v * 3 * N;
-    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+    int base_o = 0, base_q = 0;
+    for (int i0 = 0; i0 < N; i0 += 1024) {
         const int i = i0 + threadIdx.x;
-        const bool out = i < N && outside[(size_t)v * N + i];
-        const bool qry = out && !(skip != nullptr && skip[(size_t)v * N + i]);
+        const uint8_t o = i < N ? outside[(size_t)v * N + i] : 0;
+        const bool sk = i < N && skip != nullptr && skip[(size_t)v * N + i];
+        const bool out = o != 0, qry = o == 1 && !sk;
+        if (o == 2 && !sk) vis[(size_t)v * N + i] = 1;
         const unsigned long long bo = __ballot(out), bq = __ballot(qry);
         if (lane == 0) { s_o[wave] = __popcll(bo); s_q[wave] = __popcll(bq); }
         __syncthreads();
-        if (threadIdx.x == 0) {                                       // one returning atomic per block and counter
-            s_bo = atomicAdd(&scount[v], s_o[0] + s_o[1] + s_o[2] + s_o[3]);
-            s_bq = atomicAdd(&count2[v], s_q[0] + s_q[1] + s_q[2] + s_q[3]);
+        int po = base_o, pq = base_q, to = 0, tq = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            po += w < wave ? s_o[w] : 0; pq += w < wave ? s_q[w] : 0;
+            to += s_o[w]; tq += s_q[w];
         }
-        __syncthreads();
-        int baseo = s_bo, baseq = s_bq;
-        for (int w = 0; w < wave; ++w) { baseo += s_o[w]; baseq += s_q[w]; }
         if (out) {
-            const int pos = baseo + __popcll(bo & ((1ull << lane) - 1ull));
+            const int pos = po + __popcll(bo & ((1ull << lane) - 1ull));
             so[pos] = f[i]; so[N + pos] = f[N + i]; so[2 * (size_t)N + pos] = f[2 * (size_t)N + i];
             sidx[(size_t)v * N + pos] = i;
         }
-        if (qry) list2[(size_t)v * N + baseq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
+        if (qry) list2[(size_t)v * N + pq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
+        base_o += to; base_q += tq;
         __syncthreads();
     }
+    if (threadIdx.x == 0) { scount[v] = base_o; count2[v] = base_q; }
 }
 
 // coarse support set: the extreme point of the flipped cloud in each of KC Fibonacci-sphere directions (ties: smallest index)
 __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, int KC, double* __restrict__ cs,
-                                                      int* __restrict__ cidx) {
+                                                      int* __restrict__ cidx, uint8_t* __restrict__ mark) {
     const int v = blockIdx.y;
     const double* fx = flipped + (size_t)v * 3 * N;
     const double* fy = fx + N;
@@ -263,9 +309,15 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
             if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
         }
         if (lane == 0 && k0 + k < KC) {
+            // The hull is that of the cloud AND the eye (the origin of the flipped space): in a direction where every point
+            // has a negative projection the origin is the extreme element, not a cloud point -- the slot then holds the origin
+            // (support value 0, which the GJK step already treats as "the origin").  Otherwise the point is a certain hull
+            // vertex: member of the coarse set, marked 2, never queried.
             double* c = cs + (size_t)v * 3 * KC;
-            c[k0 + k] = fx[id]; c[KC + k0 + k] = fy[id]; c[2 * (size_t)KC + k0 + k] = fz[id];
-            cidx[(size_t)v * KC + k0 + k] = id;
+            const bool real = b > 0.0;
+            c[k0 + k] = real ? fx[id] : 0.0; c[KC + k0 + k] = real ? fy[id] : 0.0; c[2 * (size_t)KC + k0 + k] = real ? fz[id] : 0.0;
+            cidx[(size_t)v * KC + k0 + k] = real ? id : -1;
+            if (real) mark[(size_t)v * N + id] = 2;
         }
     }
 }
@@ -305,17 +357,20 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     PD_HIP(hipMemsetAsync(count2, 0, 64 * sizeof(int), s));
     PD_HIP(hipMemsetAsync(scount, 0, 64 * sizeof(int), s));
     k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);      // marks the skipped points visible; `list` = the queries
-    dim3 gg(cdiv(N, 4 * QPW), V);
+    dim3 gg(cdiv(N, 4 * QPW), V), gg4(cdiv(min(N, HPR_NARROW_BELOW), 4 * 4), V);
     if (N > 4 * HPR_KC) {            // the coarse level pays off only when the cloud is much larger than the coarse set
         dim3 ge(cdiv(HPR_KC, 4 * QPW), V);
-        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, HPR_KC, cs, cidx);
-        k_hpr_gjk<true><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, HPR_KC, nullptr, outside);
-        k_hpr_build<<<gf, 256, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2);
-        k_hpr_gjk<false><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr);
+        PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
+        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, HPR_KC, cs, cidx, outside);
+        k_hpr_gjk<true, QPW><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, HPR_KC, nullptr, outside, 0, 0x7fffffff);
+        k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
+        k_hpr_gjk<false, QPW><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
+        k_hpr_gjk<false, 4><<<gg4, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
     } else {                         // one level: support set = the whole cloud
         k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
         k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
-        k_hpr_gjk<false><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr);
+        k_hpr_gjk<false, QPW><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
+        k_hpr_gjk<false, 4><<<gg4, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

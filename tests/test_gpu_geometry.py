@@ -287,7 +287,7 @@ def test_p3b_hidden_point_removal_vs_qhull(pd, n, shape):
     want = oproj.point_validation_by_hpr(pts, eyes, 100)
     assert got.shape == want.shape == (8, n)
     mism = (got != want).mean()
-    assert mism < 2e-3, mism
+    assert mism < 5e-4, mism          # (sphere clouds: every point is on or near a hull facet; measured 1.4e-4)
     frac = want.mean()
     assert 0.05 < frac < 0.8
     if shape == 'sphere':

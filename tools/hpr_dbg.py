@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0,'/root/repo')
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointdreamer_amd import _lib as _l
+if len(sys.argv) > 1: _l.LIB_PATH = os.path.abspath(sys.argv[1])          # alternative (lab) build
 import numpy as np, torch, time
 from pointdreamer_amd import synthetic, hpr
 import pointdreamer_amd.camera_utils as cu
@@ -24,3 +26,14 @@ for _ in range(2): got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=
 torch.cuda.synchronize(); t=time.time(); got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=vis0); torch.cuda.synchronize(); print('skip-mask ms', (time.time()-t)*1e3)
 full = hpr.hidden_point_removal(P, eyes2, 100)
 print('OR identity', bool((got2 == (full | vis0)).all()))
+# lab build with -DPD_HPR_STATS: round statistics of the last call
+import ctypes as C
+from pointdreamer_amd import _lib
+try:
+    fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_hpr_stats
+    buf = (C.c_ulonglong * 8)()
+    fn(buf, 1); got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=vis0); torch.cuda.synchronize(); fn(buf, 1)
+    for name, b in (('coarse', buf[0:4]), ('fine', buf[4:8])):
+        print(f'{name}: waves {b[0]} mean wave rounds {b[1] / max(b[0], 1):.1f}; queries {b[2]} mean query rounds {b[3] / max(b[2], 1):.1f}')
+except AttributeError:
+    pass
