@@ -173,7 +173,7 @@ def main():
         roofline = dict(bound="hbm", kernel="n/a (nearest workload: sub-millisecond HBM-bound kernels)", achieved=None, peak=8000.0,
                         unit="GB/s", frac=None, traffic=None)
     if rank == 0:
-        out = dict(metric="shapes/hour (30k-pt cloud, 8x256^2 views, DDNM) on MI355X", value=value, unit="shapes/hour",
+        out = dict(metric=f"shapes/hour (30k-pt cloud, 8x256^2 views, {'DDNM' if args.workload == 'ddnm' else 'nearest inpainting, no diffusion'}) on MI355X", value=value, unit="shapes/hour",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
                    higher_is_better=True, scaling="weak" if args.parallel == 'shapes' else "strong", vs_baseline=None,
                    dtype="f16 (f32 accumulate; f32 GroupNorm/softmax statistics, f32 geometry)", data="synthetic",

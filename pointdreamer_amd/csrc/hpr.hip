@@ -10,9 +10,12 @@
 // SoA, L2-resident: 24 N bytes per view) and evaluate the 16 search directions against every point (48 f64 FMAs per
 // 24 bytes), the 16 GJK states live in lanes 0-15.  Work: ~10 rounds x N^2 x 3 FMA per view (f64 vector rate bound).
 // Two levels: ALL points are first tested against a COARSE support set -- the KC extreme points of the flipped cloud in KC
-// Fibonacci-sphere directions (one streaming pass).  conv(subset) is inside conv(cloud), so "origin enclosed" there is already
-// the final answer (hidden).  A point strictly inside conv(subset) is also never a support point of the full cloud, so the
-// second level -- only for the queries the coarse hull cannot enclose -- scans just the OUTSIDE set (~40 % of the cloud).  30 k points x 8 views: 88 -> 27 ms for all points, 48 -> 12.5 ms behind the depth-test skip mask
+// Fibonacci-sphere directions (one streaming pass; its members are certain hull vertices and are never queried).  conv(subset)
+// is inside conv(cloud), so "origin enclosed" there is already the final answer (hidden).  A point strictly inside conv(subset)
+// is also never a support point of the full cloud, so the second level -- only for the queries the coarse hull cannot enclose --
+// scans just the OUTSIDE set (~40 % of the cloud), compacted in cloud order so that the scan needs no index tie-break.  Short
+// query lists (the pipeline's case: only depth-rejected points are queried) run 4 queries per 256-lane block with the scan split
+// over the four waves.  30 k points x 8 views: 88 -> 15 ms for all points, 48 -> 2.6 ms behind the depth-test skip mask
 // (KC = 1024 measured best of 512..8192).
 // qhull's facet-merging tolerances are not reproduced (PARITY UNPINNED, open3d absent): points within ~1e-9 of a hull
 // facet may be classified differently; tests bound the disagreement with scipy's qhull.
@@ -26,10 +29,10 @@ using namespace pdhip;
 #define HPR_NARROW_BELOW 4096   // query lists shorter than this (per view) run 4 queries per wavefront instead of 16
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
-__device__ unsigned long long g_hpr_stats[2][4];              // [pass][waves, wave rounds, queries, query rounds]
+__device__ unsigned long long g_hpr_stats[2][16];             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
 extern "C" int pdhip_lab_hpr_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hpr_stats), sizeof(g_hpr_stats)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_stats), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -78,17 +81,19 @@ __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __re
 }
 
 // Support set = ss[v][3][scap] (first `ns` entries valid) with original cloud indices sidx[v][scap].
-// Q = queries per wavefront (16 when there are enough queries to fill the chip; 4 for short lists, where the kernel time is the
-// longest wave's rounds x scan length and a narrower wave scans 4x faster).
+// Q = queries per wavefront (16 when there are enough queries to fill the chip; short lists -- where the kernel time is the
+// longest query's rounds x the scan length -- use Q = 4 with COOP: 4 queries per 256-lane block, 16x shorter scans).
 // COARSE: every point of the cloud is a query (ns = scap = KC extreme points); writes outside[v][q] = origin not enclosed.
 // !COARSE: queries from list / count, support set = the points outside the coarse hull (ns = scount[v]); writes vis.
-template <bool COARSE, int Q>
-__global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+template <bool COARSE, int Q, bool COOP>
+__global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                  const int* __restrict__ list, uint8_t* __restrict__ vis,
                                                  const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
                                                  const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi) {
     __shared__ double s_dir[4][Q][3];
     __shared__ int s_q[4][Q];
+    __shared__ double s_rv[2][4][Q];                            // COOP: per-wave partial argmax of the round (double-buffered)
+    __shared__ int s_ri[2][4][Q];
     const int v = blockIdx.y;
     const double* qfx = flipped + (size_t)v * 3 * N;          // the queries' own coordinates
     const double* qfy = qfx + N;
@@ -99,20 +104,27 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
     const int* sidx = sidx_all + (size_t)v * scap;
     const int NS = COARSE ? scap : scount[v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = (blockIdx.x * 4 + wave) * Q;
+    // COOP: the four waves of the block own the SAME Q queries, scan a quarter of the support set each and merge through LDS
+    // (all four run the identical state machine on the merged result): a round is 4x shorter, which is what bounds the
+    // kernel when the query list is short and a few queries need 40-60 rounds.
+    const int q0 = COOP ? blockIdx.x * Q : (blockIdx.x * 4 + wave) * Q;
     const int nq = COARSE ? N : count[v];
     if (q0 >= nq || nq < q_lo || nq >= q_hi) return;        // (q_lo, q_hi: which launch geometry serves this view's query count)
-    bool owner = lane < Q && q0 + lane < nq;
-    const int q = owner ? (COARSE ? q0 + lane : list[(size_t)v * N + q0 + lane]) : -1;
+    // query k of the wave lives in lane k * ST (the lane the halving reduction below leaves its support point in)
+    constexpr int ST = 64 / Q;
+    const int kq = lane / ST;
+    const bool slot = (lane % ST) == 0;
+    bool owner = slot && q0 + kq < nq;
+    const int q = owner ? (COARSE ? q0 + kq : list[(size_t)v * N + q0 + kq]) : -1;
     // coarse pass: a point of the coarse set itself is an extreme point of the cloud -- a certain hull vertex, marked 2 by
     // k_hpr_extremes, never queried (so no query of this pass is a member of its own support set)
     if (COARSE && owner && outside[(size_t)v * N + q] == 2) owner = false;
-    if (lane < Q) s_q[wave][lane] = q;
+    if (slot) s_q[wave][kq] = q;
     __builtin_amdgcn_wave_barrier();
     int qk[Q];
 #pragma unroll
     for (int k = 0; k < Q; ++k) qk[k] = s_q[wave][k];
-    // ---- per-query GJK state (meaningful in lanes < Q)
+    // ---- per-query GJK state (meaningful in the slot lanes)
     d3 pi = {0, 0, 0}, sa = {0, 0, 0}, sb = {0, 0, 0}, sc = {0, 0, 0}, sd = {0, 0, 0}, dir = {0, 0, 1};
     int dim = 0;                   // simplex size; phases: 0 -> fetch c, 1 -> fetch b, >= 2 -> main loop
     int state = owner ? 0 : 2;     // 0 running, 1 visible (origin outside), 2 hidden / not a query
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
 #ifdef PD_HPR_STATS
         ++wave_rounds; if (state == 0) ++my_rounds;
 #endif
-        if (lane < Q) { s_dir[wave][lane][0] = dir.x; s_dir[wave][lane][1] = dir.y; s_dir[wave][lane][2] = dir.z; }
+        if (slot) { s_dir[wave][kq][0] = dir.x; s_dir[wave][kq][1] = dir.y; s_dir[wave][kq][2] = dir.z; }
         __builtin_amdgcn_wave_barrier();
         double dx[Q], dy[Q], dz[Q], best[Q];
         int bi[Q];                                                 // position in the support set
@@ -143,11 +155,13 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
         // (the next point is requested before the current one is evaluated: two waves per SIMD do not hide an L2 round trip)
         double nx = 0.0, ny = 0.0, nz = 0.0;
         int njo = -1;
-        if (lane < NS) { nx = fx[lane]; ny = fy[lane]; nz = fz[lane]; if (!COARSE) njo = sidx[lane]; }
-        for (int j = lane; j < NS; j += 64) {
+        constexpr int JS = COOP ? 256 : 64;
+        const int j0 = COOP ? wave * 64 + lane : lane;
+        if (j0 < NS) { nx = fx[j0]; ny = fy[j0]; nz = fz[j0]; if (!COARSE) njo = sidx[j0]; }
+        for (int j = j0; j < NS; j += JS) {
             const double x = nx, y = ny, z = nz;
             const int jo = njo;
-            const int jn = j + 64;
+            const int jn = j + JS;
             if (jn < NS) { nx = fx[jn]; ny = fy[jn]; nz = fz[jn]; if (!COARSE) njo = sidx[jn]; }
             if (COARSE) {
 #pragma unroll
@@ -163,20 +177,44 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
                 }
             }
         }
-        double myv = -1.0e300;
-        int myi = 0x7fffffff;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            double b = best[k];
-            int id = bi[k];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ob = __shfl_xor(b, off);
-                const int oi = __shfl_xor(id, off);
-                if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
-            }
-            if (lane == k) { myv = b; myi = id; }
+        // ---- Q argmax reductions over the 64 lanes at once: every step swaps one half of the still-live queries with the
+        // partner lane and keeps the other half (Q-1 exchanged items instead of 6 Q), then plain butterflies inside the ST
+        // lanes that end up holding the same query.  Equal values: smaller position.
+#define HPR_HALVE(I)                                                                                                  \
+        if constexpr ((Q >> (I)) > 1) {                                                                               \
+            constexpr int off = 32 >> (I), n = Q >> (I);                                                              \
+            const bool hi = (lane & off) != 0;                                                                        \
+            _Pragma("unroll") for (int k = 0; k < n / 2; ++k) {                                                       \
+                const double send = hi ? best[k] : best[k + n / 2], keep = hi ? best[k + n / 2] : best[k];            \
+                const int sendi = hi ? bi[k] : bi[k + n / 2], keepi = hi ? bi[k + n / 2] : bi[k];                     \
+                const double ob = __shfl_xor(send, off);                                                              \
+                const int oi = __shfl_xor(sendi, off);                                                                \
+                const bool take = ob > keep || (ob == keep && oi < keepi);                                            \
+                best[k] = take ? ob : keep; bi[k] = take ? oi : keepi;                                                \
+            }                                                                                                         \
         }
+        HPR_HALVE(0) HPR_HALVE(1) HPR_HALVE(2) HPR_HALVE(3)
+#undef HPR_HALVE
+#pragma unroll
+        for (int off = ST / 2; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best[0], off);
+            const int oi = __shfl_xor(bi[0], off);
+            if (ob > best[0] || (ob == best[0] && oi < bi[0])) { best[0] = ob; bi[0] = oi; }
+        }
+        if (COOP) {                                                  // merge the four quarters (ties: smaller position)
+            const int pb = round & 1;
+            if (slot) { s_rv[pb][wave][kq] = best[0]; s_ri[pb][wave][kq] = bi[0]; }
+            __syncthreads();
+            best[0] = s_rv[pb][0][kq]; bi[0] = s_ri[pb][0][kq];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double ob = s_rv[pb][w][kq];
+                const int oi = s_ri[pb][w][kq];
+                if (ob > best[0] || (ob == best[0] && oi < bi[0])) { best[0] = ob; bi[0] = oi; }
+            }
+        }
+        const double myv = best[0];
+        const int myi = bi[0];
         if (state == 0) {
             // support point of S_i in direction dir: best flipped point, or the origin of the flipped space (value 0)
             d3 a;
@@ -221,7 +259,9 @@ __global__ __launch_bounds__(256) void k_hpr_gjk(const double* __restrict__ flip
     }
 #ifdef PD_HPR_STATS
     if (lane == 0) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][0], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][1], (unsigned long long)wave_rounds); }
-    if (owner) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][2], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][3], (unsigned long long)my_rounds); }
+    if (owner) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][2], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][3], (unsigned long long)my_rounds);
+                 if (state == 0) atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][4], 1ull);
+                 atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][8 + min(my_rounds, 63) / 8], 1ull); }
 #endif
     if (!COARSE) {
         if (owner) vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
@@ -357,20 +397,20 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     PD_HIP(hipMemsetAsync(count2, 0, 64 * sizeof(int), s));
     PD_HIP(hipMemsetAsync(scount, 0, 64 * sizeof(int), s));
     k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);      // marks the skipped points visible; `list` = the queries
-    dim3 gg(cdiv(N, 4 * QPW), V), gg4(cdiv(min(N, HPR_NARROW_BELOW), 4 * 4), V);
+    dim3 gg(cdiv(N, 4 * QPW), V), gg4(cdiv(min(N, HPR_NARROW_BELOW), 4), V);
     if (N > 4 * HPR_KC) {            // the coarse level pays off only when the cloud is much larger than the coarse set
         dim3 ge(cdiv(HPR_KC, 4 * QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
         k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, HPR_KC, cs, cidx, outside);
-        k_hpr_gjk<true, QPW><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, HPR_KC, nullptr, outside, 0, 0x7fffffff);
+        k_hpr_gjk<true, QPW, false><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, HPR_KC, nullptr, outside, 0, 0x7fffffff);
         k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
-        k_hpr_gjk<false, QPW><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
-        k_hpr_gjk<false, 4><<<gg4, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
+        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
+        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
     } else {                         // one level: support set = the whole cloud
         k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
         k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
-        k_hpr_gjk<false, QPW><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
-        k_hpr_gjk<false, 4><<<gg4, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
+        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
+        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

@@ -31,9 +31,9 @@ import ctypes as C
 from pointdreamer_amd import _lib
 try:
     fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_hpr_stats
-    buf = (C.c_ulonglong * 8)()
+    buf = (C.c_ulonglong * 32)()
     fn(buf, 1); got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=vis0); torch.cuda.synchronize(); fn(buf, 1)
-    for name, b in (('coarse', buf[0:4]), ('fine', buf[4:8])):
-        print(f'{name}: waves {b[0]} mean wave rounds {b[1] / max(b[0], 1):.1f}; queries {b[2]} mean query rounds {b[3] / max(b[2], 1):.1f}')
+    for name, b in (('coarse', buf[0:16]), ('fine', buf[16:32])):
+        print(f'{name}: waves {b[0]} mean wave rounds {b[1] / max(b[0], 1):.1f}; queries {b[2]} mean query rounds {b[3] / max(b[2], 1):.1f}; unfinished {b[4]}; rounds histogram (x8) {list(b[8:16])}')
 except AttributeError:
     pass
