@@ -15,7 +15,7 @@
 // is also never a support point of the full cloud, so the second level -- only for the queries the coarse hull cannot enclose --
 // scans just the OUTSIDE set (~40 % of the cloud), compacted in cloud order so that the scan needs no index tie-break.  Short
 // query lists (the pipeline's case: only depth-rejected points are queried) run 4 queries per 256-lane block with the scan split
-// over the four waves.  30 k points x 8 views: 88 -> 15 ms for all points, 48 -> 2.6 ms behind the depth-test skip mask
+// over the four waves.  30 k points x 8 views: 88 -> 15 ms for all points, 48 -> 2.4 ms behind the depth-test skip mask
 // (KC = 1024 measured best of 512..8192).
 // qhull's facet-merging tolerances are not reproduced (PARITY UNPINNED, open3d absent): points within ~1e-9 of a hull
 // facet may be classified differently; tests bound the disagreement with scipy's qhull.
@@ -89,7 +89,8 @@ template <bool COARSE, int Q, bool COOP>
 __global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                  const int* __restrict__ list, uint8_t* __restrict__ vis,
                                                  const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
-                                                 const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi) {
+                                                 const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi,
+                                                    const uint8_t* __restrict__ skip) {
     __shared__ double s_dir[4][Q][3];
     __shared__ int s_q[4][Q];
     __shared__ double s_rv[2][4][Q];                            // COOP: per-wave partial argmax of the round (double-buffered)
@@ -119,6 +120,10 @@ __global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ f
     // coarse pass: a point of the coarse set itself is an extreme point of the cloud -- a certain hull vertex, marked 2 by
     // k_hpr_extremes, never queried (so no query of this pass is a member of its own support set)
     if (COARSE && owner && outside[(size_t)v * N + q] == 2) owner = false;
+    // ... and a point the cheaper test already accepted needs no verdict of its own: it joins the second-level support set
+    // unexamined (any superset of the outside set inside the cloud is a valid support set; depth-visible points are almost all
+    // outside anyway), which removes a third of the coarse queries
+    if (COARSE && owner && skip != nullptr && skip[(size_t)v * N + q]) { outside[(size_t)v * N + q] = 1; owner = false; }
     if (slot) s_q[wave][kq] = q;
     __builtin_amdgcn_wave_barrier();
     int qk[Q];
@@ -398,19 +403,20 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     PD_HIP(hipMemsetAsync(scount, 0, 64 * sizeof(int), s));
     k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);      // marks the skipped points visible; `list` = the queries
     dim3 gg(cdiv(N, 4 * QPW), V), gg4(cdiv(min(N, HPR_NARROW_BELOW), 4), V);
+    constexpr int KC = HPR_KC;
     if (N > 4 * HPR_KC) {            // the coarse level pays off only when the cloud is much larger than the coarse set
-        dim3 ge(cdiv(HPR_KC, 4 * QPW), V);
+        dim3 ge(cdiv(KC, 4 * QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
-        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, HPR_KC, cs, cidx, outside);
-        k_hpr_gjk<true, QPW, false><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, HPR_KC, nullptr, outside, 0, 0x7fffffff);
+        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, cs, cidx, outside);
+        k_hpr_gjk<true, QPW, false><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip);
         k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
-        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
-        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
+        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr);
+        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr);
     } else {                         // one level: support set = the whole cloud
         k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
         k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
-        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff);
-        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW);
+        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr);
+        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
