@@ -163,7 +163,8 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv.json')
         if os.path.exists(pmc):          # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh)
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+            pj = json.load(open(pmc))                 # per-launch bytes depend on the UNet batch: only quoted for the batch it was measured at
+            traffic = pj.get('hbm_bytes_per_launch') if pj.get('shapes_per_step', 1) == SPS else None
         roofline = dict(bound="mfma", kernel="k_conv3x3_halo (3x3 conv of the 64^2/128^2/256^2 levels, LDS-resident activation halo, f16 in / f32 acc)", achieved=achieved,
                         peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=traffic,
                         launches=int(launches), avg_launch_ms=ms / max(launches, 1),

@@ -3,6 +3,7 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  -- FETCH_SIZE / WRI
 rocprofv3, FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads (MI355X_MICROARCH.md, HBM section): doubled."""
 import csv, glob, json, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_bench'
+sps = int(sys.argv[3]) if len(sys.argv) > 3 else 4      # --shapes-per-step of the profiled bench.py command (its default)
 out = {}
 for f in glob.glob(root + '/*/pmc_counter_collection.csv'):
     acc = collections.defaultdict(list)
@@ -11,10 +12,10 @@ for f in glob.glob(root + '/*/pmc_counter_collection.csv'):
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in acc.items():
         out[k] = dict(avg=sum(v) / len(v), launches=len(v), total=sum(v))
-res = dict(counters=out)
+res = dict(counters=out, shapes_per_step=sps)
 if 'FETCH_SIZE' in out and 'WRITE_SIZE' in out:
     res['hbm_bytes_per_launch'] = (2 * out['FETCH_SIZE']['avg'] + out['WRITE_SIZE']['avg']) * 1024
-    res['note'] = "avg over all k_conv3x3_halo<...> dispatches of `bench.py --steps 1 --warmup 0 --ddnm-steps 2`; FETCH_SIZE doubled (gfx950 correction)"
+    res['note'] = "avg over all k_conv3x3_halo<...> dispatches of `bench.py --steps 1 --warmup 0 --ddnm-steps 2` (" + str(sps) + " shapes per step = " + str(8 * sps) + " views per UNet batch); FETCH_SIZE doubled (gfx950 correction)"
 if 'SQ_VALU_MFMA_BUSY_CYCLES' in out and 'GRBM_GUI_ACTIVE' in out:
     # gfx94x MfmaUtil formula: MFMA busy cycles / (GUI_ACTIVE x CUs x 4 SIMDs); rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs
     res['mfma_util'] = out['SQ_VALU_MFMA_BUSY_CYCLES']['total'] / (out['GRBM_GUI_ACTIVE']['total'] / 8 * 256 * 4)
