@@ -70,9 +70,21 @@ def prepare(cfg_file, device, ckpt_path=None, allow_random_weights=False, overri
     return cfg, inpainter, camera_info, logger
 
 
+_STANDIN = {}
+
+
 def standin_geometry(xyz, atlas_res, device, logger):
-    """No mesh next to the PLY and no POCO here: UV sphere (radius 0.5 = the normalised cloud's half extent) + analytic atlas."""
+    """No mesh next to the PLY and no POCO here: UV sphere (radius 0.5 = the normalised cloud's half extent) + analytic atlas.
+    The same for every cloud, so a directory run builds it once per (atlas_res, device)."""
     logger.warning('no <pc>_untextured_mesh.obj supplied: using the stand-in UV sphere geometry (POCO/SPR/xatlas are upstream)')
+    key = (int(atlas_res), str(device))
+    if key not in _STANDIN:
+        _STANDIN[key] = _standin_geometry(atlas_res, device)
+    v, f, d = _STANDIN[key]
+    return v.clone(), f.clone(), {k: t.clone() for k, t in d.items()}
+
+
+def _standin_geometry(atlas_res, device):
     verts, faces, lut = synthetic.uv_sphere(50, 100)
     gb_pos, mask, fid = synthetic.latlong_atlas(atlas_res, 50, 100, lut=lut)
     # per-corner UVs of the lat-long parametrisation (one vt per face corner, like xatlas' unshared output)
@@ -172,12 +184,18 @@ def main(argv=None):
     pc_files = [args.pc_file] if args.pc_file.endswith('.ply') else \
         [os.path.join(args.pc_file, i) for i in sorted(os.listdir(args.pc_file)) if i.endswith('.ply')]
     outs = []
-    for pc_file in pc_files:
-        name = os.path.basename(pc_file).split('.ply')[0] + '_' + os.path.basename(args.config).split('.')[0]
-        os.makedirs(os.path.join(cfg.output_path, name), exist_ok=True)
-        shutil.copy(args.config, os.path.join(cfg.output_path, name, 'config.yaml'))
-        logger.info(f'Start Recon {pc_file}...')
-        outs.append(recon_one_textured_mesh(cfg, inpainter, camera_info, pc_file, name, device, logger))
+    # PNG / OBJ encoding of one shape runs on host threads under the GPU work of the next (io_utils.set_async); every file is on
+    # disk when main() returns
+    io_utils.set_async(True)
+    try:
+        for pc_file in pc_files:
+            name = os.path.basename(pc_file).split('.ply')[0] + '_' + os.path.basename(args.config).split('.')[0]
+            os.makedirs(os.path.join(cfg.output_path, name), exist_ok=True)
+            shutil.copy(args.config, os.path.join(cfg.output_path, name, 'config.yaml'))
+            logger.info(f'Start Recon {pc_file}...')
+            outs.append(recon_one_textured_mesh(cfg, inpainter, camera_info, pc_file, name, device, logger))
+    finally:
+        io_utils.set_async(False)          # flushes
     return outs
 
 

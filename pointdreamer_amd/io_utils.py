@@ -29,11 +29,55 @@ def _u8_hwc(img, channels):
     return arr
 
 
+# ---- deferred writes.  The encoders are native calls that release the GIL, so a directory run (demo.py over many clouds) can
+# overlap the PNG / OBJ encoding of one shape with the GPU work of the next: `set_async(True)` queues the encode + write on a
+# small thread pool (the pixel data has already been converted and copied to the host), `flush()` waits and re-raises the first
+# error.  Default is synchronous: the file exists when the save function returns, as in the reference.
+_pool = None
+_pending = []
+
+
+def set_async(on, workers=8):
+    global _pool
+    flush()
+    if on and _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix='pdhip-io')
+    elif not on and _pool is not None:
+        _pool.shutdown(wait=True)
+        _pool = None
+
+
+def flush():
+    """Wait for every queued write; raises the first failure."""
+    global _pending
+    todo, _pending = _pending, []
+    err = None
+    for f in todo:
+        try:
+            f.result()
+        except Exception as e:          # noqa: BLE001 -- re-raised below, after every write has been waited for
+            err = err or e
+    if err is not None:
+        raise err
+
+
+def _submit(fn):
+    if _pool is None:
+        fn()
+    else:
+        _pending.append(_pool.submit(fn))
+
+
 def _save_png(img, file_name, channels):
     L = _lib.lib()
     arr = _u8_hwc(img, channels)
-    _lib.check(L.pdhip_io_write_png(os.fspath(file_name).encode(), arr.ctypes.data_as(C.c_void_p), arr.shape[0], arr.shape[1],
-                                    channels, 1), 'pdhip_io_write_png')
+    path = os.fspath(file_name).encode()
+
+    def write():
+        _lib.check(L.pdhip_io_write_png(path, arr.ctypes.data_as(C.c_void_p), arr.shape[0], arr.shape[1], channels, 1),
+                   'pdhip_io_write_png')
+    _submit(write)
 
 
 def save_CHW_RGB_img(img, file_name):
@@ -119,5 +163,9 @@ def savemeshtes2(pointnp_px3, tcoords_px2, facenp_fx3, facetex_fx3, fname):
     f1 = np.ascontiguousarray(facenp_fx3, np.int64)
     f2 = np.ascontiguousarray(facetex_fx3, np.int64)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
-    _lib.check(L.pdhip_io_write_obj_mtl(os.fspath(fname).encode(), os.path.join(fol, 'model_normalized.mtl').encode(), na.encode(),
-                                        vp(pts), len(pts), vp(tcs), len(tcs), vp(f1), vp(f2), len(f1)), 'pdhip_io_write_obj_mtl')
+    obj, mtl = os.fspath(fname).encode(), os.path.join(fol, 'model_normalized.mtl').encode()
+
+    def write():
+        _lib.check(L.pdhip_io_write_obj_mtl(obj, mtl, na.encode(), vp(pts), len(pts), vp(tcs), len(tcs), vp(f1), vp(f2), len(f1)),
+                   'pdhip_io_write_obj_mtl')
+    _submit(write)

@@ -3,6 +3,8 @@
 import os
 import numpy as np
 import PIL.Image
+import pytest
+import torch
 from pointdreamer_amd import io_utils
 
 
@@ -97,3 +99,40 @@ def test_native_ply_reader_ascii_and_extra_properties(tmp_path):
                 b"property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" + v.tobytes())
     xyz, rgb = io_utils.read_ply_xyzrgb(q)
     assert np.array_equal(xyz, np.array([[0.25, 1, 3], [-3.5, 2, 4]], np.float32)) and np.array_equal(rgb, np.array([[9, 7, 5], [8, 6, 4]], np.uint8))
+
+
+def test_native_png_parallel_strips_decode_to_the_same_pixels(tmp_path):
+    """Images of 512 KiB and more are deflated in parallel strips (pigz-style concatenation): still one valid zlib stream."""
+    import PIL.Image
+    rng = np.random.default_rng(5)
+    for ch, h, w in ((3, 1024, 1024), (4, 700, 333), (3, 419, 419)):          # 419*420*3 = just above the threshold
+        a = rng.random((ch, h, w)).astype(np.float32)
+        a[:, : h // 3] = 0.25                                                   # compressible and incompressible strips
+        f = str(tmp_path / f"big{ch}_{h}.png")
+        (io_utils.save_CHW_RGB_img if ch == 3 else io_utils.save_CHW_RGBA_img)(torch.from_numpy(a), f)
+        want = (a.transpose(1, 2, 0) * 255.0).clip(0, 255).astype(np.uint8)
+        assert np.array_equal(np.array(PIL.Image.open(f)), want)
+
+
+def test_deferred_writes_land_on_flush_and_report_errors(tmp_path):
+    import PIL.Image
+    rng = np.random.default_rng(6)
+    imgs = [rng.random((3, 64, 80)).astype(np.float32) for _ in range(12)]
+    io_utils.set_async(True, workers=4)
+    try:
+        for i, a in enumerate(imgs):
+            io_utils.save_CHW_RGB_img(torch.from_numpy(a), str(tmp_path / f"{i}.png"))
+        v = rng.random((5, 3)); uv = rng.random((5, 2)); f = np.array([[0, 1, 2], [2, 3, 4]])
+        io_utils.savemeshtes2(v, uv, f, f, str(tmp_path / "m.obj"))
+        io_utils.flush()
+        for i, a in enumerate(imgs):
+            assert np.array_equal(np.array(PIL.Image.open(tmp_path / f"{i}.png")), (a.transpose(1, 2, 0) * 255.0).clip(0, 255).astype(np.uint8))
+        assert (tmp_path / "m.obj").exists() and (tmp_path / "model_normalized.mtl").exists()
+        io_utils.save_CHW_RGB_img(torch.from_numpy(imgs[0]), str(tmp_path / "no_such_dir" / "x.png"))
+        with pytest.raises(Exception):
+            io_utils.flush()
+    finally:
+        io_utils.set_async(False)
+    # back to synchronous: the file exists on return
+    io_utils.save_CHW_RGB_img(torch.from_numpy(imgs[0]), str(tmp_path / "sync.png"))
+    assert (tmp_path / "sync.png").exists()
