@@ -146,25 +146,55 @@ __global__ void k_oc_fill(const float* __restrict__ uv_map, const uint8_t* __res
     }
 }
 
-// contributions of one texel in ascending pixel order (the cursor order above is a race): insertion sort, lists are short
-__global__ void k_oc_sort(const int* __restrict__ off, const int* __restrict__ cnt, int ntex, int* __restrict__ e_pix,
-                          double* __restrict__ e_w) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x) {
-        const int b = off[t], n = cnt[t];
-        for (int i = 1; i < n; ++i) {
-            const int kp = e_pix[b + i]; const double kw = e_w[b + i];
-            int j = i - 1;
-            while (j >= 0 && e_pix[b + j] > kp) { e_pix[b + j + 1] = e_pix[b + j]; e_w[b + j + 1] = e_w[b + j]; --j; }
-            e_pix[b + j + 1] = kp; e_w[b + j + 1] = kw;
+// contributions of one texel in ascending pixel order (the cursor order above is a race): insertion sort, lists are short.
+// One wave owns 64 consecutive texels, whose lists are one contiguous CSR range: the range is staged through LDS (coalesced
+// loads and stores), every lane sorts its own list there.  Ranges longer than OC_SORT_CAP fall back to sorting in global memory.
+#define OC_SORT_CAP 3072
+__global__ __launch_bounds__(64) void k_oc_sort(const int* __restrict__ off, const int* __restrict__ cnt, int ntex,
+                                                int* __restrict__ e_pix, double* __restrict__ e_w) {
+    __shared__ int s_p[OC_SORT_CAP];
+    __shared__ double s_w[OC_SORT_CAP];
+    const int lane = threadIdx.x;
+    for (int t0 = blockIdx.x * 64; t0 < ntex; t0 += gridDim.x * 64) {
+        const int t = t0 + lane;
+        const int b = t < ntex ? off[t] : 0, n = t < ntex ? cnt[t] : 0;
+        const int tl = min(t0 + 63, ntex - 1);
+        const int R0 = off[t0], R1 = off[tl] + cnt[tl], len = R1 - R0;
+        if (len <= OC_SORT_CAP) {
+            for (int i = lane; i < len; i += 64) { s_p[i] = e_pix[R0 + i]; s_w[i] = e_w[R0 + i]; }
+            __syncthreads();
+            const int lb = b - R0;
+            for (int i = 1; i < n; ++i) {
+                const int kp = s_p[lb + i]; const double kw = s_w[lb + i];
+                int j = i - 1;
+                while (j >= 0 && s_p[lb + j] > kp) { s_p[lb + j + 1] = s_p[lb + j]; s_w[lb + j + 1] = s_w[lb + j]; --j; }
+                s_p[lb + j + 1] = kp; s_w[lb + j + 1] = kw;
+            }
+            __syncthreads();
+            for (int i = lane; i < len; i += 64) { e_pix[R0 + i] = s_p[i]; e_w[R0 + i] = s_w[i]; }
+            __syncthreads();
+        } else {
+            for (int i = 1; i < n; ++i) {
+                const int kp = e_pix[b + i]; const double kw = e_w[b + i];
+                int j = i - 1;
+                while (j >= 0 && e_pix[b + j] > kp) { e_pix[b + j + 1] = e_pix[b + j]; e_w[b + j + 1] = e_w[b + j]; --j; }
+                e_pix[b + j + 1] = kp; e_w[b + j + 1] = kw;
+            }
         }
     }
 }
 
 // forward: sign of the L1 residual per masked pixel and channel (0 where the clamp or the residual kills the gradient)
-__global__ __launch_bounds__(256) void k_oc_forward(const float* __restrict__ atlas, int A, const float* __restrict__ uv_map, int V,
+// interleaved copy of the atlas being optimised (x, y, z = the three planes): the forward pass fetches a corner with one 16-byte
+// gather instead of three 4-byte ones; the backward pass keeps it in step with the planar parameter
+__global__ void k_oc_pack(const float* __restrict__ atlas, int ntex, float4* __restrict__ at4) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x)
+        at4[t] = make_float4(atlas[t], atlas[(size_t)ntex + t], atlas[2 * (size_t)ntex + t], 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ at4, int A, const float* __restrict__ uv_map, int V,
                                                     int res, const float* __restrict__ target, const uint8_t* __restrict__ wmask,
                                                     int8_t* __restrict__ sgn /*[V*res*res][4]*/, float* __restrict__ images) {
-    const size_t plane = (size_t)A * A;
     const long long total = (long long)V * res * res;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
         const int v = (int)(p / ((long long)res * res)), idx = (int)(p - (long long)v * res * res);
@@ -176,10 +206,11 @@ __global__ __launch_bounds__(256) void k_oc_forward(const float* __restrict__ at
         int tex[4]; double wt[4];
         const int n = oc_corners(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, tex, wt);
         char4 sg = make_char4(0, 0, 0, 0);
+        float4 cor[4];
+        for (int k = 0; k < n; ++k) cor[k] = at4[tex[k]];
         for (int c = 0; c < 3; ++c) {
-            const float* at = atlas + (size_t)c * plane;
             double val = 0.0;
-            for (int k = 0; k < n; ++k) val += wt[k] * (double)at[tex[k]];
+            for (int k = 0; k < n; ++k) val += wt[k] * (double)(c == 0 ? cor[k].x : (c == 1 ? cor[k].y : cor[k].z));
             const bool pass = val >= 0.0 && val <= 1.0;                 // clamp backward is inclusive
             const double img = fmin(fmax(val, 0.0), 1.0);
             if (images) images[(((size_t)v * 3 + c) * res + y) * res + x] = (float)img;
@@ -191,42 +222,57 @@ __global__ __launch_bounds__(256) void k_oc_forward(const float* __restrict__ at
     }
 }
 
-// backward + torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay; single-tensor update order), per texel
-__global__ __launch_bounds__(256) void k_oc_backward_adam(const int* __restrict__ off, const int* __restrict__ cnt,
-                                                          const int* __restrict__ e_pix, const double* __restrict__ e_w,
-                                                          const int8_t* __restrict__ sgn, double inv_count, float* __restrict__ param,
-                                                          float* __restrict__ m, float* __restrict__ vv, int ntex, float step_size,
-                                                          float bc2_sqrt) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x) {
-        const int b = off[t], n = cnt[t];
+// backward + torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay; single-tensor update order), per texel.
+// One wave owns 64 consecutive texels = one contiguous CSR range.  The range is streamed through LDS in chunks: 64 lanes load
+// (pixel, weight) coalesced and gather the pixels' sign bytes with 64 independent requests in flight, then every lane adds the
+// entries of its own list that fall into the chunk, in list order (same f64 summation order as a plain per-texel walk).
+#define OC_BW_CHUNK 1024
+__global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__ off, const int* __restrict__ cnt,
+                                                         const int* __restrict__ e_pix, const double* __restrict__ e_w,
+                                                         const int8_t* __restrict__ sgn, double inv_count, float* __restrict__ param,
+                                                         float* __restrict__ m, float* __restrict__ vv, int ntex, float step_size,
+                                                         float bc2_sqrt, float4* __restrict__ at4) {
+    __shared__ double sw[OC_BW_CHUNK];                         // one wave per workgroup: the barriers below are wave-local
+    __shared__ char4 ss[OC_BW_CHUNK];
+    const int lane = threadIdx.x;
+    for (int t0 = blockIdx.x * 64; t0 < ntex; t0 += gridDim.x * 64) {
+        const int t = t0 + lane;
+        const int b = t < ntex ? off[t] : 0, n = t < ntex ? cnt[t] : 0;
+        const int tl = min(t0 + 63, ntex - 1);
+        const int R0 = off[t0], R1 = off[tl] + cnt[tl];
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-        int k = 0;
-        for (; k + 4 <= n; k += 4) {                                    // 4 independent index -> sign gathers in flight
-            int px[4]; double w[4]; char4 sg[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { px[u] = e_pix[b + k + u]; w[u] = e_w[b + k + u]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sg[u] = reinterpret_cast<const char4*>(sgn)[px[u]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                               // same order as the plain loop
-                const double wi = w[u] * inv_count;                     // = w * (+-1/count), as the scatter form adds it
-                g0 += wi * (double)sg[u].x; g1 += wi * (double)sg[u].y; g2 += wi * (double)sg[u].z;
+        int cur = b;
+        const int e = b + n;
+        for (int c0 = R0; c0 < R1; c0 += OC_BW_CHUNK) {
+            const int len = min(OC_BW_CHUNK, R1 - c0);
+            for (int i = lane; i < len; i += 64) {
+                const int px = e_pix[c0 + i];
+                sw[i] = e_w[c0 + i];
+                ss[i] = reinterpret_cast<const char4*>(sgn)[px];
             }
+            __syncthreads();
+            const int stop = min(e, c0 + len);
+            for (; cur < stop; ++cur) {
+                const char4 sg = ss[cur - c0];
+                const double wi = sw[cur - c0] * inv_count;                 // = w * (+-1/count), as the scatter form adds it
+                g0 += wi * (double)sg.x; g1 += wi * (double)sg.y; g2 += wi * (double)sg.z;
+            }
+            __syncthreads();
         }
-        for (; k < n; ++k) {
-            const char4 sg = reinterpret_cast<const char4*>(sgn)[e_pix[b + k]];
-            const double w = e_w[b + k] * inv_count;
-            g0 += w * (double)sg.x; g1 += w * (double)sg.y; g2 += w * (double)sg.z;
-        }
-        const double gs[3] = {g0, g1, g2};
-        for (int c = 0; c < 3; ++c) {
-            const size_t i = (size_t)c * ntex + t;
-            const float g = (float)gs[c];
-            const float mi = m[i] + (g - m[i]) * (1.0f - 0.9f);
-            const float vi = vv[i] * 0.999f + (g * g) * (1.0f - 0.999f);
-            m[i] = mi; vv[i] = vi;
-            const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
-            param[i] = param[i] + (-step_size) * (mi / denom);
+        if (t < ntex) {
+            const double gs[3] = {g0, g1, g2};
+            float np[3];
+            for (int c = 0; c < 3; ++c) {
+                const size_t i = (size_t)c * ntex + t;
+                const float g = (float)gs[c];
+                const float mi = m[i] + (g - m[i]) * (1.0f - 0.9f);
+                const float vi = vv[i] * 0.999f + (g * g) * (1.0f - 0.999f);
+                m[i] = mi; vv[i] = vi;
+                const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
+                np[c] = param[i] + (-step_size) * (mi / denom);
+                param[i] = np[c];
+            }
+            at4[t] = make_float4(np[0], np[1], np[2], 0.f);
         }
     }
 }
@@ -235,7 +281,8 @@ static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t pdhip_optimize_color_ws_bytes(int V, int res, int A) {
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
     return a256(px * 3 * 4) /*target*/ + a256(px) /*wmask*/ + a256(px * 4) /*sgn*/ + 2 * a256(tx * 3 * 4) /*m, v*/ +
-           3 * a256((tx + 4096) * 4) /*cnt, off, cursor*/ + a256(4096 * 4) /*block sums*/ + a256(px * 4 * 4) /*e_pix*/ + a256(px * 4 * 8) /*e_w*/;
+           3 * a256((tx + 4096) * 4) /*cnt, off, cursor*/ + a256(4096 * 4) /*block sums*/ + a256(px * 4 * 4) /*e_pix*/ + a256(px * 4 * 8) /*e_w*/ +
+           a256(tx * 16) /*interleaved atlas*/;
 }
 
 extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, const float* uv_map, const int64_t* face_idxs, int V,
@@ -257,7 +304,8 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
     int* cursor = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
     int* bsum = reinterpret_cast<int*>(p); p += a256(4096 * 4);
     int* e_pix = reinterpret_cast<int*>(p); p += a256(px * 4 * 4);
-    double* e_w = reinterpret_cast<double*>(p);
+    double* e_w = reinterpret_cast<double*>(p); p += a256(px * 4 * 8);
+    float4* at4 = reinterpret_cast<float4*>(p);
     const long long n = 3LL * A * A;
     PD_HIP(hipMemsetAsync(m, 0, n * 4, s));
     PD_HIP(hipMemsetAsync(vv, 0, n * 4, s));
@@ -265,23 +313,24 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
     PD_HIP(hipMemsetAsync(cursor, 0, tx * 4, s));
     dim3 g(min(cdiv((long long)res * res, 256), 2048), V);
     k_optcolor_target<<<g, 256, 0, s>>>(inpainted, r, uv_map, face_idxs, res, shrinked, A, target, wmask);
-    const int gp = min(cdiv((long long)px, 256), 8192), gt = min(cdiv((long long)tx, 256), 8192);
+    const int gp = min(cdiv((long long)px, 256), 8192);
     const int nb = cdiv((long long)tx, 1024);
     k_oc_count<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, cnt);
     k_oc_scan1<<<nb, 1024, 0, s>>>(cnt, (int)tx, off, bsum);
     k_oc_scan2<<<1, 1024, 0, s>>>(bsum, nb);
     k_oc_scan3<<<nb, 1024, 0, s>>>(off, (int)tx, bsum);
     k_oc_fill<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, off, cursor, e_pix, e_w);
-    k_oc_sort<<<gt, 256, 0, s>>>(off, cnt, (int)tx, e_pix, e_w);
+    k_oc_sort<<<min(cdiv((long long)tx, 64), 16384), 64, 0, s>>>(off, cnt, (int)tx, e_pix, e_w);
+    k_oc_pack<<<min(cdiv((long long)tx, 256), 4096), 256, 0, s>>>(atlas, (int)tx, at4);
     const double inv_count = 1.0 / ((double)V * 3.0 * res * res);
     for (int it = 0; it < iterations; ++it) {
         const bool last = it == iterations - 1;
-        k_oc_forward<<<gp, 256, 0, s>>>(atlas, A, uv_map, V, res, target, wmask, sgn, last ? final_images : nullptr);
+        k_oc_forward<<<gp, 256, 0, s>>>(at4, A, uv_map, V, res, target, wmask, sgn, last ? final_images : nullptr);
         const int step = it + 1;
         const double cur_lr = lr * pow(0.5, (double)(it / 15));            // StepLR(step_size 15, gamma 0.5)
         const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
-        k_oc_backward_adam<<<gt, 256, 0, s>>>(off, cnt, e_pix, e_w, sgn, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
-                                              (float)sqrt(bc2));
+        k_oc_backward_adam<<<min(cdiv((long long)tx, 64), 16384), 64, 0, s>>>(off, cnt, e_pix, e_w, sgn, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
+                                              (float)sqrt(bc2), at4);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
