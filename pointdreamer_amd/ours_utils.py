@@ -177,22 +177,25 @@ def naive_inpainting(img, no_need_inpaint_mask2, method='linear'):
     return nearest_fill(img.unsqueeze(0), m, 'CHW')[0]
 
 
+def save_inpainted_images(out, hard_mask0s, save_path, view_num, method):
+    """`{k}_inpainted.png`: RGBA with alpha = mask0 for DDNM (ours_utils.py:924-928), RGB for nearest (:939-941)."""
+    os.makedirs(save_path, exist_ok=True)
+    for i in range(view_num):
+        if method == 'DDNM_inpaint':
+            rgba = torch.cat([out[i], hard_mask0s[i][0].unsqueeze(0)])
+            io_utils.save_CHW_RGBA_img(rgba, os.path.join(save_path, f'{i}_inpainted.png'))
+        else:
+            io_utils.save_CHW_RGB_img(out[i], os.path.join(save_path, f'{i}_inpainted.png'))
+
+
 def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpainter, view_num, method='linear'):
     """ours_utils.py:884-951 -> inpainted[V,3,r,r]."""
     if method == 'DDNM_inpaint':
         out = inpainter.inpaint_views(sparse_imgs, hard_mask2s[:, 0].contiguous())
-        if save_path is not None:
-            os.makedirs(save_path, exist_ok=True)
-            for i in range(view_num):
-                rgba = torch.cat([out[i], hard_mask0s[i][0].unsqueeze(0)])
-                io_utils.save_CHW_RGBA_img(rgba, os.path.join(save_path, f'{i}_inpainted.png'))
-        return out
-    if method != 'nearest':
+    elif method == 'nearest':
+        out = nearest_fill(sparse_imgs, hard_mask2s[:, 0].contiguous(), 'CHW')
+    else:
         raise NotImplementedError(f"texture_gen_method={method!r} is not built (DDNM_inpaint | nearest)")
-    m = hard_mask2s[:, 0].contiguous()
-    out = nearest_fill(sparse_imgs, m, 'CHW')
     if save_path is not None:
-        os.makedirs(save_path, exist_ok=True)
-        for i in range(view_num):
-            io_utils.save_CHW_RGB_img(out[i], os.path.join(save_path, f'{i}_inpainted.png'))
+        save_inpainted_images(out, hard_mask0s, save_path, view_num, method)
     return out

@@ -9,9 +9,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _write_cloud(path, n=20000):
+def _write_cloud(path, n=20000, seed=3):
     from pointdreamer_amd import synthetic, io_utils
-    xyz, rgb = synthetic.sphere_points(n, seed=3)
+    xyz, rgb = synthetic.sphere_points(n, seed=seed)
     io_utils.save_colored_pc_ply(xyz * 1.7 + 0.3, rgb, path)          # off-centre / scaled: the driver normalises it
 
 
@@ -72,3 +72,26 @@ def test_demo_with_supplied_mesh_obj_builds_and_caches_the_atlas(tmp_path):
     out2 = demo.main(args)[0]                                   # second run: cached dict
     a2 = np.array(PIL.Image.open(os.path.join(out2, "models/model_normalized.png")))
     assert np.array_equal(a1, a2)
+
+
+def test_demo_directory_run_batches_shapes_and_matches_one_at_a_time(tmp_path):
+    """`--pc_file <dir>`: clouds are textured in groups (views of a group in one inpainter batch); same files and the same atlas
+    as the one-at-a-time run ('nearest' config: deterministic)."""
+    from pointdreamer_amd import demo
+    d = tmp_path / 'clouds'
+    d.mkdir()
+    for k in range(3):
+        _write_cloud(str(d / f'c{k}.ply'), seed=20 + k)
+    cfgf = os.path.join(ROOT, "configs", "nearest.yaml")
+    over = ["xatlas_texture_res=512"]
+    outs_b = demo.main(["--config", cfgf, "--pc_file", str(d), "--batch_shapes", "2", "--set", f"output_path={tmp_path / 'b'}"] + over)
+    outs_1 = demo.main(["--config", cfgf, "--pc_file", str(d), "--batch_shapes", "1", "--set", f"output_path={tmp_path / 'o'}"] + over)
+    assert len(outs_b) == len(outs_1) == 3
+    for ob, o1 in zip(outs_b, outs_1):
+        assert os.path.basename(ob) == os.path.basename(o1)
+        for f in ["config.yaml", "input_pc.ply", "models/model_normalized.obj", "models/model_normalized.mtl", "models/model_normalized.png",
+                  "others/atlas_wo_background.png"] + [f"others/{k}_{s}.png" for k in range(8) for s in ("sparse", "mask0", "mask2", "inpainted")]:
+            assert os.path.exists(os.path.join(ob, f)), f
+        a = np.array(PIL.Image.open(os.path.join(ob, "models/model_normalized.png")))
+        b = np.array(PIL.Image.open(os.path.join(o1, "models/model_normalized.png")))
+        assert np.array_equal(a, b)

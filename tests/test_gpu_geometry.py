@@ -2,6 +2,7 @@
 same seeded inputs, vs the golden vectors made by the imported reference, and size-independent
 properties at BASELINE sizes.  Integer / index / mask outputs must be bit-identical; colour outputs are
 exact copies of inputs, so they are compared bit-exactly too."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -489,3 +490,31 @@ def test_batched_shapes_equal_one_by_one(pd):
         one = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, complete_unseen_by='unproject',
                                          optimize_from=None, return_intermediates=True, **kw)
         assert np.array_equal(N_(atlas), N_(one['atlas']))
+
+
+def test_batched_shapes_with_neighbor_completion_and_optimize_equal_one_by_one(pd, tmp_path):
+    """The batched entry point runs the full option set (the shipped configs: complete_unseen_by='neighbor', optimize_from='ours')
+    shape by shape behind the shared inpainter batch, and writes each shape's per-view PNGs into its own directory."""
+    from pointdreamer_amd import pipeline
+    syn = pd['syn']
+    stacks, slices, A, V, R, r = 16, 32, 256, 4, 256, 128
+    verts, faces, lut = syn.uv_sphere(stacks, slices)
+    gb_pos, mask, fid = syn.latlong_atlas(A, stacks, slices, gutter=2, lut=lut)
+    uvs, fuv = syn.uv_sphere_uvs(stacks, slices, A, gutter=2)
+    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(V, 1.6, R, device=DEV)
+    xat = dict(gb_pos=T(gb_pos), mask=T(mask), per_atlas_pixel_face_id=T(fid), uvs=T(uvs), mesh_tex_idx=T(fuv))
+    cam_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    fn = T(syn.face_normals(verts, faces))
+    kw = dict(view_num=V, res=r, cam_res=R, point_validation_by_o3d=True, texture_gen_method='nearest', point_size=1,
+              edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, edge_dilate_kernels=[21],
+              complete_unseen_by='neighbor', optimize_from='ours')
+    clouds = [syn.sphere_points(3000, seed=s) for s in (4, 5)]
+    shapes = [dict(coords=T(x), colors=T(c), vertices=T(verts), faces=T(faces), f_normals=fn, xatlas=xat) for x, c in clouds]
+    dirs = [str(tmp_path / f"s{i}") for i in range(2)]
+    got = pipeline.colorize_meshes_batched(shapes, cam_info, save_img_paths=dirs, return_full=True, **kw)
+    for (x, c), full, d in zip(clouds, got, dirs):
+        one = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, **kw)
+        assert len(full) == 6 and np.array_equal(N_(full[4]), N_(one[4]))
+        for k in range(V):
+            for sfx in ("sparse", "mask0", "mask2", "inpainted"):
+                assert os.path.exists(os.path.join(d, f"{k}_{sfx}.png"))
