@@ -198,6 +198,12 @@ def recon_textured_meshes_batched(cfg, inpainter, camera_info, pc_files, names, 
     return [sh['out'] for sh in shapes]
 
 
+def files_of_rank(pc_files, rank, world):
+    """The clouds rank `rank` of `world` textures: a contiguous block of the sorted list (dist.shard_range)."""
+    from .dist import shard_range
+    return [pc_files[i] for i in shard_range(len(pc_files), rank, world)]
+
+
 def main(argv=None):
     p = argparse.ArgumentParser("PointDreamer (MI355X texturing path)")
     p.add_argument("--config", type=str, default='configs/default.yaml', help="path to config file")
@@ -208,11 +214,17 @@ def main(argv=None):
     p.add_argument("--batch_shapes", type=int, default=4, help="directory runs: clouds textured together, their views in one "
                    "inpainter batch (1 = one at a time, as the reference; 4 is ~16 %% more shapes/hour on one MI355X)")
     args = p.parse_args(argv)
-    device = torch.device('cuda')
+    # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pointdreamer_amd.demo ...`): every rank textures its
+    # own contiguous block of the directory's clouds -- independent shapes, no collective on the data path
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0))) if world > 1 else torch.device('cuda')
+    if world > 1:
+        torch.cuda.set_device(device)
     overrides = {k: yaml.safe_load(v) for k, v in (kv.split('=', 1) for kv in args.set)}
     pc_files = [args.pc_file] if args.pc_file.endswith('.ply') else \
         [os.path.join(args.pc_file, i) for i in sorted(os.listdir(args.pc_file)) if i.endswith('.ply')]
-    group = max(1, min(args.batch_shapes, len(pc_files)))
+    pc_files = files_of_rank(pc_files, rank, world)
+    group = max(1, min(args.batch_shapes, max(1, len(pc_files))))
     cfg, inpainter, camera_info, logger = prepare(args.config, device, args.ckpt, args.allow_random_weights, overrides, batch_shapes=group)
     outs = []
     # PNG / OBJ encoding of one shape runs on host threads under the GPU work of the next (io_utils.set_async); every file is on

@@ -78,3 +78,14 @@ def test_shard_range_partitions():
             assert seen == list(range(n))
             sizes = [len(pdist.shard_range(n, r, w)) for r in range(w)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_demo_directory_is_partitioned_over_ranks():
+    """`demo.py --pc_file <dir>` under torch.distributed.run: every cloud goes to exactly one rank, blocks differ by at most one."""
+    sys.path.insert(0, ROOT)
+    from pointdreamer_amd import demo
+    files = [f"c{i:02d}.ply" for i in range(11)]
+    for w in (1, 2, 3, 8, 16):
+        parts = [demo.files_of_rank(files, r, w) for r in range(w)]
+        assert sum(parts, []) == files
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
