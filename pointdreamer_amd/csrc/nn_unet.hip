@@ -315,7 +315,7 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     u->mult.assign(channel_mult, channel_mult + n_mult);
     u->att_ds.assign(attention_ds, attention_ds + n_att);
     auto is_att = [&](int ds) { for (int a : u->att_ds) if (a == ds) return true; return false; };
-    auto fail = [&](int rc) { for (void* p : u->owned) hipFree(p); delete u; return rc; };
+    auto fail = [&](int rc) { for (void* p : u->owned) (void)hipFree(p); delete u; return rc; };
     long long emb_rows = 0;
     auto add_res = [&](const std::string& name, int cin, int cout, int mode) -> int {
         ResB rb; rb.name = name; rb.cin = cin; rb.cout = cout; rb.mode = mode; rb.has_skip = cin != cout;
@@ -429,8 +429,8 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
 
 extern "C" void pdhip_unet_destroy(pdhip_unet* u) {
     if (!u) return;
-    for (hipEvent_t e : u->prof.ev) hipEventDestroy(e);
-    for (void* p : u->owned) hipFree(p);
+    for (hipEvent_t e : u->prof.ev) (void)hipEventDestroy(e);
+    for (void* p : u->owned) (void)hipFree(p);
     delete u;
 }
 
