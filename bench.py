@@ -134,9 +134,10 @@ def main():
                                           camera_info, **cfg)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
