@@ -205,6 +205,7 @@ int pdhip_debug_set_conv_tile(int geometry);    /* 2 = 128x128 tile / 4 waves, 4
                                                  * 16 = 256x128 / 4 waves, 32 = halo-resident 3x3 kernel (512x128); 0 = automatic */
 int pdhip_debug_set_conv_stages(int stages);   /* 2..4 LDS pipeline stages, 12 = 2 stages + hand-scheduled fragment loop; 0 = automatic */
 int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int splits); /* split-K workspace for pdhip_conv2d_nhwc_f16 + forced factor (0 = automatic) */
+int pdhip_debug_set_conv_halo_strips(int mode); /* halo-resident 3x3 kernel on 256-wide images: 0 = automatic (column strips of 128), 1 = full-row tiles, 2 = strips of 64; returns the previous value */
 int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed /*[Cout][taps*Cin] f16*/, void* stream);
 int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*Cin]*/, const float* bias, const void* residual,
                           void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, const void* zero_page,

@@ -36,6 +36,7 @@ _reg('pdhip_ddnm_sample', C.c_int, [vp, vp, vp, i32, vp, vp, u64, i32, vp, vp])
 _reg('pdhip_debug_set_conv_bk', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_stages', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_tile', C.c_int, [i32])
+_reg('pdhip_debug_set_conv_halo_strips', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_splitk', C.c_int, [vp, C.c_longlong, i32])
 _reg('pdhip_pack_conv_weight_f16', C.c_int, [vp, i32, i32, i32, vp, vp])
 _reg('pdhip_unet_head_ws_floats', C.c_size_t, [i32, i32, i32, i32, i32])

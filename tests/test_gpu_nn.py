@@ -315,6 +315,29 @@ def test_conv3x3_halo_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, res, splits):
         L.pdhip_debug_set_conv_splitk(None, 0, 0)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("N,H,Cin,Cout,res", [(2, 16, 64, 128, True), (1, 24, 96, 256, False)])
+def test_conv3x3_halo_tile_geometries_on_256_wide_images(nn, mode, N, H, Cin, Cout, res):
+    """256-wide images: tiles of 4 rows x 128 columns (automatic), full rows (1) or 8 rows x 64 columns (2) -- strip borders inside
+    the image must read their neighbours' columns, the image border the zero padding; the fused GroupNorm partials (one chunk per
+    tile) are covered by the UNet tests, which run the automatic geometry."""
+    L = nn['L']
+    old = (L.pdhip_debug_set_conv_tile(32), L.pdhip_debug_set_conv_halo_strips(mode))
+    try:
+        g = torch.Generator().manual_seed(7 * H + Cin + mode)
+        x = torch.randn((N, Cin, H, 256), generator=g).half().float()
+        w = (torch.randn((Cout, Cin, 3, 3), generator=g) / math.sqrt(Cin * 9)).half().float()
+        b = (torch.randn((Cout,), generator=g) * 0.1).half().float()
+        r = torch.randn((N, Cout, H, 256), generator=g).half().float() if res else None
+        ref = F.conv2d(x, w, b, padding=1).half().float()
+        if res:
+            ref = (ref + r).half().float()
+        out = hip_conv(nn, x, w, b, r)
+        assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+    finally:
+        L.pdhip_debug_set_conv_tile(old[0]); L.pdhip_debug_set_conv_halo_strips(old[1])
+
+
 @pytest.mark.parametrize("bk,stages,wmw", [(32, 2, 2), (32, 3, 2), (32, 4, 4), (64, 2, 2), (64, 3, 4), (64, 2, 4), (32, 3, 4),
                                            (64, 2, 8), (64, 12, 2), (64, 12, 8), (64, 12, 16)])
 def test_conv_igemm_all_kernel_variants(nn, bk, stages, wmw):
