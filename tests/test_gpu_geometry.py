@@ -518,3 +518,19 @@ def test_batched_shapes_with_neighbor_completion_and_optimize_equal_one_by_one(p
         for k in range(V):
             for sfx in ("sparse", "mask0", "mask2", "inpainted"):
                 assert os.path.exists(os.path.join(d, f"{k}_{sfx}.png"))
+
+
+def test_degenerate_sizes_do_not_break_the_entry_points(pd):
+    """Empty and tiny inputs: no points, fewer points than a tetrahedron (every point is a hull vertex = visible), no faces."""
+    from pointdreamer_amd import hpr
+    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(3, 1.6, 128, device=DEV)
+    verts, faces, _ = pd['syn'].uv_sphere(8, 12)
+    for n in (0, 1, 2, 3, 4):
+        pts = np.random.default_rng(n).normal(size=(n, 3)).astype(np.float32) * 0.3
+        vis = hpr.hidden_point_removal(T(pts).reshape(n, 3), eyes, 100)
+        assert tuple(vis.shape) == (3, n) and bool(vis.all())
+    out = pd['ou'].get_rendered_hard_mask_and_face_idx_batch(cams, T(verts), T(faces[:0].reshape(0, 3)), T(np.zeros((5, 3), np.float32)),
+                                                            None, True, 0.05)
+    assert int(out[0].sum()) == 0 and bool((out[1] == -1).all()) and bool((out[2] == 0).all())
+    out = pd['ou'].get_rendered_hard_mask_and_face_idx_batch(cams, T(verts), T(faces), T(np.zeros((0, 3), np.float32)), None, True, 0.05)
+    assert tuple(out[7].shape) == (3, 0, 2) and int(out[0].sum()) > 0
