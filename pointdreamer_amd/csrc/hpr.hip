@@ -323,24 +323,47 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
     const double* fx = flipped + (size_t)v * 3 * N;
     const double* fy = fx + N;
     const double* fz = fy + N;
+    // a block owns QPW directions; its four waves scan a quarter of the cloud each and merge through LDS (KC / QPW blocks of
+    // 4 waves per view fill the chip, one wave per QPW directions did not: 300 -> 100 us)
+    __shared__ double s_b[4][QPW];
+    __shared__ int s_i[4][QPW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = (blockIdx.x * 4 + wave) * QPW;
+    const int k0 = blockIdx.x * QPW;
     if (k0 >= KC) return;
     double dx[QPW], dy[QPW], dz[QPW], best[QPW];
     int bi[QPW];
+    // the block's QPW Fibonacci directions: one lane each (f64 sin / cos of a large argument are hundreds of instructions; every
+    // lane computing all of them was most of this kernel's time), shared through LDS
+    __shared__ double s_d[QPW][3];
+    if (threadIdx.x < QPW) {
+        const int kk = min(k0 + (int)threadIdx.x, KC - 1);
+        const double z = 1.0 - (2.0 * kk + 1.0) / KC, r = sqrt(fmax(0.0, 1.0 - z * z)), phi = kk * 2.399963229728653;
+        s_d[threadIdx.x][0] = r * cos(phi); s_d[threadIdx.x][1] = r * sin(phi); s_d[threadIdx.x][2] = z;
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < QPW; ++k) {
-        const int kk = min(k0 + k, KC - 1);
-        const double z = 1.0 - (2.0 * kk + 1.0) / KC, r = sqrt(fmax(0.0, 1.0 - z * z)), phi = kk * 2.399963229728653;
-        dx[k] = r * cos(phi); dy[k] = r * sin(phi); dz[k] = z;
+        dx[k] = s_d[k][0]; dy[k] = s_d[k][1]; dz[k] = s_d[k][2];
         best[k] = -1.0e300; bi[k] = 0x7fffffff;
     }
-    for (int j = lane; j < N; j += 64) {
-        const double x = fx[j], y = fy[j], z = fz[j];
+    // four points per lane in flight: with two waves per SIMD a single dependent load per iteration leaves the L2 latency exposed
+    for (int j = wave * 64 + lane; j < N; j += 1024) {
+        double x[4], y[4], z[4];
 #pragma unroll
-        for (int k = 0; k < QPW; ++k) {
-            const double val = dx[k] * x + dy[k] * y + dz[k] * z;
-            if (val > best[k]) { best[k] = val; bi[k] = j; }
+        for (int u = 0; u < 4; ++u) {
+            const int ju = min(j + u * 256, N - 1);                   // (a clamped duplicate cannot change an argmax)
+            x[u] = fx[ju]; y[u] = fy[ju]; z[u] = fz[ju];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ju = j + u * 256;
+            if (ju < N) {
+#pragma unroll
+                for (int k = 0; k < QPW; ++k) {
+                    const double val = dx[k] * x[u] + dy[k] * y[u] + dz[k] * z[u];
+                    if (val > best[k]) { best[k] = val; bi[k] = ju; }
+                }
+            }
         }
     }
 #pragma unroll
@@ -351,6 +374,20 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
         for (int off = 32; off > 0; off >>= 1) {
             const double ob = __shfl_xor(b, off);
             const int oi = __shfl_xor(id, off);
+            if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
+        }
+        if (lane == 0) { s_b[wave][k] = b; s_i[wave][k] = id; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int k = 0; k < QPW; ++k) {
+        double b = s_b[0][k];
+        int id = s_i[0][k];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const double ob = s_b[w][k];
+            const int oi = s_i[w][k];
             if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
         }
         if (lane == 0 && k0 + k < KC) {
@@ -405,7 +442,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     dim3 gg(cdiv(N, 4 * QPW), V), gg4(cdiv(min(N, HPR_NARROW_BELOW), 4), V);
     constexpr int KC = HPR_KC;
     if (N > 4 * HPR_KC) {            // the coarse level pays off only when the cloud is much larger than the coarse set
-        dim3 ge(cdiv(KC, 4 * QPW), V);
+        dim3 ge(cdiv(KC, QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
         k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, cs, cidx, outside);
         k_hpr_gjk<true, QPW, false><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip);
