@@ -26,6 +26,7 @@ using namespace pdhip;
 #define GJK_MAX_ROUNDS 64
 #define GJK_COARSE_ROUNDS 32
 #define HPR_KC 1024            // coarse support set size
+#define HPR_COOP_WAVES 4       // waves that share one group of 4 queries in the short-list geometry (8: -6 %, 16: -13 %)
 #define HPR_NARROW_BELOW 4096   // query lists shorter than this (per view) run 4 queries per wavefront instead of 16
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
@@ -85,16 +86,16 @@ __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __re
 // longest query's rounds x the scan length -- use Q = 4 with COOP: 4 queries per 256-lane block, 16x shorter scans).
 // COARSE: every point of the cloud is a query (ns = scap = KC extreme points); writes outside[v][q] = origin not enclosed.
 // !COARSE: queries from list / count, support set = the points outside the coarse hull (ns = scount[v]); writes vis.
-template <bool COARSE, int Q, bool COOP>
-__global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+template <bool COARSE, int Q, bool COOP, int NW>
+__global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                  const int* __restrict__ list, uint8_t* __restrict__ vis,
                                                  const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
                                                  const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi,
                                                     const uint8_t* __restrict__ skip) {
-    __shared__ double s_dir[4][Q][3];
-    __shared__ int s_q[4][Q];
-    __shared__ double s_rv[2][4][Q];                            // COOP: per-wave partial argmax of the round (double-buffered)
-    __shared__ int s_ri[2][4][Q];
+    __shared__ double s_dir[NW][Q][3];
+    __shared__ int s_q[NW][Q];
+    __shared__ double s_rv[2][NW][Q];                            // COOP: per-wave partial argmax of the round (double-buffered)
+    __shared__ int s_ri[2][NW][Q];
     const int v = blockIdx.y;
     const double* qfx = flipped + (size_t)v * 3 * N;          // the queries' own coordinates
     const double* qfy = qfx + N;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ f
     // COOP: the four waves of the block own the SAME Q queries, scan a quarter of the support set each and merge through LDS
     // (all four run the identical state machine on the merged result): a round is 4x shorter, which is what bounds the
     // kernel when the query list is short and a few queries need 40-60 rounds.
-    const int q0 = COOP ? blockIdx.x * Q : (blockIdx.x * 4 + wave) * Q;
+    const int q0 = COOP ? blockIdx.x * Q : (blockIdx.x * NW + wave) * Q;
     const int nq = COARSE ? N : count[v];
     if (q0 >= nq || nq < q_lo || nq >= q_hi) return;        // (q_lo, q_hi: which launch geometry serves this view's query count)
     // query k of the wave lives in lane k * ST (the lane the halving reduction below leaves its support point in)
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ f
         // (the next point is requested before the current one is evaluated: two waves per SIMD do not hide an L2 round trip)
         double nx = 0.0, ny = 0.0, nz = 0.0;
         int njo = -1;
-        constexpr int JS = COOP ? 256 : 64;
+        constexpr int JS = COOP ? NW * 64 : 64;
         const int j0 = COOP ? wave * 64 + lane : lane;
         if (j0 < NS) { nx = fx[j0]; ny = fy[j0]; nz = fz[j0]; if (!COARSE) njo = sidx[j0]; }
         for (int j = j0; j < NS; j += JS) {
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_hpr_gjk(const double* __restrict__ f
             __syncthreads();
             best[0] = s_rv[pb][0][kq]; bi[0] = s_ri[pb][0][kq];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 const double ob = s_rv[pb][w][kq];
                 const int oi = s_ri[pb][w][kq];
                 if (ob > best[0] || (ob == best[0] && oi < bi[0])) { best[0] = ob; bi[0] = oi; }
@@ -445,15 +446,15 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
         dim3 ge(cdiv(KC, QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
         k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, cs, cidx, outside);
-        k_hpr_gjk<true, QPW, false><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip);
+        k_hpr_gjk<true, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip);
         k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
-        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr);
-        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr);
+        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr);
+        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr);
     } else {                         // one level: support set = the whole cloud
         k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
         k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
-        k_hpr_gjk<false, QPW, false><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr);
-        k_hpr_gjk<false, 4, true><<<gg4, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr);
+        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr);
+        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
