@@ -32,6 +32,7 @@ extern "C" {
 #define PDHIP_E_HIP (-2)      /* HIP runtime error (message has the hipError string) */
 #define PDHIP_E_STATE (-3)    /* handle in wrong state (e.g. weights missing) */
 #define PDHIP_E_NOMEM (-4)
+#define PDHIP_E_UNKNOWN_NAME (-5)   /* pdhip_unet_load_tensor: not a tensor of this architecture (strict=False callers skip it) */
 
 int pdhip_version(void);
 const char* pdhip_last_error(void);
@@ -91,10 +92,16 @@ int pdhip_point_visibility(int cam_res, const float* point_uvs /*[V,N,2]*/, cons
  *      spherical flip about each eye + convex-hull vertex test, all V views in one call, float64 on the device.
  *      eyes: V*3 float64 (device).  ws: pdhip_hpr_ws_bytes(V, N) bytes.  visibility[V,N] u8.
  *      skip (may be NULL): [V,N] u8; points already accepted by another test (demo.py:110 ORs the depth test with
- *      this one) are not queried and come back as 1, so the result is directly the OR-ed validation. */
+ *      this one) are not queried and come back as 1, so the result is directly the OR-ed validation.
+ *      Every verdict carries a floating-point certificate (separating direction / enclosing tetrahedron with error
+ *      bounds); what f64 cannot certify is re-run in double-double arithmetic, so the result is the vertex set of the
+ *      exact hull of the flipped points.  pdhip_hpr_read_counters (synchronises) reports, for the last call on `ws`:
+ *      out[0] queries sent to the double-double fallback, out[1] queries not certifiable even there (exactly
+ *      degenerate input; reported hidden), out[2] fallback rounds. */
 size_t pdhip_hpr_ws_bytes(int V, int N);
 int pdhip_hidden_point_removal(const float* points /*[N,3]*/, int N, const double* eyes /*[V,3]*/, int V, double radius,
                                const uint8_t* skip, uint8_t* visibility, void* ws, void* stream);
+int pdhip_hpr_read_counters(const void* ws, int V, long long* out /*[3]*/, void* stream);
 
 /* ---- demo.py:121-125: point_pixels = clip(long(uv*res)) as (row,col). */
 int pdhip_point_pixels(const float* point_uvs /*[V,N,2]*/, int V, int N, int res,
@@ -138,6 +145,11 @@ int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos /
  *      out[K,V,A,A] u8.  ws: 2*V*A*A bytes. */
 int pdhip_nbf_shrink(const uint8_t* mask /*[A,A]*/, const uint8_t* visibility /*[V,A,A]*/, int V, int A,
                      const int32_t* kernels, int K, uint8_t* out, uint8_t* ws, void* stream);
+/* the reference's always-on debug triptychs `others/shrink_per_view_edge/{v}.png` (unproject.py:459-474): per view
+ * [visibility + background edges (red) + view edges (blue) | view edge mask | border mask of `kernel`] with 10 white columns
+ * between panels, rows reversed; out [V][A][3A+20][3] u8 (HWC), ws (2V+1)*A*A bytes. */
+int pdhip_nbf_triptych(const uint8_t* mask, const uint8_t* visibility, int V, int A, int kernel, uint8_t* out, uint8_t* ws,
+                       void* stream);
 
 /* ---- Uq3+Uq4: view selection + colour gather (unproject.py:298-400).
  *      shrinked[K,V,A,A] (K = number of NBF levels actually consulted), visibility[V,A,A] raw.
@@ -197,6 +209,11 @@ int pdhip_ddnm_step(float* x, const float* et, int et_channels, const float* y, 
  * out[N,3,S,S] in [0,1]. */
 int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
                       const float* eps_tape, uint64_t seed, int n_steps, float* out, void* stream);
+/* the same with an explicit noise key: image n draws the Philox stream of key first_image_key + n, so a view's noise does not
+ * depend on its batch position, on the batch composition or on how views are sharded over ranks (the reference draws
+ * independent torch.randn noise per view, diffusion.py:493,552).  pdhip_ddnm_sample == first_image_key 0. */
+int pdhip_ddnm_sample_keyed(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
+                            const float* eps_tape, uint64_t seed, uint64_t first_image_key, int n_steps, float* out, void* stream);
 
 /* stand-alone operators of the engine (NHWC f16); also the unit-test surface of the kernels */
 /* tuning / test hook: force the conv K-step (32 or 64; 0 = automatic); returns the previous value */

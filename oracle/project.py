@@ -190,14 +190,29 @@ def point_validation_by_hpr(points, eye_positions, radius):
     points = np.asarray(points, np.float64)
     out = np.zeros((len(eye_positions), points.shape[0]), bool)
     for i, eye in enumerate(eye_positions):
-        q = points - np.asarray(eye, np.float64)[None]
-        n = np.linalg.norm(q, axis=1, keepdims=True)
-        n = np.maximum(n, 1e-300)
-        flipped = q + 2 * (radius - n) * q / n
+        flipped = hpr_flip(points, eye, radius)
         hull = ConvexHull(np.concatenate([flipped, np.zeros((1, 3))], 0))
         vid = hull.vertices
         out[i, vid[vid < points.shape[0]]] = True
     return out
+
+
+def hpr_flip(points, eye, radius):
+    """The spherical flip exactly as open3d's PointCloud::HiddenPointRemoval forms it (float64):
+    q = p - eye; n = |q| (0 -> 1e-4); p' = q + 2 (radius - n) q / n."""
+    q = np.asarray(points, np.float64) - np.asarray(eye, np.float64)[None]
+    n = np.sqrt((q[:, 0:1] * q[:, 0:1] + q[:, 1:2] * q[:, 1:2]) + q[:, 2:3] * q[:, 2:3])
+    n[n == 0] = 0.0001
+    return q + ((2 * (radius - n)) * q) / n
+
+
+def hpr_margin(flipped, i):
+    """Signed distance of flipped point i to the hull of all OTHER flipped points and the eye (qhull facet equations):
+    > 0: strictly outside, i.e. a hull vertex; < 0: inside.  Used by tests to characterise verdicts near a facet."""
+    from scipy.spatial import ConvexHull
+    others = np.concatenate([np.delete(flipped, i, 0), np.zeros((1, 3))], 0)
+    eq = ConvexHull(others).equations
+    return float((eq[:, :3] @ flipped[i] + eq[:, 3]).max())
 
 
 # ----------------------------------------------------------------------------- nvdiffrast pieces for the atlas producer

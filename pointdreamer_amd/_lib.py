@@ -31,6 +31,7 @@ _SIGS = {
     'pdhip_point_visibility': (C.c_int, [i32, vp, vp, vp, i32, i32, f32, vp, vp, vp]),
     'pdhip_hpr_ws_bytes': (sz, [i32, i32]),
     'pdhip_hidden_point_removal': (C.c_int, [vp, i32, vp, i32, f64, vp, vp, vp, vp]),
+    'pdhip_hpr_read_counters': (C.c_int, [vp, i32, vp, vp]),
     'pdhip_point_pixels': (C.c_int, [vp, i32, i32, i32, vp, vp]),
     'pdhip_sparse_views_ws_bytes': (sz, [i32, i32, i32]),
     'pdhip_sparse_views': (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
@@ -38,6 +39,7 @@ _SIGS = {
     'pdhip_nearest_fill': (C.c_int, [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp, i32, i64, vp, vp]),
     'pdhip_texel_visibility': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, f64, vp, i32, f32, vp, vp]),
     'pdhip_nbf_shrink': (C.c_int, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
+    'pdhip_nbf_triptych': (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
     'pdhip_view_select_blend': (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp, i32, vp, i32,
                                           vp, vp, vp, vp]),
     'pdhip_compact_texels': (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
@@ -84,8 +86,17 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def resolve_device(device):
+    """torch.device with an explicit index ('cuda' -> the current device)."""
+    d = torch.device(device)
+    if d.type == 'cuda' and d.index is None:
+        d = torch.device('cuda', torch.cuda.current_device())
+    return d
+
+
 def ptr(t, dtype=None, allow_none=False):
-    """Device pointer of a contiguous CUDA(HIP) tensor, with dtype check."""
+    """Device pointer of a contiguous CUDA(HIP) tensor, with dtype check.  The kernels are launched on the CURRENT device's
+    current stream (stream()), so a tensor living on another device is refused here instead of faulting in a kernel."""
     if t is None:
         if allow_none:
             return C.c_void_p(0)
@@ -93,6 +104,9 @@ def ptr(t, dtype=None, allow_none=False):
     if not t.is_cuda:
         raise PdhipError("pointdreamer_amd needs tensors on the GPU (cuda:N == HIP device); got a CPU tensor. "
                          "There is no CPU path.")
+    if t.device.index != torch.cuda.current_device():
+        raise PdhipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: call "
+                         "torch.cuda.set_device / use `with torch.cuda.device(...)` around pointdreamer_amd calls")
     if not t.is_contiguous():
         raise PdhipError("tensor must be contiguous")
     if dtype is not None and t.dtype != dtype:

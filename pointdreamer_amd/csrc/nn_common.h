@@ -66,9 +66,12 @@ int gemv_rows(const float* Wm /*[R][K]*/, const float* b, const float* x /*[N][K
 struct DdnmCoef { float sqrt_1m_at, sqrt_at, sqrt_at_next, sigma_t, c1, c2; };
 int ddnm_update(float* x /*[N,3,HW] in/out*/, const float* et /*[N,Cet,HW], first 3 used*/, int Cet, const float* y,
                 const float* mask /*[N,HW]*/, const float* eps /*null -> philox*/, unsigned long long seed,
-                unsigned long long step, DdnmCoef co, int N, int HW, hipStream_t s);
+                unsigned long long step, DdnmCoef co, int N, int HW, hipStream_t s, unsigned long long quad0 = 0);
 int ddnm_prepare(const float* masked_img, const float* mask, float* y, int N, int HW, hipStream_t s);
 int ddnm_finish(const float* x, float* out, long long n, hipStream_t s);
-int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s);
+// Philox counter = (quad0 + element / 4, stream_id), key = seed.  quad0 = first image key * quads per image makes the noise of an
+// image a function of its KEY only (not of its position in the batch or of how views are sharded over ranks).
+int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s,
+                  unsigned long long quad0 = 0);
 
 }  // namespace pdnn

@@ -178,19 +178,21 @@ __device__ __forceinline__ void normal4(unsigned long long seed, unsigned long l
     out[2] = r1 * cosf(6.283185307179586f * u3); out[3] = r1 * sinf(6.283185307179586f * u3);
 }
 
-__global__ void k_philox_normal(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long stream_id) {
+__global__ void k_philox_normal(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long stream_id,
+                                unsigned long long quad0) {
     const long long quads = (n + 3) / 4;
     for (long long qd = blockIdx.x * (long long)blockDim.x + threadIdx.x; qd < quads; qd += (long long)gridDim.x * blockDim.x) {
         float z[4];
-        normal4(seed, stream_id, (unsigned long long)qd, z);
+        normal4(seed, stream_id, quad0 + (unsigned long long)qd, z);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (qd * 4 + e < n) out[qd * 4 + e] = z[e];
     }
 }
 
-int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s) {
-    k_philox_normal<<<(int)std::min<long long>(((n + 3) / 4 + 255) / 256, 4096), 256, 0, s>>>(out, n, seed, stream_id);
+int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s,
+                  unsigned long long quad0) {
+    k_philox_normal<<<(int)std::min<long long>(((n + 3) / 4 + 255) / 256, 4096), 256, 0, s>>>(out, n, seed, stream_id, quad0);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -215,7 +217,7 @@ int ddnm_prepare(const float* masked_img, const float* mask, float* y, int N, in
 
 __global__ void k_ddnm_update(float* __restrict__ x, const float* __restrict__ et, int Cet, const float* __restrict__ y,
                               const float* __restrict__ mask, const float* __restrict__ eps, unsigned long long seed,
-                              unsigned long long step, DdnmCoef co, int HW, long long total) {
+                              unsigned long long step, DdnmCoef co, int HW, long long total, unsigned long long quad0) {
     // one thread = 4 consecutive elements (HW % 4 == 0), so one Philox call feeds it
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q * 4 < total; q += (long long)gridDim.x * blockDim.x) {
         const long long i = q * 4;
@@ -224,7 +226,7 @@ __global__ void k_ddnm_update(float* __restrict__ x, const float* __restrict__ e
         const int p = (int)(i % HW);
         float z[4];
         if (eps) { const float4 e4 = *reinterpret_cast<const float4*>(eps + i); z[0] = e4.x; z[1] = e4.y; z[2] = e4.z; z[3] = e4.w; }
-        else normal4(seed, step, (unsigned long long)q, z);
+        else normal4(seed, step, quad0 + (unsigned long long)q, z);
         const float4 x4 = *reinterpret_cast<const float4*>(x + i);
         const float4 e4 = *reinterpret_cast<const float4*>(et + ((size_t)n * Cet + c) * HW + p);
         const float4 y4 = *reinterpret_cast<const float4*>(y + i);
@@ -242,11 +244,12 @@ __global__ void k_ddnm_update(float* __restrict__ x, const float* __restrict__ e
     }
 }
 int ddnm_update(float* x, const float* et, int Cet, const float* y, const float* mask, const float* eps,
-                unsigned long long seed, unsigned long long step, DdnmCoef co, int N, int HW, hipStream_t s) {
+                unsigned long long seed, unsigned long long step, DdnmCoef co, int N, int HW, hipStream_t s,
+                unsigned long long quad0) {
     PD_REQUIRE(HW % 4 == 0, "ddnm_update: H*W must be a multiple of 4");
     const long long total = (long long)N * 3 * HW;
     k_ddnm_update<<<(int)std::min<long long>((total / 4 + 255) / 256, 4096), 256, 0, s>>>(x, et, Cet, y, mask, eps, seed, step, co,
-                                                                                       HW, total);
+                                                                                       HW, total, quad0);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -554,7 +554,7 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
     }
     (void)ends;
     set_error("pdhip_unet_load_tensor: unknown tensor name '%s'", name_c);
-    return PDHIP_E_ARG;
+    return PDHIP_E_UNKNOWN_NAME;
 }
 
 extern "C" int pdhip_unet_forward(pdhip_unet* u, const float* x, const float* t, int N, float* out, void* stream) {
@@ -644,8 +644,12 @@ extern "C" int pdhip_ddnm_prepare(const float* masked_imgs, const float* masks, 
 
 // The whole of simplified_ddnm_inpainting for N images at once: no host round trip inside the loop.
 // x_T / eps_tape (eps_tape[k] = noise of step k, [n_steps,N,3,S,S]) may be NULL -> Philox noise from `seed`.
-extern "C" int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
-                                 const float* eps_tape, uint64_t seed, int n_steps, float* out, void* stream) {
+// first_image_key: image n of the batch draws the Philox noise stream of key first_image_key + n (x_T: stream 0, step k: stream
+// k + 1, counter = key * 3HW/4 + element / 4): the noise of a view does not depend on its position in the batch, on the batch
+// it shares a sampler call with, or on how the views of a shape are sharded over ranks.
+extern "C" int pdhip_ddnm_sample_keyed(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
+                                       const float* eps_tape, uint64_t seed, uint64_t first_image_key, int n_steps, float* out,
+                                       void* stream) {
     PD_REQUIRE(u && masked_imgs && masks && out, "pdhip_ddnm_sample: null argument");
     PD_REQUIRE(N >= 1 && N <= u->max_batch && n_steps >= 1 && n_steps <= 100, "pdhip_ddnm_sample: bad N / n_steps");
     static const Sched sched = make_schedule();
@@ -653,8 +657,9 @@ extern "C" int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const 
     const int HW = u->image_size * u->image_size;
     const long long n3 = (long long)N * 3 * HW;
     PD_TRY(ddnm_prepare(masked_imgs, masks, u->sy, N, HW, s));
+    const unsigned long long quad0 = (unsigned long long)first_image_key * (unsigned long long)(3LL * HW / 4);
     if (x_T) PD_HIP(hipMemcpyAsync(u->sx, x_T, n3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    else PD_TRY(philox_normal(u->sx, n3, seed, 0, s));
+    else PD_TRY(philox_normal(u->sx, n3, seed, 0, s, quad0));
     if (u->steps_cached != n_steps) {            // embeddings of every schedule step, one pass over the emb_layers weights
         PD_REQUIRE(u->have_te[0] && u->have_te[1] && u->have_te[2] && u->have_te[3], "unet: time_embed not loaded");
         float th[100];
@@ -668,9 +673,13 @@ extern "C" int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const 
     for (int k = 0; k < n_steps; ++k) {
         PD_TRY(forward_impl(u, u->sx, nullptr, N, u->set_, s, false, u->steps_emb + (size_t)k * u->emb_rows));
         PD_TRY(ddnm_update(u->sx, u->set_, u->out_ch, u->sy, masks, eps_tape ? eps_tape + (size_t)k * n3 : nullptr, seed,
-                           (unsigned long long)k + 1, sched.co[k], N, HW, s));
+                           (unsigned long long)k + 1, sched.co[k], N, HW, s, quad0));
     }
     return ddnm_finish(u->sx, out, n3, s);
+}
+extern "C" int pdhip_ddnm_sample(pdhip_unet* u, const float* masked_imgs, const float* masks, int N, const float* x_T,
+                                 const float* eps_tape, uint64_t seed, int n_steps, float* out, void* stream) {
+    return pdhip_ddnm_sample_keyed(u, masked_imgs, masks, N, x_T, eps_tape, seed, 0, n_steps, out, stream);
 }
 
 // ---- stand-alone operators (also the unit-test surface of the kernels)

@@ -226,6 +226,63 @@ extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, 
     return PDHIP_OK;
 }
 
+// ---- O1: the `others/shrink_per_view_edge/{v}.png` triptychs the reference writes next to N1-N3 (unproject.py:459-474):
+// [ visibility, chart-background edges red, view edges blue | view edge mask | border mask of the last kernel ] side by side with
+// 10 white columns between the panels (utils_2d.cat_images), rows reversed (`cat[:, ::-1, :]`), 8-bit RGB, HWC.
+__global__ void k_nbf_bg_edges(const uint8_t* __restrict__ mask, int A, uint8_t* __restrict__ bg) {
+    const size_t n = (size_t)A * A;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(idx / A), x = (int)(idx - (size_t)y * A);
+        bg[idx] = scharr_edge(mask, A, y, x) ? 1 : 0;
+    }
+}
+__global__ void k_nbf_triptych(const uint8_t* __restrict__ vis, const uint8_t* __restrict__ bg, const uint8_t* __restrict__ edges,
+                               const uint8_t* __restrict__ dil_h, int A, int r, uint8_t* __restrict__ out) {
+    const int v = blockIdx.y, Wd = 3 * A + 20;
+    const size_t n = (size_t)A * A, total = (size_t)A * Wd;
+    uint8_t* o = out + (size_t)v * total * 3;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int yo = (int)(idx / Wd), xo = (int)(idx - (size_t)yo * Wd);
+        const int y = A - 1 - yo;
+        uint8_t c0 = 255, c1 = 255, c2 = 255;
+        if (xo < A) {
+            const size_t t = (size_t)y * A + xo;
+            const uint8_t g = vis[(size_t)v * n + t] ? 255 : 0;
+            c0 = c1 = c2 = g;
+            if (bg[t]) { c0 = 255; c1 = 0; c2 = 0; }
+            if (edges[(size_t)v * n + t]) { c0 = 0; c1 = 0; c2 = 255; }
+        } else if (xo >= A + 10 && xo < 2 * A + 10) {
+            c0 = c1 = c2 = edges[(size_t)v * n + (size_t)y * A + (xo - A - 10)] ? 255 : 0;
+        } else if (xo >= 2 * A + 20) {
+            const int x = xo - 2 * A - 20;
+            const int lo = max(0, y - r), hi = min(A - 1, y + r);
+            uint8_t b = 0;
+            for (int k = lo; k <= hi; ++k) b |= dil_h[(size_t)v * n + (size_t)k * A + x];
+            c0 = c1 = c2 = b ? 255 : 0;
+        }
+        o[idx * 3] = c0; o[idx * 3 + 1] = c1; o[idx * 3 + 2] = c2;
+    }
+}
+/* ws: (2 V + 1) A^2 bytes; out: [V][A][3A+20][3] u8 */
+extern "C" int pdhip_nbf_triptych(const uint8_t* mask, const uint8_t* visibility, int V, int A, int kernel, uint8_t* out,
+                                  uint8_t* ws, void* stream) {
+    PD_REQUIRE(mask && visibility && out && ws && V > 0 && A > 0, "pdhip_nbf_triptych: bad arguments");
+    PD_REQUIRE(kernel >= 1 && (kernel & 1), "pdhip_nbf_triptych: kernel size must be odd and >= 1 (got %d)", kernel);
+    hipStream_t s = as_stream(stream);
+    const size_t n = (size_t)V * A * A;
+    uint8_t* edges = ws;
+    uint8_t* tmp = ws + n;
+    uint8_t* bg = ws + 2 * n;
+    dim3 g(min(cdiv((long long)A * A, 256), 2048), V);
+    const int r = (kernel - 1) / 2;
+    k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges);
+    k_nbf_bg_edges<<<g.x, 256, 0, s>>>(mask, A, bg);
+    k_nbf_dilate_h<<<g, 256, 0, s>>>(edges, A, r, tmp);
+    k_nbf_triptych<<<dim3(min(cdiv((long long)A * (3 * A + 20), 256), 4096), V), 256, 0, s>>>(visibility, bg, edges, tmp, A, r, out);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
 // ------------------------------------------------------------------------------ Uq3 + Uq4
 __global__ void k_view_select_blend(const float* __restrict__ cams, int V, const float* __restrict__ gb_pos,
                                     const uint8_t* __restrict__ mask, const int64_t* __restrict__ face_id, int A,

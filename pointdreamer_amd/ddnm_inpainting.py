@@ -33,6 +33,7 @@ _reg('pdhip_ddnm_schedule', C.c_int, [vp, vp, vp, vp, vp])
 _reg('pdhip_ddnm_prepare', C.c_int, [vp, vp, vp, i32, i32, vp])
 _reg('pdhip_ddnm_step', C.c_int, [vp, vp, i32, vp, vp, vp, u64, i32, i32, i32, vp])
 _reg('pdhip_ddnm_sample', C.c_int, [vp, vp, vp, i32, vp, vp, u64, i32, vp, vp])
+_reg('pdhip_ddnm_sample_keyed', C.c_int, [vp, vp, vp, i32, vp, vp, u64, u64, i32, vp, vp])
 _reg('pdhip_debug_set_conv_bk', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_stages', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_tile', C.c_int, [i32])
@@ -70,7 +71,7 @@ class UNetModel:
             raise NotImplementedError("fractional channel multipliers (image_size 512) are not built")
         ads = tuple(image_size // int(r) for r in attention_resolutions.split(","))
         self.image_size, self.out_channels, self.max_batch = image_size, 6 if learn_sigma else 3, max_batch
-        self.device = torch.device(device)
+        self.device = _lib.resolve_device(device)
         cm_arr = (C.c_int * len(cm))(*[int(c) for c in cm])
         ad_arr = (C.c_int * len(ads))(*ads)
         h = vp()
@@ -99,8 +100,11 @@ class UNetModel:
                     t = t.float()
                 t = t.to(self.device).contiguous()
                 shape = (C.c_int64 * t.dim())(*t.shape)
-                check(L.pdhip_unet_load_tensor(self._h, name.encode(), ptr(t), 1 if t.dtype == torch.float16 else 0, shape,
-                                               t.dim(), stream()), f'pdhip_unet_load_tensor({name})')
+                rc = L.pdhip_unet_load_tensor(self._h, name.encode(), ptr(t), 1 if t.dtype == torch.float16 else 0, shape,
+                                              t.dim(), stream())
+                if rc == -5 and not strict:            # PDHIP_E_UNKNOWN_NAME: nn.Module.load_state_dict(strict=False) ignores unexpected keys
+                    continue
+                check(rc, f'pdhip_unet_load_tensor({name})')
                 n += 1
             torch.cuda.synchronize(self.device)
         buf = C.create_string_buffer(4096)
@@ -113,8 +117,11 @@ class UNetModel:
         x = x.float().contiguous()
         t = timesteps.float().to(x.device).contiguous()
         N = x.shape[0]
+        if x.device != self.device:
+            raise _lib.PdhipError(f"UNetModel lives on {self.device}, input is on {x.device}")
         out = torch.empty((N, self.out_channels, self.image_size, self.image_size), device=x.device)
-        check(self._L.pdhip_unet_forward(self._h, ptr(x), ptr(t), N, ptr(out), stream()), 'pdhip_unet_forward')
+        with torch.cuda.device(self.device):
+            check(self._L.pdhip_unet_forward(self._h, ptr(x), ptr(t), N, ptr(out), stream()), 'pdhip_unet_forward')
         return out
 
     __call__ = forward
@@ -217,7 +224,7 @@ class Inpainter:
 
     def __init__(self, device, ckpt_path=DEFAULT_CKPT, model_kwargs=None, max_batch=8, allow_random_weights=False,
                  seed=1234, state_dict=None):
-        self.device = torch.device(device)
+        self.device = _lib.resolve_device(device)
         kw = dict(IMAGENET_256)
         kw.update(model_kwargs or {})
         self.model = UNetModel(max_batch=max_batch, device=self.device, **kw)
@@ -232,26 +239,33 @@ class Inpainter:
         self.model.load_state_dict(state_dict, strict=True)
         self.seed = seed
         self.n_steps = 100
-        self._calls = 0
+        self._images = 0           # images inpainted so far = the noise key of the next one
         self.max_batch = max_batch
 
-    def inpaint_views(self, masked_imgs, masks, x_T=None, eps_tape=None, n_steps=None):
+    def inpaint_views(self, masked_imgs, masks, x_T=None, eps_tape=None, n_steps=None, first_key=None, advance=None):
         """masked_imgs [V,3,r,r] in [0,1], masks [V,r,r] (1 = keep) -> [V,3,r,r].  All V views go through the
-        100-step sampler together (chunks of max_batch)."""
+        100-step sampler together (chunks of max_batch).
+
+        Noise: view k of this call draws the Philox stream (seed, key = first_key + k); by default first_key is the number of
+        images this Inpainter has processed, so successive calls get fresh noise and the result does not depend on how the
+        views are chunked or batched.  Sharded callers (dist.py) pass the key of their first view and `advance` = the number
+        of views of the whole shape so that every rank stays in step."""
         L = _lib.lib()
         masked_imgs = masked_imgs.float().contiguous()
         masks = masks.float().contiguous()
         V = masked_imgs.shape[0]
         out = torch.empty_like(masked_imgs)
         steps = int(n_steps or self.n_steps)
-        for s in range(0, V, self.max_batch):
-            e = min(V, s + self.max_batch)
-            xt = None if x_T is None else x_T[s:e].float().contiguous()
-            tape = None if eps_tape is None else eps_tape[:, s:e].float().contiguous()
-            self._calls += 1
-            check(L.pdhip_ddnm_sample(self.model._h, ptr(masked_imgs[s:e]), ptr(masks[s:e]), e - s, ptr(xt, allow_none=True),
-                                      ptr(tape, allow_none=True), self.seed + 7919 * self._calls, steps, ptr(out[s:e]),
-                                      stream()), 'pdhip_ddnm_sample')
+        key0 = self._images if first_key is None else int(first_key)
+        with torch.cuda.device(self.device):
+            for s in range(0, V, self.max_batch):
+                e = min(V, s + self.max_batch)
+                xt = None if x_T is None else x_T[s:e].float().contiguous()
+                tape = None if eps_tape is None else eps_tape[:, s:e].float().contiguous()
+                check(L.pdhip_ddnm_sample_keyed(self.model._h, ptr(masked_imgs[s:e]), ptr(masks[s:e]), e - s, ptr(xt, allow_none=True),
+                                                ptr(tape, allow_none=True), self.seed, key0 + s, steps, ptr(out[s:e]),
+                                                stream()), 'pdhip_ddnm_sample')
+        self._images = (key0 + V) if advance is None else (self._images + int(advance))
         return out
 
     def inpaint(self, masked_imgs, masks):

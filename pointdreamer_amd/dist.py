@@ -1,11 +1,13 @@
 """Multi-GPU sharding of the texturing path -- new functionality, the reference is single-GPU.
 
 Two partitionings, one process per GPU (torch.distributed; backend 'nccl' == RCCL over xGMI on ROCm):
-  * shape-parallel: independent shapes, no data-path collective (bench.py default, weak scaling);
-  * view-parallel (this module): the V views of ONE shape are split across ranks for the inpainting stage --
-    >99 % of a DDNM shape -- and assembled with a single all_gather of the inpainted images
-    (V/world x 3 x r x r f32 = 786 KB per view); projection (sub-millisecond) and the NBF unprojection
-    (34 P bytes of work) run replicated on every rank so no second collective is needed.
+  * shape-parallel: independent shapes, no data-path collective (bench.py default, weak scaling; demo.files_of_rank);
+  * view-parallel (this module): the V views of ONE shape are split across ranks.  A rank owns, for its views, everything that
+    is per-view: P1-P6 (project / raster / visibility / sparse image), the DDNM inpainting (> 99 % of the time), Uq1-Uq2 (texel
+    visibility) and N1-N3 (NBF shrink).  ONE all_gather then moves, per view, the inpainted image (3 r^2 f32), the raw and the
+    shrunk texel visibility (A^2 bytes each level) and four crop parameters; the cross-view part -- Uq3-Uq5 view selection,
+    blend, dilation and the optional completion / optimisation stages -- runs replicated on every rank (34 P bytes of work),
+    so every rank returns the full atlas and no second collective exists.
 The stage functions are injectable so the sharding / gather logic is testable on CPU with gloo."""
 import torch
 import torch.distributed as dist
@@ -32,47 +34,105 @@ def all_gather_views(local, n_views, rank, world, group=None):
     return torch.cat(pieces, 0)
 
 
+def pack_view_records(inpainted, vis, per_kernel, uv_centers, uv_scales, scale_factors):
+    """One byte record per view: [image f32 | visibility u8 | K shrunk levels u8 | centre x, centre y, scale, factor f32]."""
+    v = inpainted.shape[0]
+    dev = inpainted.device
+    par = torch.cat([uv_centers.reshape(v, 2).float(), uv_scales.reshape(v, 1).float(), scale_factors.reshape(v, 1).float()], 1)
+    parts = [inpainted.reshape(v, -1).float().contiguous().view(torch.uint8),
+             vis.reshape(v, -1).contiguous().view(torch.uint8),
+             per_kernel.permute(1, 0, 2, 3).reshape(v, -1).contiguous().view(torch.uint8),
+             par.contiguous().view(torch.uint8)]
+    return torch.cat([p.to(dev) for p in parts], 1).contiguous()
+
+
+def unpack_view_records(rec, img_shape, A, K):
+    """Inverse of pack_view_records for all V views: (inpainted [V,3,r,r], vis [V,A,A] bool, per_kernel [K,V,A,A] bool,
+    uv_centers [V,1,2], uv_scales [V,1,1], scale_factors [V])."""
+    V = rec.shape[0]
+    n_img = 4 * img_shape[0] * img_shape[1] * img_shape[2]
+    o = 0
+    img = rec[:, o:o + n_img].contiguous().view(torch.float32).reshape(V, *img_shape); o += n_img
+    vis = rec[:, o:o + A * A].contiguous().view(torch.bool).reshape(V, A, A); o += A * A
+    pk = rec[:, o:o + K * A * A].contiguous().view(torch.bool).reshape(V, K, A, A).permute(1, 0, 2, 3).contiguous(); o += K * A * A
+    par = rec[:, o:o + 16].contiguous().view(torch.float32).reshape(V, 4)
+    return img, vis, pk, par[:, 0:2].reshape(V, 1, 2).contiguous(), par[:, 2].reshape(V, 1, 1).contiguous(), par[:, 3].contiguous()
+
+
+def _subset_camera_info(camera_info, sl):
+    out = dict(camera_info)
+    for k in ('cams', 'base_dirs', 'eye_positions', 'up_dirs'):
+        if camera_info.get(k) is not None:
+            out[k] = camera_info[k][sl]
+    return out
+
+
+def default_stages():
+    """The real (HIP) stages: pipeline._before_inpaint / ours_utils.get_inpainted_images / unproject.per_view_visibility /
+    pipeline._after_inpaint."""
+    from . import ours_utils as ou, unproject as up, pipeline as pl
+
+    def before(coords, colors, vertices, faces, cam_info_local, n_local, res, cam_res, save_img_path, opts, view_offset):
+        return pl._before_inpaint(coords, colors, vertices, faces, cam_info_local, n_local, res, cam_res, save_img_path,
+                                  opts['point_validation_by_o3d'], opts['hidden_point_removal_radius'], opts['point_size'],
+                                  opts['edge_point_size'], opts['crop_img'], opts['crop_padding'], opts['mask_ratio_thresh'],
+                                  view_offset=view_offset)
+
+    def inpaint(pre, save_img_path, inpainter, n_local, method, first_key, advance, view_offset):
+        return ou.get_inpainted_images(pre['sparse'], pre['mask0'], pre['mask2'], save_img_path, inpainter, n_local, method=method,
+                                       first_key=first_key, advance=advance, view_offset=view_offset)
+
+    def visibility(pre, cam_info_local, cam_res, xatlas_dict, edge_dilate_kernels, save_img_path, view_offset):
+        import os
+        sp = None if save_img_path is None else os.path.join(save_img_path, 'shrink_per_view_edge')
+        return up.per_view_visibility(cam_info_local['cams'], cam_res, xatlas_dict['gb_pos'], xatlas_dict['mask'], pre['uv_centers'],
+                                      pre['uv_scales'], pre['padding'], pre['mesh_depths'], edge_dilate_kernels, sp, view_offset)
+
+    def after(pre_all, inpainted, vis, per_kernel, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,
+              edge_dilate_kernels, complete_unseen_by, optimize_from):
+        atlas, _ = pl._after_inpaint(pre_all, inpainted, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,
+                                     edge_dilate_kernels, complete_unseen_by, optimize_from, vis_and_shrunk=(vis, per_kernel))
+        return atlas
+    return dict(before=before, inpaint=inpaint, visibility=visibility, after=after)
+
+
 def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, xatlas_dict, camera_info, view_num, res,
                                     cam_res, rank, world, inpainter=None, texture_gen_method='DDNM_inpaint',
                                     point_size=1, edge_point_size=1, crop_img=True, crop_padding=0.05,
-                                    mask_ratio_thresh=0.82, edge_dilate_kernels=(21,), point_validation_by_o3d=False,
-                                    hidden_point_removal_radius=100, group=None, stages=None, **unused):
-    """View-parallel demo.colorize_one_mesh (complete_unseen_by='unproject', optimize_from=None).
-    Every rank returns the full atlas [A,A,3]."""
-    if stages is None:
-        from . import ours_utils as ou, unproject as up
-        stages = dict(project=_project_stage, inpaint=ou.get_inpainted_images, unproject=up.unproject_dense,
-                      dilate=up.dilate_atlas)
+                                    mask_ratio_thresh=0.82, edge_dilate_kernels=(21,), point_validation_by_o3d=True,
+                                    hidden_point_removal_radius=100, complete_unseen_by='unproject', optimize_from=None,
+                                    save_img_path=None, group=None, stages=None, shape_key=None, return_full=False, **unused):
+    """View-parallel demo.colorize_one_mesh: same keyword surface and defaults as pipeline.colorize_one_mesh, same atlas on
+    every rank (bit-identical to the single-process result for the index / copy stages; for DDNM the noise of view k is keyed by
+    its global index, so the result does not depend on `world` either).  shape_key: running index of the shape (noise key base
+    = shape_key * view_num); default = the inpainter's own image counter, which every rank advances by view_num."""
+    from . import pipeline as pl
+    pl._check_options(xatlas_dict, False, complete_unseen_by, optimize_from)
+    st = default_stages() if stages is None else stages
     mine = shard_range(view_num, rank, world)
+    sl = slice(mine.start, mine.stop)
+    opts = dict(point_validation_by_o3d=point_validation_by_o3d, hidden_point_removal_radius=hidden_point_removal_radius,
+                point_size=point_size, edge_point_size=edge_point_size, crop_img=crop_img, crop_padding=crop_padding,
+                mask_ratio_thresh=mask_ratio_thresh)
+    A = xatlas_dict['mask'].shape[1]
     with torch.no_grad():
-        pr = stages['project'](coords, colors, vertices, faces, camera_info, view_num, res, cam_res, point_size,
-                               edge_point_size, crop_img, crop_padding, mask_ratio_thresh, point_validation_by_o3d,
-                               hidden_point_removal_radius)
-        sl = slice(mine.start, mine.stop)
-        local = stages['inpaint'](pr['sparse'][sl].contiguous(), pr['mask0'][sl].contiguous(), pr['mask2'][sl].contiguous(),
-                                  None, inpainter, len(mine), method=texture_gen_method)
-        inpainted = all_gather_views(local, view_num, rank, world, group)          # the one collective
-        atlas, shr, view_ids, painted, vis = stages['unproject'](
-            inpainted, f_normals, res, camera_info['cams'], cam_res, camera_info['base_dirs'], xatlas_dict['gb_pos'],
-            xatlas_dict['mask'], xatlas_dict['per_atlas_pixel_face_id'], pr['uv_centers'], pr['uv_scales'], pr['padding'],
-            pr['scale_factors'], pr['mesh_depths'], list(edge_dilate_kernels), True)
-        atlas = stages['dilate'](atlas, xatlas_dict['mask'])
+        cam_local = _subset_camera_info(camera_info, sl)
+        pre = st['before'](coords, colors, vertices, faces, cam_local, len(mine), res, cam_res, save_img_path, opts, mine.start)
+        base = (inpainter._images if (shape_key is None and inpainter is not None) else (shape_key or 0) * view_num)
+        local = st['inpaint'](pre, save_img_path, inpainter, len(mine), texture_gen_method, base + mine.start, view_num, mine.start)
+        vis_l, pk_l = st['visibility'](pre, cam_local, cam_res, xatlas_dict, list(edge_dilate_kernels), save_img_path, mine.start)
+        K = pk_l.shape[0]
+        dev = local.device
+        v = len(mine)
+        uvc = pre['uv_centers'] if torch.is_tensor(pre['uv_centers']) else torch.full((v, 1, 2), float(pre['uv_centers'] or 0.0), device=dev)
+        uvs = pre['uv_scales'] if torch.is_tensor(pre['uv_scales']) else torch.full((v, 1, 1), float(pre['uv_scales'] or 2.0), device=dev)
+        sf = pre['scale_factors'] if torch.is_tensor(pre['scale_factors']) else torch.ones((v,), device=dev)
+        rec = pack_view_records(local, vis_l, pk_l, uvc, uvs, sf)
+        rec = all_gather_views(rec, view_num, rank, world, group)                  # the one collective
+        inpainted, vis, per_kernel, uvc_a, uvs_a, sf_a = unpack_view_records(rec, tuple(local.shape[1:]), A, K)
+        pre_all = dict(uv_centers=uvc_a, uv_scales=uvs_a, padding=pre['padding'], scale_factors=sf_a, mesh_depths=None)
+        atlas = st['after'](pre_all, inpainted, vis, per_kernel, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,
+                            edge_dilate_kernels, complete_unseen_by, optimize_from)
+    if return_full:
+        return vertices, xatlas_dict.get('uvs'), faces, xatlas_dict.get('mesh_tex_idx'), atlas, xatlas_dict['mask']
     return atlas
-
-
-def _project_stage(coords, colors, vertices, faces, camera_info, view_num, res, cam_res, point_size, edge_point_size,
-                   crop_img, crop_padding, mask_ratio_thresh, point_validation_by_o3d, hpr_radius):
-    from . import ours_utils as ou
-    cams = camera_info['cams']
-    hard, fidx, depth, vuv, uvc, uvs, pad, puv, pdep = ou.get_rendered_hard_mask_and_face_idx_batch(
-        cams, vertices, faces, coords, rescale=crop_img, padding=crop_padding)
-    hard_r = ou.resize_masks(hard, res) if cam_res != res else hard
-    pv, _ = ou.get_point_validation_by_depth(cam_res, puv, pdep, depth, offset=0.0001)
-    if point_validation_by_o3d:
-        from .hpr import hidden_point_removal
-        pv = hidden_point_removal(coords, camera_info['eye_positions'], hpr_radius, already_valid=pv)
-    pp = ou.get_point_pixels(puv, res)
-    sparse, m0, m2, sf = ou.get_sparse_images(pp, colors, pv, hard_r, None, view_num, res, point_size, edge_point_size,
-                                              mask_ratio_thresh)
-    return dict(sparse=sparse, mask0=m0, mask2=m2, scale_factors=sf, uv_centers=uvc, uv_scales=uvs, padding=pad,
-                mesh_depths=depth)

@@ -10,9 +10,11 @@ from . import _lib
 from ._lib import ptr, as_u8, stream, check
 
 
-def hidden_point_removal(points, eye_positions, radius, already_valid=None):
+def hidden_point_removal(points, eye_positions, radius, already_valid=None, return_stats=False):
     """points [N,3] (GPU), eye_positions [V,3] (numpy / list, as create_cameras returns them) -> [V,N] bool.
-    already_valid [V,N] bool (optional): points another test accepted; they are not queried and the result is the OR."""
+    already_valid [V,N] bool (optional): points another test accepted; they are not queried and the result is the OR.
+    return_stats: also return dict(exact_fallback=, unresolved=, fallback_rounds=) of the certified-verdict machinery
+    (synchronises; `unresolved` > 0 means exactly degenerate input whose verdict -- hidden -- is a convention)."""
     L = _lib.lib()
     pts = points.detach().float().contiguous()
     if not pts.is_cuda:
@@ -25,4 +27,9 @@ def hidden_point_removal(points, eye_positions, radius, already_valid=None):
     check(L.pdhip_hidden_point_removal(ptr(pts), N, ptr(eyes), V, float(radius), ptr(skip, allow_none=True), ptr(as_u8(vis)), ptr(ws),
                                        stream()),
           'pdhip_hidden_point_removal')
+    if return_stats:
+        import ctypes as C
+        out = (C.c_longlong * 3)()
+        check(L.pdhip_hpr_read_counters(ptr(ws), V, out, stream()), 'pdhip_hpr_read_counters')
+        return vis, dict(exact_fallback=int(out[0]), unresolved=int(out[1]), fallback_rounds=int(out[2]))
     return vis

@@ -80,6 +80,19 @@ def _save_png(img, file_name, channels):
     _submit(write)
 
 
+def save_HWC_u8_img(arr, file_name):
+    """uint8 [H,W,3|4] host array -> PNG (used for images composed on the device in 8-bit)."""
+    L = _lib.lib()
+    arr = np.ascontiguousarray(arr, np.uint8)
+    path = os.fspath(file_name).encode()
+    ch = arr.shape[2]
+
+    def write():
+        _lib.check(L.pdhip_io_write_png(path, arr.ctypes.data_as(C.c_void_p), arr.shape[0], arr.shape[1], ch, 1),
+                   'pdhip_io_write_png')
+    _submit(write)
+
+
 def save_CHW_RGB_img(img, file_name):
     _save_png(img, file_name, 3)
 

@@ -6,6 +6,7 @@ from . import _lib
 from ._lib import ptr, as_u8, stream, check
 from .camera_utils import stack_params
 from .extract_texture_map import rasterize, interpolate
+from .ours_utils import crop_params
 
 
 def texture_coordinates(cams, vertices, faces, uvs, mesh_tex_idx, uv_centers, uv_scales, padding, inpaint_scale_factors, res):
@@ -20,9 +21,7 @@ def texture_coordinates(cams, vertices, faces, uvs, mesh_tex_idx, uv_centers, uv
     ws = torch.empty((4 * V,), dtype=torch.int32, device=dev)
     check(L.pdhip_project_points(ptr(cp), V, ptr(verts), Vn, None, 0, 0, 0.0, ptr(pos), ptr(vuv), None, None, None, None,
                                  ptr(ws), stream()), 'pdhip_project_points')
-    uvc = uv_centers.float().reshape(V, 2).contiguous()
-    uvs_ = uv_scales.float().reshape(V).contiguous()
-    sf = inpaint_scale_factors.float().reshape(V).contiguous()
+    uvc, uvs_, padding, sf = crop_params(V, dev, uv_centers, uv_scales, padding, inpaint_scale_factors)
     check(L.pdhip_rescale_vertices(ptr(pos), V, Vn, ptr(uvc), ptr(uvs_), ptr(sf), float(padding), stream()), 'pdhip_rescale_vertices')
     fidx, bary, _, _ = rasterize(pos, faces, res)
     uv_map = interpolate(uvs, fidx, bary, mesh_tex_idx)

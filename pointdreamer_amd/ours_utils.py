@@ -22,6 +22,24 @@ def _dev(t):
     return t.device
 
 
+def crop_params(V, dev, uv_centers, uv_scales, padding, inpaint_scale_factors):
+    """The crop / rescale parameters in the one form the kernels take: centres [V,2], scales [V], padding (float), factors [V].
+    With crop_img=False the reference hands python scalars around (ours_utils.py:132-136: centre 0, scale 2, padding 0) and
+    `None` for the inpaint scale factors where no rescale happened (unproject.py:260-262); both broadcast like tensors there."""
+    def vec(x, n, default):
+        if x is None:
+            x = default
+        if torch.is_tensor(x):
+            x = x.to(dev).float().reshape(-1)
+            return (x.expand(n) if x.numel() == 1 else x.reshape(n)).contiguous()
+        return torch.full((n,), float(x), device=dev)
+    if torch.is_tensor(uv_centers) and uv_centers.numel() == 2 * V:
+        uvc = uv_centers.to(dev).float().reshape(V, 2).contiguous()
+    else:
+        uvc = vec(uv_centers, 2 * V, 0.0).reshape(V, 2)
+    return uvc, vec(uv_scales, V, 2.0), float(0.0 if padding is None else padding), vec(inpaint_scale_factors, V, 1.0)
+
+
 def transform_points(cams, pts):
     """cam.transform for a list of cameras: pts[M,3] -> [V,M,3] NDC (kaolin Camera.transform contract)."""
     L = _lib.lib()
@@ -112,8 +130,9 @@ def get_point_validation_by_o3d(points, eye_positions=None, hidden_point_removal
 
 
 def get_sparse_images(point_pixels, colors, point_validation, hard_masks, save_path, view_num, res, point_size,
-                      edge_point_size, mask_ratio_thresh):
-    """ours_utils.py:848-882 -> sparse_imgs[V,3,r,r], hard_mask0s, hard_mask2s, scale_factors[V]."""
+                      edge_point_size, mask_ratio_thresh, view_offset=0):
+    """ours_utils.py:848-882 -> sparse_imgs[V,3,r,r], hard_mask0s, hard_mask2s, scale_factors[V].
+    view_offset: index of the first view in the file names (a rank that owns views [lo, hi) of a shape)."""
     L = _lib.lib()
     dev = _dev(point_pixels)
     point_pixels = point_pixels.to(torch.int64).contiguous()
@@ -134,9 +153,10 @@ def get_sparse_images(point_pixels, colors, point_validation, hard_masks, save_p
         os.makedirs(save_path, exist_ok=True)
         for i in range(V):
             save_mask = (m0[i][0] * m2[i][0]).unsqueeze(0)
-            io_utils.save_CHW_RGBA_img(torch.cat([sparse[i], save_mask]), os.path.join(save_path, f'{i}_sparse.png'))
-            io_utils.save_CHW_RGB_img(m0[i], os.path.join(save_path, f'{i}_mask0.png'))
-            io_utils.save_CHW_RGB_img(m2[i], os.path.join(save_path, f'{i}_mask2.png'))
+            k = i + view_offset
+            io_utils.save_CHW_RGBA_img(torch.cat([sparse[i], save_mask]), os.path.join(save_path, f'{k}_sparse.png'))
+            io_utils.save_CHW_RGB_img(m0[i], os.path.join(save_path, f'{k}_mask0.png'))
+            io_utils.save_CHW_RGB_img(m2[i], os.path.join(save_path, f'{k}_mask2.png'))
     return sparse, m0, m2, sf
 
 
@@ -177,25 +197,38 @@ def naive_inpainting(img, no_need_inpaint_mask2, method='linear'):
     return nearest_fill(img.unsqueeze(0), m, 'CHW')[0]
 
 
-def save_inpainted_images(out, hard_mask0s, save_path, view_num, method):
+def save_inpainted_images(out, hard_mask0s, save_path, view_num, method, view_offset=0):
     """`{k}_inpainted.png`: RGBA with alpha = mask0 for DDNM (ours_utils.py:924-928), RGB for nearest (:939-941)."""
     os.makedirs(save_path, exist_ok=True)
     for i in range(view_num):
         if method == 'DDNM_inpaint':
             rgba = torch.cat([out[i], hard_mask0s[i][0].unsqueeze(0)])
-            io_utils.save_CHW_RGBA_img(rgba, os.path.join(save_path, f'{i}_inpainted.png'))
+            io_utils.save_CHW_RGBA_img(rgba, os.path.join(save_path, f'{i + view_offset}_inpainted.png'))
         else:
-            io_utils.save_CHW_RGB_img(out[i], os.path.join(save_path, f'{i}_inpainted.png'))
+            io_utils.save_CHW_RGB_img(out[i], os.path.join(save_path, f'{i + view_offset}_inpainted.png'))
 
 
-def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpainter, view_num, method='linear'):
-    """ours_utils.py:884-951 -> inpainted[V,3,r,r]."""
+def load_inpainted_images(save_path, view_num, device):
+    """demo.py:138-147: when every `{i}_inpainted.png` of a shape is already on disk the reference loads them instead of
+    inpainting again (its resume surface: the 8-bit RGB of the saved files).  Returns [V,3,r,r] float32 or None."""
+    if save_path is None:
+        return None
+    paths = [os.path.join(save_path, f'{i}_inpainted.png') for i in range(view_num)]
+    if not all(os.path.exists(p) for p in paths):
+        return None
+    io_utils.flush()                                  # a queued write of the same files must have landed
+    return torch.stack([io_utils.load_CHW_RGB_img(p) for p in paths], 0).to(device)
+
+
+def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpainter, view_num, method='linear',
+                         first_key=None, advance=None, view_offset=0):
+    """ours_utils.py:884-951 -> inpainted[V,3,r,r].  first_key / advance: the noise keys of these views (Inpainter.inpaint_views)."""
     if method == 'DDNM_inpaint':
-        out = inpainter.inpaint_views(sparse_imgs, hard_mask2s[:, 0].contiguous())
+        out = inpainter.inpaint_views(sparse_imgs, hard_mask2s[:, 0].contiguous(), first_key=first_key, advance=advance)
     elif method == 'nearest':
         out = nearest_fill(sparse_imgs, hard_mask2s[:, 0].contiguous(), 'CHW')
     else:
         raise NotImplementedError(f"texture_gen_method={method!r} is not built (DDNM_inpaint | nearest)")
     if save_path is not None:
-        save_inpainted_images(out, hard_mask0s, save_path, view_num, method)
+        save_inpainted_images(out, hard_mask0s, save_path, view_num, method, view_offset)
     return out

@@ -24,8 +24,11 @@ def _check_options(xatlas_dict, refine_point_validation_by_remove_abnormal_depth
 
 
 def _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res, cam_res, save_img_path, point_validation_by_o3d,
-                    hidden_point_removal_radius, point_size, edge_point_size, crop_img, crop_padding, mask_ratio_thresh, glctx=None):
-    """demo.py:93-129: project, rasterise, visibility, sparse views -- everything of one shape ahead of the inpainter."""
+                    hidden_point_removal_radius, point_size, edge_point_size, crop_img, crop_padding, mask_ratio_thresh, glctx=None,
+                    view_offset=0):
+    """demo.py:93-129: project, rasterise, visibility, sparse views -- everything of one shape ahead of the inpainter.
+    Every view is independent here: `camera_info` may hold a subset of a shape's cameras (view-parallel sharding), view_offset
+    is then the index of its first view in the per-view file names."""
     cams = camera_info['cams']
     hard_masks, face_idxs, mesh_depths, vertice_uvs, uv_centers, uv_scales, padding, point_uvs, point_depths = \
         ou.get_rendered_hard_mask_and_face_idx_batch(cams, vertices, faces, coords, glctx=glctx, rescale=crop_img,
@@ -41,19 +44,21 @@ def _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res,
     point_pixels = ou.get_point_pixels(point_uvs, res)
     sparse_imgs, hard_mask0s, hard_mask2s, scale_factors = ou.get_sparse_images(
         point_pixels, colors, point_validation, hard_masks, save_img_path, view_num, res, point_size,
-        edge_point_size, mask_ratio_thresh)
+        edge_point_size, mask_ratio_thresh, view_offset=view_offset)
     return dict(sparse=sparse_imgs, mask0=hard_mask0s, mask2=hard_mask2s, scale_factors=scale_factors, uv_centers=uv_centers,
                 uv_scales=uv_scales, padding=padding, mesh_depths=mesh_depths, point_validation=point_validation)
 
 
 def _after_inpaint(pre, inpainted, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res, edge_dilate_kernels,
-                   complete_unseen_by, optimize_from, glctx=None):
-    """demo.py:167-236: unproject, complete the unseen texels, optionally optimise.  Returns (atlas, intermediates)."""
+                   complete_unseen_by, optimize_from, glctx=None, save_img_path=None, vis_and_shrunk=None):
+    """demo.py:167-236: unproject, complete the unseen texels, optionally optimise.  Returns (atlas, intermediates).
+    vis_and_shrunk: per-view visibility + NBF levels gathered from the ranks that own the views (dist.py); else computed here."""
     cams, base_dirs, eye_positions = camera_info['cams'], camera_info['base_dirs'], camera_info['eye_positions']
     gb_pos, mask, face_id = xatlas_dict['gb_pos'], xatlas_dict['mask'], xatlas_dict['per_atlas_pixel_face_id']
     atlas, shrinked, view_ids, painted, vis = up.unproject_dense(
         inpainted, f_normals, res, cams, cam_res, base_dirs, gb_pos, mask, face_id, pre['uv_centers'], pre['uv_scales'],
-        pre['padding'], pre['scale_factors'], pre['mesh_depths'], list(edge_dilate_kernels), complete_unseen_by == 'unproject')
+        pre['padding'], pre['scale_factors'], pre.get('mesh_depths'), list(edge_dilate_kernels), complete_unseen_by == 'unproject',
+        save_img_path=save_img_path, vis_and_shrunk=vis_and_shrunk)
     if complete_unseen_by == 'neighbor':
         # demo.py:180-200: faces that still own unpainted texels -> subdivide, average over mesh neighbours, nearest fill
         tif = up.unpainted_face_ids(face_id, painted, faces.shape[0])
@@ -80,16 +85,21 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
                       texture_gen_method='DDNM_inpaint', point_size=1, edge_point_size=1, crop_img=True,
                       crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None, edge_dilate_kernels=(21,),
                       complete_unseen_by='unproject', inpainter=None, glctx=None, logger=None,
-                      xatlas_texture_res=1024, refine_res=512, return_intermediates=False, **kwargs):
+                      xatlas_texture_res=1024, refine_res=512, return_intermediates=False, reuse_inpainted=True, **kwargs):
     _check_options(xatlas_dict, refine_point_validation_by_remove_abnormal_depth, complete_unseen_by, optimize_from)
     with torch.no_grad():
         pre = _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res, cam_res, save_img_path,
                               point_validation_by_o3d, hidden_point_removal_radius, point_size, edge_point_size, crop_img,
                               crop_padding, mask_ratio_thresh, glctx)
-        inpainted = ou.get_inpainted_images(pre['sparse'], pre['mask0'], pre['mask2'], save_img_path, inpainter, view_num,
-                                            method=texture_gen_method)
+        # demo.py:138-147: every {i}_inpainted.png already on disk -> load them instead of inpainting again (resume surface)
+        inpainted = ou.load_inpainted_images(save_img_path, view_num, coords.device) if reuse_inpainted else None
+        if inpainted is None:
+            inpainted = ou.get_inpainted_images(pre['sparse'], pre['mask0'], pre['mask2'], save_img_path, inpainter, view_num,
+                                                method=texture_gen_method)
+        elif logger is not None:
+            logger.info('All inpainted images exist, load them instead of inpainting again')
         atlas, post = _after_inpaint(pre, inpainted, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,
-                                     edge_dilate_kernels, complete_unseen_by, optimize_from, glctx)
+                                     edge_dilate_kernels, complete_unseen_by, optimize_from, glctx, save_img_path)
     if return_intermediates:
         return dict(atlas=atlas, inpainted=inpainted, sparse=pre['sparse'], mask0=pre['mask0'], mask2=pre['mask2'],
                     view_ids=post['view_ids'], painted=post['painted'], shrinked=post['shrinked'], visibility=post['visibility'],
@@ -106,8 +116,10 @@ def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpaint
     stage runs per shape, the views of ALL shapes go through the inpainter together (one UNet batch of len(shapes) * V views --
     the 8x8 .. 32x32 levels of the UNet fill the chip better), unprojection / completion / optimisation run per shape.
     `shapes`: list of dicts with coords, colors, vertices, faces, f_normals, xatlas (gb_pos, mask, per_atlas_pixel_face_id
-    [, uvs, mesh_tex_idx]).  Same stages and results as colorize_one_mesh shape by shape; `save_img_paths`: one directory per
-    shape for the per-view PNGs.  Returns the atlases, or colorize_one_mesh's 6-tuples with return_full."""
+    [, uvs, mesh_tex_idx]).  Same stages and results as colorize_one_mesh shape by shape -- also for DDNM: the noise of a view is
+    keyed by the running image count of the inpainter (Inpainter.inpaint_views), which advances by V per shape either way;
+    `save_img_paths`: one directory per shape for the per-view PNGs.  Returns the atlases, or colorize_one_mesh's 6-tuples with
+    return_full.  (The `{i}_inpainted.png` reuse of demo.py:138-147 applies per shape only in colorize_one_mesh.)"""
     for sh in shapes:
         _check_options(sh['xatlas'], refine_point_validation_by_remove_abnormal_depth, complete_unseen_by, optimize_from)
     paths = list(save_img_paths) if save_img_paths is not None else [None] * len(shapes)
@@ -124,7 +136,7 @@ def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpaint
             if pth is not None:
                 ou.save_inpainted_images(inp, pr['mask0'], pth, view_num, texture_gen_method)
             atlas, _ = _after_inpaint(pr, inp, sh['vertices'], sh['faces'], sh['f_normals'], sh['xatlas'], camera_info, res,
-                                      cam_res, edge_dilate_kernels, complete_unseen_by, optimize_from)
+                                      cam_res, edge_dilate_kernels, complete_unseen_by, optimize_from, None, pth)
             xat = sh['xatlas']
             outs.append((sh['vertices'], xat.get('uvs'), sh['faces'], xat.get('mesh_tex_idx'), atlas, xat['mask']) if return_full
                         else atlas)

@@ -1,20 +1,14 @@
 """Host-side mirror of the reference's pointdreamer/unproject.py (rows Uq1-Uq5, N1-N3): same names,
 argument order and return tuples (/root/reference/pointdreamer/unproject.py:201-425, 429-475, 480-504);
 each routes to libpdhip.so.  The debug PNG triptychs the reference always writes
-(unproject.py:459-474) are not produced: they are not consumed by anything downstream."""
+(unproject.py:459-474, `others/shrink_per_view_edge/{v}.png`) are produced by save_shrink_triptychs when a save path is given."""
 import ctypes as C
 import torch
 
 from . import _lib
 from ._lib import ptr, as_u8, stream, check
 from .camera_utils import stack_params
-from .ours_utils import nearest_fill, _dev
-
-
-def _as_vec(x, V, dev):
-    if torch.is_tensor(x):
-        return x.to(dev).float().reshape(-1).contiguous()
-    return torch.full((V,), float(x), device=dev)
+from .ours_utils import nearest_fill, _dev, crop_params
 
 
 def texel_visibility(cams, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, cam_res, offset=0.0001):
@@ -26,8 +20,7 @@ def texel_visibility(cams, gb_pos, mask, uv_centers, uv_scales, padding, mesh_no
     cp = stack_params(cams)
     gb = gb_pos[0].float().contiguous()
     m = as_u8(mask[0, :, :, 0].contiguous())
-    uvc = uv_centers.float().reshape(V, 2).contiguous()
-    uvs = uv_scales.float().reshape(V).contiguous()
+    uvc, uvs, padding, _ = crop_params(V, dev, uv_centers, uv_scales, padding, None)
     md = mesh_normalized_depths.float().contiguous()
     vis = torch.empty((V, A, A), dtype=torch.bool, device=dev)
     check(L.pdhip_texel_visibility(ptr(cp), V, ptr(gb), ptr(m), A, ptr(uvc), ptr(uvs), float(padding), ptr(md),
@@ -57,25 +50,33 @@ def shrink_visibility(per_pixel_mask, vis_VAA, kernel_sizes):
     return out
 
 
-def unproject_dense(inpainted_images, f_normals, view_img_res, cams, cam_res, base_dirs, gb_pos, mask,
-                    per_atlas_pixel_face_id, uv_centers, uv_scales, padding, inpaint_scale_factors,
-                    mesh_normalized_depths, edge_dilate_kernels, complete_unseen_by_projection=False):
-    """The whole of unproject() in its dense [A,A] form (no compaction, no host sync).
-    Returns atlas[A,A,3], shrinked[V,A,A] bool (last level), view_ids[A,A] int32, painted[A,A] bool, vis[V,A,A]."""
+def save_shrink_triptychs(per_pixel_mask, vis_VAA, kernel, save_path, view_offset=0):
+    """`{save_path}/{v}.png` exactly as unproject.py:459-474 composes them (device composition, native PNG encode on the
+    io_utils write queue)."""
+    import os
+    from . import io_utils
     L = _lib.lib()
+    dev = _dev(vis_VAA)
+    V, A, _ = vis_VAA.shape
+    out = torch.empty((V, A, 3 * A + 20, 3), dtype=torch.uint8, device=dev)
+    ws = torch.empty(((2 * V + 1) * A * A,), dtype=torch.uint8, device=dev)
+    check(L.pdhip_nbf_triptych(ptr(as_u8(per_pixel_mask.contiguous())), ptr(as_u8(vis_VAA.contiguous())), V, A, int(kernel),
+                               ptr(out), ptr(ws), stream()), 'pdhip_nbf_triptych')
+    os.makedirs(save_path, exist_ok=True)
+    host = out.cpu().numpy()
+    for v in range(V):
+        io_utils.save_HWC_u8_img(host[v], os.path.join(save_path, f'{v + view_offset}.png'))
+
+
+def per_view_visibility(cams, cam_res, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, edge_dilate_kernels,
+                        save_path=None, view_offset=0):
+    """Uq1-Uq2 + N1-N3 of the given views (each view is independent of the others -- the part of unproject() a rank owns for its
+    views under view-parallel sharding): visibility [V,A,A] bool, shrunk visibility per kernel level [K,V,A,A] bool."""
     dev = _dev(gb_pos)
     V = len(cams)
     A = mask.shape[1]
-    if uv_scales is None or uv_centers is None or inpaint_scale_factors is None or padding is None:
-        # unproject.py:260-262: uv = xy*0.5+0.5  ==  centre 0, scale 2, padding 0, factor 1
-        uv_centers = torch.zeros((V, 1, 2), device=dev)
-        uv_scales = torch.full((V, 1, 1), 2.0, device=dev)
-        inpaint_scale_factors, padding = torch.ones((V,), device=dev), 0.0
-    if not torch.is_tensor(uv_centers):
-        uv_centers = torch.full((V, 1, 2), float(uv_centers), device=dev)
-    if not torch.is_tensor(uv_scales):
-        uv_scales = torch.full((V, 1, 1), float(uv_scales), device=dev)
-    vis = texel_visibility(cams, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, cam_res)
+    uvc, uvs, padding, _ = crop_params(V, dev, uv_centers, uv_scales, padding, None)
+    vis = texel_visibility(cams, gb_pos, mask, uvc, uvs, padding, mesh_normalized_depths, cam_res)
     per_pixel_mask = mask[0, :, :, 0].contiguous()
     kernel_sizes = list(edge_dilate_kernels) * (A // 256)          # list repetition, unproject.py:289
     if len(kernel_sizes) == 0:
@@ -84,24 +85,60 @@ def unproject_dense(inpainted_images, f_normals, view_img_res, cams, cam_res, ba
     # consulted (unproject.py:324-346): compute exactly those
     K = 1 if int(kernel_sizes[0]) == 0 else min(len(edge_dilate_kernels), len(kernel_sizes))
     per_kernel = shrink_visibility(per_pixel_mask, vis, kernel_sizes[:K])
+    if save_path is not None and int(kernel_sizes[0]) != 0:
+        save_shrink_triptychs(per_pixel_mask, vis, int(kernel_sizes[-1]), save_path, view_offset)
+    return vis, per_kernel
+
+
+def blend_views(inpainted_images, f_normals, view_img_res, cams, base_dirs, gb_pos, mask, per_atlas_pixel_face_id, uv_centers,
+                uv_scales, padding, inpaint_scale_factors, vis, per_kernel, complete_unseen_by_projection=False):
+    """Uq3-Uq4 over ALL views (unproject.py:298-400): per-texel view selection + colour fetch.
+    Returns atlas[A,A,3], view_ids[A,A] int32, painted[A,A] bool."""
+    L = _lib.lib()
+    dev = _dev(gb_pos)
+    V = len(cams)
+    A = mask.shape[1]
+    K = per_kernel.shape[0]
+    uvc, uvs, padding, sf = crop_params(V, dev, uv_centers, uv_scales, padding, inpaint_scale_factors)
+    per_pixel_mask = mask[0, :, :, 0].contiguous()
     cp = stack_params(cams)
     gb = gb_pos[0].float().contiguous()
     fid = per_atlas_pixel_face_id[0].to(torch.int64).contiguous()
     fn = f_normals.float().contiguous()
     bd = base_dirs.float().contiguous()
-    uvc = uv_centers.float().reshape(V, 2).contiguous()
-    uvs = uv_scales.float().reshape(V).contiguous()
-    sf = _as_vec(inpaint_scale_factors, V, dev)
     img = inpainted_images.float().contiguous()
     atlas = torch.empty((A, A, 3), device=dev)
     painted = torch.empty((A, A), dtype=torch.bool, device=dev)
     view_ids = torch.empty((A, A), dtype=torch.int32, device=dev)
     check(L.pdhip_view_select_blend(ptr(cp), V, ptr(gb), ptr(as_u8(per_pixel_mask)), ptr(fid), A, ptr(fn), ptr(bd),
-                                    ptr(uvc), ptr(uvs), float(padding), ptr(sf), ptr(as_u8(per_kernel)), K,
-                                    ptr(as_u8(vis)), 1 if complete_unseen_by_projection else 0, ptr(img),
+                                    ptr(uvc), ptr(uvs), float(padding), ptr(sf), ptr(as_u8(per_kernel.contiguous())), K,
+                                    ptr(as_u8(vis.contiguous())), 1 if complete_unseen_by_projection else 0, ptr(img),
                                     int(view_img_res), ptr(atlas), ptr(as_u8(painted)), ptr(view_ids), stream()),
           'pdhip_view_select_blend')
-    return atlas, per_kernel[K - 1], view_ids, painted, vis
+    return atlas, view_ids, painted
+
+
+def unproject_dense(inpainted_images, f_normals, view_img_res, cams, cam_res, base_dirs, gb_pos, mask,
+                    per_atlas_pixel_face_id, uv_centers, uv_scales, padding, inpaint_scale_factors,
+                    mesh_normalized_depths, edge_dilate_kernels, complete_unseen_by_projection=False, save_img_path=None,
+                    vis_and_shrunk=None):
+    """The whole of unproject() in its dense [A,A] form (no compaction, no host sync).
+    Returns atlas[A,A,3], shrinked[V,A,A] bool (last level), view_ids[A,A] int32, painted[A,A] bool, vis[V,A,A].
+    vis_and_shrunk: (vis, per_kernel) already computed (gathered from the ranks that own the views)."""
+    if uv_scales is None or uv_centers is None or inpaint_scale_factors is None or padding is None:
+        # unproject.py:260-262: uv = xy*0.5+0.5  ==  centre 0, scale 2, padding 0, factor 1
+        uv_centers, uv_scales, inpaint_scale_factors, padding = None, None, None, None
+    if vis_and_shrunk is None:
+        import os
+        vis, per_kernel = per_view_visibility(
+            cams, cam_res, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, edge_dilate_kernels,
+            None if save_img_path is None else os.path.join(save_img_path, 'shrink_per_view_edge'))
+    else:
+        vis, per_kernel = vis_and_shrunk
+    atlas, view_ids, painted = blend_views(inpainted_images, f_normals, view_img_res, cams, base_dirs, gb_pos, mask,
+                                           per_atlas_pixel_face_id, uv_centers, uv_scales, padding, inpaint_scale_factors, vis,
+                                           per_kernel, complete_unseen_by_projection)
+    return atlas, per_kernel[per_kernel.shape[0] - 1], view_ids, painted, vis
 
 
 def compact_texels(gb_pos, mask, view_ids):
@@ -132,7 +169,7 @@ def unproject(inpainted_images, vertices, f_normals, view_img_res, cams, cam_res
     atlas, shr, view_ids, painted, _ = unproject_dense(
         inpainted_images, f_normals, view_img_res, cams, cam_res, base_dirs, gb_pos, mask, per_atlas_pixel_face_id,
         uv_centers, uv_scales, padding, inpaint_scale_factors, mesh_normalized_depths, edge_dilate_kernels,
-        complete_unseen_by_projection)
+        complete_unseen_by_projection, save_img_path)
     points, coords, pvid = compact_texels(gb_pos, mask, view_ids)
     return atlas, shr, pvid, coords, points, painted
 

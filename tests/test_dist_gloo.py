@@ -33,26 +33,47 @@ def _worker(rank, world, port, n_views, ret):
         got = pdist.all_gather_views(full[mine.start:mine.stop].clone(), n_views, rank, world)
         assert torch.equal(got, full), "all_gather_views must reassemble the views in order on every rank"
 
-        calls = {'inpaint_views': None}
+        # the view-parallel driver with injected CPU stages: a rank owns project / inpaint / visibility of ITS views, one
+        # all_gather of the per-view records, the cross-view stage replicated
+        A, K, r = 8, 2, 4
+        gen = torch.Generator().manual_seed(5)
+        all_vis = torch.rand((n_views, A, A), generator=gen) > 0.5
+        all_pk = torch.rand((K, n_views, A, A), generator=gen) > 0.5
+        all_uvc = torch.rand((n_views, 1, 2), generator=gen)
+        all_uvs = torch.rand((n_views, 1, 1), generator=gen) + 1
+        all_sf = torch.rand((n_views,), generator=gen) + 0.5
+        calls = {}
 
-        def project(coords, colors, *a):
-            return dict(sparse=full.clone(), mask0=torch.ones_like(full), mask2=torch.ones_like(full),
-                        scale_factors=torch.ones(n_views), uv_centers=None, uv_scales=None, padding=0.05, mesh_depths=None)
+        def before(coords, colors, vertices, faces, cam_local, n_local, res, cam_res, save, opts, view_offset):
+            assert n_local == len(mine) and view_offset == mine.start and cam_local['cams'] == list(mine)
+            assert opts['point_validation_by_o3d'] is True          # same default as pipeline.colorize_one_mesh
+            sl = slice(mine.start, mine.stop)
+            return dict(sparse=full[sl].clone(), mask0=torch.ones_like(full[sl]), mask2=torch.ones_like(full[sl]),
+                        scale_factors=all_sf[sl].clone(), uv_centers=all_uvc[sl].clone(), uv_scales=all_uvs[sl].clone(), padding=0.05,
+                        mesh_depths=None)
 
-        def inpaint(sparse, m0, m2, save_path, inpainter, view_num, method):
-            calls['inpaint_views'] = view_num
-            return sparse * 2.0 + 1.0                                  # stands in for the DDNM stage
+        def inpaint(pre, save, inpainter, n_local, method, first_key, advance, view_offset):
+            calls['inpaint'] = (n_local, first_key, advance)
+            return pre['sparse'] * 2.0 + 1.0                          # stands in for the DDNM stage
 
-        def unproject(inpainted, *a):
-            return inpainted.sum(0).permute(1, 2, 0), None, None, None, None
+        def visibility(pre, cam_local, cam_res, xatlas, kernels, save, view_offset):
+            sl = slice(mine.start, mine.stop)
+            return all_vis[sl].clone(), all_pk[:, sl].clone()
+
+        def after(pre_all, inpainted, vis, pk, vertices, faces, f_normals, xatlas, camera_info, res, cam_res, kernels, cub, opt):
+            assert torch.equal(vis, all_vis) and torch.equal(pk, all_pk)
+            assert torch.equal(pre_all['uv_centers'], all_uvc) and torch.equal(pre_all['uv_scales'], all_uvs)
+            assert torch.equal(pre_all['scale_factors'], all_sf) and pre_all['padding'] == 0.05
+            return inpainted.sum(0).permute(1, 2, 0)
 
         atlas = pdist.colorize_one_mesh_view_parallel(
-            None, None, None, None, None, dict(gb_pos=None, mask=None, per_atlas_pixel_face_id=None),
-            dict(cams=None, base_dirs=None, eye_positions=None), n_views, 4, 8, rank, world,
-            stages=dict(project=project, inpaint=inpaint, unproject=unproject, dilate=lambda a, m: a))
+            None, None, None, None, None, dict(gb_pos=None, mask=torch.zeros((1, A, A, 1)), per_atlas_pixel_face_id=None),
+            dict(cams=list(range(n_views)), base_dirs=None, eye_positions=None), n_views, r, 8, rank, world, shape_key=3,
+            stages=dict(before=before, inpaint=inpaint, visibility=visibility, after=after))
         expect = (full * 2.0 + 1.0).sum(0).permute(1, 2, 0)
         assert torch.equal(atlas, expect), "every rank must hold the full atlas built from all views"
-        assert calls['inpaint_views'] == len(mine), "each rank inpaints only its own block of views"
+        assert calls['inpaint'] == (len(mine), 3 * n_views + mine.start, n_views), \
+            "each rank inpaints only its own block of views, with noise keys = global view indices"
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

@@ -273,22 +273,35 @@ def test_full_size_shape_properties(pd):
     assert np.array_equal(N_(atlas), o['atlas_img'])
 
 
-@pytest.mark.parametrize("n,shape", [(3000, 'sphere'), (30000, 'sphere'), (4000, 'blob')])
+@pytest.mark.parametrize("n,shape", [(3000, 'sphere'), (30000, 'sphere'), (4000, 'blob'), (30000, 'noisy')])
 def test_p3b_hidden_point_removal_vs_qhull(pd, n, shape):
-    """Device HPR (per-point GJK hull-vertex test) vs the oracle (same spherical flip + qhull through scipy).
-    open3d itself is absent (parity unpinned); agreement with qhull is required up to facet-tolerance cases."""
+    """Device HPR (per-point certified GJK hull-vertex test + double-double fallback) vs the oracle (same spherical flip +
+    qhull through scipy; open3d itself is absent -- parity unpinned).  Row P3b is an index row: the verdicts must be
+    IDENTICAL.  The only admissible exception is a point inside qhull's own merge tolerance of a hull facet (the device
+    answers for the exact hull): each such point must have |signed distance to the hull of the other points| < 1e-9
+    (radius 100 => coordinates ~ 200, qhull's roundoff ~ 1e-13), and no query may be left uncertified."""
     from pointdreamer_amd import hpr
     rng = np.random.default_rng(n)
     if shape == 'sphere':
         pts, _ = pd['syn'].sphere_points(n, seed=n)
+    elif shape == 'noisy':                                 # a rough surface: many points just above / below the hull facets
+        pts, _ = pd['syn'].sphere_points(n, seed=n + 1)
+        pts = (pts * (1.0 + 0.02 * rng.standard_normal((n, 1)))).astype(np.float32)
     else:                                                  # a solid blob: most points are interior, hence hidden
         pts = (rng.standard_normal((n, 3)) * 0.15).astype(np.float32)
     _, _, eyes, _ = pd['cu'].create_cameras(8, 1.6, 512, device=DEV)
-    got = N_(hpr.hidden_point_removal(T(pts), eyes, 100))
+    got, st = hpr.hidden_point_removal(T(pts), eyes, 100, return_stats=True)
+    got = N_(got)
     want = oproj.point_validation_by_hpr(pts, eyes, 100)
     assert got.shape == want.shape == (8, n)
-    mism = (got != want).mean()
-    assert mism < 5e-4, mism          # (sphere clouds: every point is on or near a hull facet; measured 1.4e-4)
+    assert st['unresolved'] == 0, st
+    assert st['exact_fallback'] <= 0.01 * 8 * n, st       # the f64 certificates decide all but a handful
+    bad = np.argwhere(got != want)
+    for v, i in bad[:50]:
+        m = oproj.hpr_margin(oproj.hpr_flip(pts, eyes[v], 100), i)
+        assert abs(m) < 1e-9, (v, i, m, bool(got[v, i]), bool(want[v, i]))
+        assert bool(got[v, i]) == (m > 0), (v, i, m)      # the device verdict is the exact one
+    assert len(bad) <= 2, (len(bad), st)
     frac = want.mean()
     assert 0.05 < frac < 0.8
     if shape == 'sphere':
@@ -299,6 +312,28 @@ def test_p3b_hidden_point_removal_vs_qhull(pd, n, shape):
     # through the reference-signature entry point
     got2 = pd['ou'].get_point_validation_by_o3d(T(pts), eyes, 100)
     assert np.array_equal(N_(got2), got)
+
+
+def test_p3b_duplicates_and_tiny_clouds(pd):
+    """Coinciding points: the smallest index is the hull vertex, the copies are hidden (qhull keeps one of them, which one is
+    its processing order); clouds below the two-level threshold and of a handful of points take the one-level path."""
+    from pointdreamer_amd import hpr
+    pts, _ = pd['syn'].sphere_points(2000, seed=5)
+    pts = np.concatenate([pts, pts[:40]], 0)               # 40 exact duplicates appended
+    _, _, eyes, _ = pd['cu'].create_cameras(4, 1.6, 512, device=DEV)
+    got, st = hpr.hidden_point_removal(T(pts), eyes, 100, return_stats=True)
+    got = N_(got)
+    base = oproj.point_validation_by_hpr(pts[:2000], eyes, 100)
+    assert st['unresolved'] == 0, st
+    assert np.array_equal(got[:, :2000], base)
+    assert not got[:, 2000:].any()
+    for n in (1, 2, 3, 4, 5, 17):
+        p = pts[:n]
+        g = N_(hpr.hidden_point_removal(T(p), eyes, 100))
+        if n >= 4:
+            assert np.array_equal(g, oproj.point_validation_by_hpr(p, eyes, 100))
+        else:                                              # fewer than 4 points: every point is extreme (qhull refuses such input)
+            assert g.all()
 
 
 def test_p3b_skip_mask_gives_the_or(pd):

@@ -1,0 +1,44 @@
+"""UNet forward latency at small and large batches (rows U1 / 8e: view-parallel runs batch 1 per rank).
+Usage (GPU box): python tools/time_unet.py [--batches 1 2 4 8 32] [--iters 10] -> gpurun_out/unet_latency.json"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import pointdreamer_amd.ddnm_inpainting as di
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batches', type=int, nargs='*', default=[1, 2, 4, 8, 32])
+ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--sampler-steps', type=int, default=10, help='also time this many DDNM steps through pdhip_ddnm_sample (0 = skip)')
+a = ap.parse_args()
+dev = torch.device('cuda:0')
+sd = di.random_state_dict(dict(di.IMAGENET_256), seed=0)
+rows = []
+for N in a.batches:
+    m = di.UNetModel(max_batch=N, device=dev, **di.IMAGENET_256)
+    m.load_state_dict(sd)
+    x = torch.randn((N, 3, 256, 256), device=dev)
+    t = torch.full((N,), 500.0, device=dev)
+    for _ in range(3):
+        m(x, t)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.iters):
+        m(x, t)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.iters
+    row = dict(batch=N, forward_ms=round(ms, 3), ms_per_image=round(ms / N, 3), tflops_effective=round(2.2397 * N / ms, 1))
+    if a.sampler_steps:
+        inp = di.Inpainter.__new__(di.Inpainter)
+        inp.device, inp.model, inp.seed, inp.n_steps, inp._calls, inp.max_batch = dev, m, 1234, a.sampler_steps, 0, N
+        imgs = torch.rand((N, 3, 256, 256), device=dev); masks = (torch.rand((N, 256, 256), device=dev) > 0.5).float()
+        inp.inpaint_views(imgs * masks[:, None], masks)
+        torch.cuda.synchronize()
+        e0.record(); inp.inpaint_views(imgs * masks[:, None], masks); e1.record(); torch.cuda.synchronize()
+        row['ddnm_step_ms'] = round(e0.elapsed_time(e1) / a.sampler_steps, 3)
+    rows.append(row)
+    print(json.dumps(row), flush=True)
+    del m
+    torch.cuda.empty_cache()
+os.makedirs('gpurun_out', exist_ok=True)
+json.dump(rows, open('gpurun_out/unet_latency.json', 'w'), indent=1)
