@@ -30,37 +30,92 @@ UNET_FLOP_PER_FORWARD = 2.0 * 1119832768512            # 1 119 832 76
 PEAK_FP16_TFLOPS = 2500.0                              # MI355X dense f16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(repeats=2):
-    """Reference CPU 'nearest' path, restated by the oracle (kind = "port": the reference itself has no runnable CPU
-    pipeline -- demo.py:12,19 hard-code CUDA): one full 8-view shape at BASELINE sizes (project, raster, depth test +
-    hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF unproject, atlas dilate),
-    timed `repeats` times on the host (about 15 s of CPU work); median reported."""
-    from pointdreamer_amd import synthetic
+def _cpu_one_shape(sh, hpr=True):
+    """One 8-view shape through the oracle's CPU restatement of the reference's 'nearest' path; returns per-stage seconds."""
     from oracle import camera as ocam, project as oproj, sparse as osparse, inpaint as oinp, unproject as ounp
-    torch.set_num_threads(1)
-    sh = synthetic.make_shape(30000, 1024)
     V = 8
+    t = {}
+    t0 = time.perf_counter()
     cams, base_dirs, eyes, ups = ocam.create_cameras(V, 1.6, 512)
-    times = []
-    for _ in range(repeats):
-        t0 = time.time()
-        pr = oproj.project_batch(cams, sh['vertices'], sh['points'], True, 0.05)
-        hard, fid, depth = oproj.rasterize(pr['pos'], sh['faces'], 512)
-        hard_r = oproj.downsample_masks(hard, 256)
-        vis, _ = oproj.point_validation_by_depth(512, pr['point_uvs'], pr['point_depths'], depth, 0.0001)
+    pr = oproj.project_batch(cams, sh['vertices'], sh['points'], True, 0.05)
+    hard, fid, depth = oproj.rasterize(pr['pos'], sh['faces'], 512)
+    hard_r = oproj.downsample_masks(hard, 256)
+    vis, _ = oproj.point_validation_by_depth(512, pr['point_uvs'], pr['point_depths'], depth, 0.0001)
+    t['project'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    if hpr:
         vis = vis | oproj.point_validation_by_hpr(sh['points'], eyes, 100)
-        pp = oproj.point_pixels_for_res(pr['point_uvs'], 256)
-        sp, m0, m2, sf = osparse.get_sparse_images(pp, sh['colors'], vis, hard_r, V, 256, 1, 1, 0.82)
-        inp = np.stack([oinp.reference_nearest_inpaint_scipy(sp[i], m2[i]) for i in range(V)]).astype(np.float32)
-        o = ounp.unproject(inp, sh['f_normals'], 256, cams, 512, base_dirs, sh['gb_pos'], sh['mask'],
-                           sh['per_atlas_pixel_face_id'], pr['uv_centers'], pr['uv_scales'], 0.05, sf, depth, [21], True)
-        oinp.reference_nearest_inpaint_scipy(o['atlas_img'].transpose(2, 0, 1), sh['mask'][..., 0])
-        times.append(time.time() - t0)
-    per_shape = sorted(times)[len(times) // 2]
-    return dict(value=3600.0 / per_shape, unit="shapes/hour", cores=1, kind="port",
-                sample=f"oracle CPU restatement of the reference's texture_gen_method='nearest' path (scipy griddata / qhull), one full "
-                       f"30k-point 8-view shape at A=1024, median of {repeats} runs = {per_shape:.2f} s/shape "
-                       f"(runs: {', '.join('%.2f' % t for t in times)} s); the CPU path has no diffusion "
+    t['hpr'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    pp = oproj.point_pixels_for_res(pr['point_uvs'], 256)
+    sp, m0, m2, sf = osparse.get_sparse_images(pp, sh['colors'], vis, hard_r, V, 256, 1, 1, 0.82)
+    t['sparse'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    inp = np.stack([oinp.reference_nearest_inpaint_scipy(sp[i], m2[i]) for i in range(V)]).astype(np.float32)
+    t['nearest_inpaint'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    o = ounp.unproject(inp, sh['f_normals'], 256, cams, 512, base_dirs, sh['gb_pos'], sh['mask'],
+                       sh['per_atlas_pixel_face_id'], pr['uv_centers'], pr['uv_scales'], 0.05, sf, depth, [21], True)
+    t['unproject_nbf'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    oinp.reference_nearest_inpaint_scipy(o['atlas_img'].transpose(2, 0, 1), sh['mask'][..., 0])
+    t['dilate_atlas'] = time.perf_counter() - t0
+    return t
+
+
+def _cpu_worker(args):
+    """One host core: 1 warm-up + `timed` shapes with hidden-point removal, then one without (the on / off split)."""
+    seed, timed = args
+    import torch as _t
+    _t.set_num_threads(1)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:                                      # noqa: BLE001 -- optional: BLAS pools inside numpy / scipy
+        pass
+    from pointdreamer_amd import synthetic
+    sh = synthetic.make_shape(30000, 1024, seed=seed)
+    _cpu_one_shape(sh)
+    t0 = time.perf_counter()
+    stages = [_cpu_one_shape(sh) for _ in range(timed)]
+    wall = time.perf_counter() - t0
+    off = _cpu_one_shape(sh, hpr=False)
+    return wall, stages, off
+
+
+def cpu_baseline(timed=3, max_workers=32):
+    """Reference CPU 'nearest' path next to the GPU number.  kind = "port": the reference has no runnable
+    CPU pipeline (demo.py:12,19 hard-code CUDA; kaolin / nvdiffrast are CUDA-only), so this is the oracle's CPU restatement of
+    it -- project, raster, depth test + hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF
+    unproject, atlas dilate -- at BASELINE sizes.  All host cores are used the way a CPU deployment of this throughput metric
+    would use them: one independent shape stream per core (the per-shape code is serial numpy / scipy, as the reference's is);
+    every worker runs 1 warm-up + `timed` shapes (about 20 s of wall time), the aggregate rate is shapes / slowest worker's
+    wall time."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, max_workers))
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    ctx = mp.get_context('spawn')                          # the parent holds a live HIP runtime: never fork it
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_cpu_worker, [(100 + w, timed) for w in range(workers)])
+    total_wall = time.perf_counter() - t0
+    slowest = max(r[0] for r in res)
+    value = workers * timed / slowest * 3600.0
+    flat = [st for r in res for st in r[1]]
+    med = {k: float(np.median([st[k] for st in flat])) for k in flat[0]}
+    per_shape = float(np.median([sum(st.values()) for st in flat]))
+    off = float(np.median([sum(r[2].values()) for r in res]))
+    return dict(value=value, unit="shapes/hour", cores=workers, kind="port", cpu_model=model, host_cores=cores,
+                seconds_per_shape_one_core=per_shape, shapes_per_hour_one_core=3600.0 / per_shape,
+                seconds_per_shape_hpr_off=off, value_hpr_off=value * per_shape / off,
+                stage_seconds=med,
+                sample=f"oracle CPU restatement of the reference's texture_gen_method='nearest' path (scipy griddata / qhull) on "
+                       f"{workers} of {cores} host cores ({model}): one independent 30k-point 8-view shape stream per core at A=1024, "
+                       f"1 warm-up + {timed} timed shapes each = {workers * timed} shapes in {slowest:.1f} s (pool wall {total_wall:.1f} s); "
+                       f"median {per_shape:.2f} s/shape/core with hidden-point removal, {off:.2f} s without; no diffusion on the CPU "
                        f"(a CPU fp32 UNet forward is ~8 s, x800 per DDNM shape)")
 
 
@@ -73,6 +128,7 @@ def main():
     ap.add_argument('--parallel', default='shapes', choices=['shapes', 'views'])
     ap.add_argument('--ddnm-steps', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the nearest-workload / one-shape-latency side measurements')
     ap.add_argument('--shapes-per-step', type=int, default=4,
                     help='independent shapes textured per step on each GPU, their 8-view sets batched through the UNet together '
                          '(BASELINE configs[4] style).  Measured on one MI355X: 1 -> 1670, 2 -> 1836, 4 -> 1939, 8 -> 1953 '
@@ -157,8 +213,10 @@ def main():
     value = shapes / dt * 3600.0
 
     roofline = None
+    extras = {}
     if inpainter is not None:
         ms, flops, launches = inpainter.model.profile_read()
+        ams, aflops, alaunches = inpainter.model.profile_read(attention=True)
         inpainter.model.profile(False)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None
@@ -170,7 +228,40 @@ def main():
                         peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=traffic,
                         launches=int(launches), avg_launch_ms=ms / max(launches, 1),
                         flops_per_launch=flops / max(launches, 1),
-                        unet_forward_tflops_effective=(UNET_FLOP_PER_FORWARD * views_here * args.ddnm_steps * args.steps) / dt / 1e12)
+                        unet_forward_tflops_effective=(UNET_FLOP_PER_FORWARD * views_here * args.ddnm_steps * args.steps) / dt / 1e12,
+                        attention=dict(bound="mfma", kernel="k_attention_t64 / k_attention (QK^T, softmax, PV; 32^2, 16^2, 8^2 levels)",
+                                       achieved=(aflops / (ams * 1e-3) / 1e12) if ams > 0 else None, peak=PEAK_FP16_TFLOPS,
+                                       unit="TFLOP/s", frac=(aflops / (ams * 1e-3) / 1e12 / PEAK_FP16_TFLOPS) if ams > 0 else None,
+                                       launches=int(alaunches), avg_launch_ms=ams / max(alaunches, 1),
+                                       flops_per_launch=aflops / max(alaunches, 1)))
+        # driver-timed side figures on the same box, after the timed region (world 1 only): BASELINE configs[1] ('nearest' + NBF,
+        # one shape per step) and the latency of ONE shape through the DDNM path (configs[2] at one shape per step)
+        if world == 1 and not args.no_extras:
+            one = lambda c: pipeline.colorize_one_mesh(g['points'], g['colors'], g['vertices'], g['faces'], g['f_normals'], xatlas,
+                                                       camera_info, **c)
+            cn = dict(cfg, texture_gen_method='nearest', inpainter=None)
+            for _ in range(3):
+                one(cn)
+            sync(); t1 = time.perf_counter()
+            for _ in range(50):
+                one(cn)
+            sync(); dn = (time.perf_counter() - t1) / 50
+            cno = dict(cn, point_validation_by_o3d=False)
+            for _ in range(3):
+                one(cno)
+            sync(); t1 = time.perf_counter()
+            for _ in range(50):
+                one(cno)
+            sync(); dno = (time.perf_counter() - t1) / 50
+            extras['nearest'] = dict(metric="shapes/hour (configs[1]: 30k-pt cloud, 8x256^2 views, texture_gen_method='nearest' + NBF [21], "
+                                            "hidden-point removal on, one shape per step)", value=3600.0 / dn, ms_per_shape=dn * 1e3,
+                                     ms_per_shape_hpr_off=dno * 1e3, value_hpr_off=3600.0 / dno)
+            one(cfg)
+            sync(); t1 = time.perf_counter()
+            one(cfg)
+            sync(); d1 = time.perf_counter() - t1
+            extras['ddnm_one_shape'] = dict(metric="seconds per shape, configs[2] with one shape per step (UNet batch 8)", seconds=d1,
+                                            value=3600.0 / d1)
     else:
         roofline = dict(bound="hbm", kernel="n/a (nearest workload: sub-millisecond HBM-bound kernels)", achieved=None, peak=8000.0,
                         unit="GB/s", frac=None, traffic=None)
@@ -184,7 +275,7 @@ def main():
                                         f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, hidden-point removal on (device)" + (f"; {SPS} independent shapes per step, their views batched through the UNet together" if SPS > 1 else ""),
                                parallelism=f"{args.parallel}-parallel x{world}", views_per_unet_batch=views_here,
                                shapes_per_step=world * SPS if args.parallel == 'shapes' else 1),
-                   roofline=roofline)
+                   roofline=roofline, extras=extras or None)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         else:

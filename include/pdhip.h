@@ -195,6 +195,8 @@ int pdhip_unet_forward(pdhip_unet* u, const float* x, const float* t, int N, flo
 /* HIP-event timing of the dominant kernel (3x3 implicit-GEMM conv launches) on the launch stream. */
 int pdhip_unet_profile(pdhip_unet* u, int enable);
 int pdhip_unet_profile_read(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches);
+/* the same for the attention launches (QK^T + softmax + PV, 4 T^2 C flop per image) -- north_star's MFMA-utilisation evidence */
+int pdhip_unet_profile_read_attention(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches);
 
 /* D1 schedule (diffusion.py:46-113, 770-812): 100 steps t = 990..0; host arrays (any may be NULL). coefs[100][6] =
  * sqrt(1-a_t), sqrt(a_t), sqrt(a_next), sigma_t, c1, c2. */

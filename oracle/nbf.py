@@ -58,3 +58,23 @@ def shrink_visibility(per_pixel_mask, vis_AAV, kernel_sizes):
         border = dilate_binary(edges, k)
         out.append(vis & ~border)
     return np.stack(out, 0)
+
+
+def shrink_triptychs(per_pixel_mask, vis_AAV, kernel_sizes):
+    """unproject.py:459-474 (the `shrink_per_view_edge/{v}.png` debug images) as uint8 [V, A, 3A+20, 3]:
+    panel 0 = visibility in grey with the chart-background edges red and the view edges blue, panel 1 = view edge mask,
+    panel 2 = border mask of the LAST kernel size (the python loop variable the reference reuses), 10 white columns between
+    panels (utils_2d.cat_images: margin 10 on a canvas of ones), rows reversed, x255 truncated."""
+    vis = np.asarray(vis_AAV, bool).transpose(2, 0, 1)
+    V, A, _ = vis.shape
+    bg = scharr_edges_binary(np.asarray(per_pixel_mask, bool))
+    edges = scharr_edges_binary(vis) & ~bg[None]
+    border = dilate_binary(edges, int(kernel_sizes[-1]))
+    out = np.full((V, A, 3 * A + 20, 3), 255, np.uint8)
+    p0 = np.repeat(vis[..., None], 3, -1).astype(np.uint8) * 255
+    p0[np.broadcast_to(bg[None], vis.shape)] = (255, 0, 0)
+    p0[edges] = (0, 0, 255)
+    out[:, :, :A] = p0
+    out[:, :, A + 10:2 * A + 10] = (edges[..., None] * 255).astype(np.uint8)
+    out[:, :, 2 * A + 20:] = (border[..., None] * 255).astype(np.uint8)
+    return out[:, ::-1].copy()

@@ -28,7 +28,7 @@ struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chunks = 0; const float* gn_partB = nullptr; int Ca = 0; int gn_chunksB = 0;
              half_t* p2 = nullptr; };   // p2: virtual channel concat [p (Ca channels) | p2 (C - Ca channels)], never materialised
 
-struct Prof { std::vector<hipEvent_t> ev; size_t used = 0; double flops = 0; bool on = false; };
+struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
 }  // namespace
 
@@ -140,14 +140,15 @@ half_t* arena_take(pdhip_unet* u, size_t halfs) {
 
 struct Ctx { pdhip_unet* u; int N; hipStream_t s; bool dry; const float* film_base; long long film_stride; };
 
-int prof_begin(Ctx& c, double flops) {
+int prof_begin(Ctx& c, double flops, int cls = 0) {
     Prof& p = c.u->prof;
     if (!p.on || c.dry) return PDHIP_OK;
     if (p.used + 2 > p.ev.size()) {
-        for (int i = 0; i < 256; ++i) { hipEvent_t e; PD_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
+        for (int i = 0; i < 256; ++i) { hipEvent_t e; PD_HIP(hipEventCreate(&e)); p.ev.push_back(e); p.cls.push_back(0); }
     }
     PD_HIP(hipEventRecord(p.ev[p.used], c.s));
-    p.flops += flops;
+    p.cls[p.used] = (uint8_t)cls;
+    p.flops[cls] += flops;
     return PDHIP_OK;
 }
 int prof_end(Ctx& c) {
@@ -220,7 +221,13 @@ int run_att(Ctx& c, const Act& x, AttB& ab, Act* out) {
     a = x;
     a.p = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);
     half_t* vt = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);      // transposed V of the T >= 128 attention kernel
-    if (!c.dry) PD_TRY(attention(qkv.p, a.p, c.N, x.H * x.W, x.C, c.u->head, c.s, vt));
+    if (!c.dry) {
+        // profile hook (bench.py roofline.attention): QK^T + PV = 4 T^2 C flop per image (12.18 GFLOP per forward)
+        const double T = (double)x.H * x.W;
+        PD_TRY(prof_begin(c, 4.0 * c.N * T * T * x.C, 1));
+        PD_TRY(attention(qkv.p, a.p, c.N, x.H * x.W, x.C, c.u->head, c.s, vt));
+        PD_TRY(prof_end(c));
+    }
     return run_conv(c, a, ab.proj, x.p, out, true);
 }
 
@@ -568,20 +575,30 @@ extern "C" int pdhip_unet_profile(pdhip_unet* u, int enable) {
     PD_REQUIRE(u, "pdhip_unet_profile: null handle");
     u->prof.on = enable != 0;
     u->prof.used = 0;
-    u->prof.flops = 0;
+    u->prof.flops[0] = u->prof.flops[1] = 0;
+    return PDHIP_OK;
+}
+static int prof_read(pdhip_unet* u, int cls, double* total_ms, double* total_flops, long long* launches) {
+    double ms = 0;
+    long long n = 0;
+    for (size_t i = 0; i + 1 < u->prof.used; i += 2) {
+        if (u->prof.cls[i] != cls) continue;
+        PD_HIP(hipEventSynchronize(u->prof.ev[i + 1]));
+        float e = 0;
+        PD_HIP(hipEventElapsedTime(&e, u->prof.ev[i], u->prof.ev[i + 1]));
+        ms += e; ++n;
+    }
+    *total_ms = ms; *total_flops = u->prof.flops[cls]; *launches = n;
     return PDHIP_OK;
 }
 extern "C" int pdhip_unet_profile_read(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches) {
     PD_REQUIRE(u && total_ms && total_flops && launches, "pdhip_unet_profile_read: null argument");
-    double ms = 0;
-    for (size_t i = 0; i + 1 < u->prof.used; i += 2) {
-        PD_HIP(hipEventSynchronize(u->prof.ev[i + 1]));
-        float e = 0;
-        PD_HIP(hipEventElapsedTime(&e, u->prof.ev[i], u->prof.ev[i + 1]));
-        ms += e;
-    }
-    *total_ms = ms; *total_flops = u->prof.flops; *launches = (long long)(u->prof.used / 2);
-    return PDHIP_OK;
+    return prof_read(u, 0, total_ms, total_flops, launches);
+}
+/* the same for the attention launches (k_attention_t64 + its V transpose / k_attention): 4 T^2 C flop per image */
+extern "C" int pdhip_unet_profile_read_attention(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches) {
+    PD_REQUIRE(u && total_ms && total_flops && launches, "pdhip_unet_profile_read_attention: null argument");
+    return prof_read(u, 1, total_ms, total_flops, launches);
 }
 
 // ---- D1: DDNM schedule (diffusion.py:46-113, 770-812) computed on the host exactly as the reference forms it

@@ -29,6 +29,7 @@ _reg('pdhip_unet_missing_tensors', C.c_int, [vp, C.c_char_p, i32])
 _reg('pdhip_unet_forward', C.c_int, [vp, vp, vp, i32, vp, vp])
 _reg('pdhip_unet_profile', C.c_int, [vp, i32])
 _reg('pdhip_unet_profile_read', C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)])
+_reg('pdhip_unet_profile_read_attention', C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)])
 _reg('pdhip_ddnm_schedule', C.c_int, [vp, vp, vp, vp, vp])
 _reg('pdhip_ddnm_prepare', C.c_int, [vp, vp, vp, i32, i32, vp])
 _reg('pdhip_ddnm_step', C.c_int, [vp, vp, i32, vp, vp, vp, u64, i32, i32, i32, vp])
@@ -129,9 +130,10 @@ class UNetModel:
     def profile(self, enable):
         check(self._L.pdhip_unet_profile(self._h, 1 if enable else 0), 'pdhip_unet_profile')
 
-    def profile_read(self):
+    def profile_read(self, attention=False):
         ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
-        check(self._L.pdhip_unet_profile_read(self._h, C.byref(ms), C.byref(fl), C.byref(n)), 'pdhip_unet_profile_read')
+        fn = self._L.pdhip_unet_profile_read_attention if attention else self._L.pdhip_unet_profile_read
+        check(fn(self._h, C.byref(ms), C.byref(fl), C.byref(n)), 'pdhip_unet_profile_read')
         return ms.value, fl.value, n.value
 
 

@@ -52,11 +52,43 @@ def get_logger(path):
     return logger
 
 
-def prepare(cfg_file, device, ckpt_path=None, allow_random_weights=False, overrides=None, batch_shapes=1):
-    """demo.py:311-356 without the POCO network."""
+# keys of the reference's configs/*.yaml that steer stages UPSTREAM or outside of the texturing path (dataset bookkeeping, POCO / SPR
+# geometry, evaluation): accepted verbatim and ignored, so that the reference's five YAML files load unchanged
+UPSTREAM_KEYS = ('exp_name', 'exist_root_path', 'dataset_name', 'cls_id', 'input_pc_generate_method', 'demo', 'geo_root', 'geo_from',
+                 'load_exist_dense_img_path', 'use_GT_geo_watertight', 'use_GT_multi_view_img', 'noise_stddev', 'coords_scale',
+                 'input_type', 'input_already_noisy', 'save_dir', 'render_after_inference', 'save_input_pc', 'project2mesh',
+                 'refine_res', 'smooth_mesh', 'sample_num')
+DEFAULTS = dict(camera_distribution='fibonacci_sphere', cam_res=512, view_num=8, res=256, point_size=1, edge_point_size=1,
+                point_validation_by_o3d=True, hidden_point_removal_radius=100, refine_point_validation_by_remove_abnormal_depth=False,
+                crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, edge_dilate_kernels=[21], optimize_from='ours',
+                xatlas_texture_res=1024, complete_unseen_by='neighbor', output_path='output')
+
+
+def load_config(cfg_file, overrides=None):
+    """demo.py:313-314 (`Munch.fromDict(yaml.safe_load(...))`): the reference's YAML files load as they are.  Keys the path reads
+    are validated, upstream keys are kept but unused, an unknown key is an error (a typo must not silently fall back)."""
     cfg = Cfg(yaml.safe_load(open(cfg_file)))
     cfg.update(overrides or {})
-    logger = get_logger(os.path.join(cfg.output_path, f'{datetime.datetime.now().strftime("%Y.%m.%d.%H.%M.%S")}_log.log'))
+    unknown = [k for k in cfg if k not in SUPPORTED_KEYS and k not in UPSTREAM_KEYS]
+    if unknown:
+        raise KeyError(f"{cfg_file}: unknown config keys {unknown}")
+    if 'texture_gen_method' not in cfg:
+        raise KeyError(f"{cfg_file}: texture_gen_method is required")
+    for k, v in DEFAULTS.items():
+        cfg.setdefault(k, v)
+    if cfg.camera_distribution != 'fibonacci_sphere':
+        raise NotImplementedError(f"camera_distribution={cfg.camera_distribution!r}: every shipped config uses fibonacci_sphere")
+    if cfg.optimize_from == 'None':                      # YAML `None` is the string 'None' (demo.py:213 treats both alike)
+        cfg['optimize_from'] = None
+    return cfg
+
+
+def prepare(cfg_file, device, ckpt_path=None, allow_random_weights=False, overrides=None, batch_shapes=1):
+    """demo.py:311-356 without the POCO network."""
+    cfg = load_config(cfg_file, overrides)
+    rank = int(os.environ.get('RANK', 0))
+    stamp = datetime.datetime.now().strftime("%Y.%m.%d.%H.%M.%S") + (f'_rank{rank}' if int(os.environ.get('WORLD_SIZE', 1)) > 1 else '')
+    logger = get_logger(os.path.join(cfg.output_path, f'{stamp}_log.log'))
     inpainter = None
     if cfg.texture_gen_method == 'DDNM_inpaint':
         logger.info('Loading inpainter...')
@@ -198,6 +230,30 @@ def recon_textured_meshes_batched(cfg, inpainter, camera_info, pc_files, names, 
     return [sh['out'] for sh in shapes]
 
 
+def recon_one_textured_mesh_view_parallel(cfg, inpainter, camera_info, pc_file, name, device, logger, rank, world, shape_key):
+    """`--parallel views` (SURVEY 8e): the views of ONE shape are split over the ranks (dist.colorize_one_mesh_view_parallel);
+    every rank writes the per-view PNGs of its own views, rank 0 the mesh / atlas files."""
+    from . import dist as pdist
+    all_start = time.time()
+    sh = _load_shape(cfg, pc_file, name, device, logger) if rank == 0 else None
+    if world > 1:
+        torch.distributed.barrier()                      # rank 0 created the output tree (input_pc.ply, geo cache) first
+        if rank != 0:
+            sh = _load_shape(cfg, pc_file, name, device, logger)
+    logger.info(f'Generate texture by PointDreamer (views of the shape split over {world} ranks)...')
+    start = time.time()
+    vertices, uvs, faces, mesh_tex_idx, atlas_img, mask = pdist.colorize_one_mesh_view_parallel(
+        sh['coords'], sh['colors'], sh['vertices'], sh['faces'], sh['f_normals'], sh['xatlas'], camera_info, rank=rank, world=world,
+        inpainter=inpainter, save_img_path=os.path.join(sh['out'], 'others'), shape_key=shape_key, return_full=True,
+        **_pipeline_kwargs(cfg))
+    torch.cuda.synchronize()
+    logger.info(f'generate texture time: {time.time() - start} s')
+    if rank == 0:
+        save_textured_mesh(vertices, uvs, faces, mesh_tex_idx, atlas_img, mask, sh['out'])
+    logger.info(f'total time: {time.time() - all_start} s')
+    return sh['out']
+
+
 def files_of_rank(pc_files, rank, world):
     """The clouds rank `rank` of `world` textures: a contiguous block of the sorted list (dist.shard_range)."""
     from .dist import shard_range
@@ -213,6 +269,9 @@ def main(argv=None):
     p.add_argument("--set", nargs='*', default=[], help="YAML overrides key=value (e.g. complete_unseen_by=unproject optimize_from=None)")
     p.add_argument("--batch_shapes", type=int, default=4, help="directory runs: clouds textured together, their views in one "
                    "inpainter batch (1 = one at a time, as the reference; 4 is ~16 %% more shapes/hour on one MI355X)")
+    p.add_argument("--parallel", choices=['shapes', 'views'], default='shapes', help="under torch.distributed.run: 'shapes' = every "
+                   "rank textures its own block of the clouds (no collective); 'views' = the views of each shape are split over the "
+                   "ranks and assembled with one all_gather (lowest latency per shape)")
     args = p.parse_args(argv)
     # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pointdreamer_amd.demo ...`): every rank textures its
     # own contiguous block of the directory's clouds -- independent shapes, no collective on the data path
@@ -223,8 +282,15 @@ def main(argv=None):
     overrides = {k: yaml.safe_load(v) for k, v in (kv.split('=', 1) for kv in args.set)}
     pc_files = [args.pc_file] if args.pc_file.endswith('.ply') else \
         [os.path.join(args.pc_file, i) for i in sorted(os.listdir(args.pc_file)) if i.endswith('.ply')]
-    pc_files = files_of_rank(pc_files, rank, world)
-    group = max(1, min(args.batch_shapes, max(1, len(pc_files))))
+    by_views = args.parallel == 'views' and world > 1
+    if by_views:
+        import torch.distributed as tdist
+        if not tdist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else:
+        pc_files = files_of_rank(pc_files, rank, world)
+    group = 1 if by_views else max(1, min(args.batch_shapes, max(1, len(pc_files))))
     cfg, inpainter, camera_info, logger = prepare(args.config, device, args.ckpt, args.allow_random_weights, overrides, batch_shapes=group)
     outs = []
     # PNG / OBJ encoding of one shape runs on host threads under the GPU work of the next (io_utils.set_async); every file is on
@@ -238,7 +304,10 @@ def main(argv=None):
                 os.makedirs(os.path.join(cfg.output_path, name), exist_ok=True)
                 shutil.copy(args.config, os.path.join(cfg.output_path, name, 'config.yaml'))
                 logger.info(f'Start Recon {pc_file}...')
-            if len(chunk) == 1:
+            if by_views:
+                outs.append(recon_one_textured_mesh_view_parallel(cfg, inpainter, camera_info, chunk[0], names[0], device, logger,
+                                                                  rank, world, shape_key=g0))
+            elif len(chunk) == 1:
                 outs.append(recon_one_textured_mesh(cfg, inpainter, camera_info, chunk[0], names[0], device, logger))
             else:
                 outs += recon_textured_meshes_batched(cfg, inpainter, camera_info, chunk, names, device, logger)

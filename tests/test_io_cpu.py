@@ -136,3 +136,58 @@ def test_deferred_writes_land_on_flush_and_report_errors(tmp_path):
     # back to synchronous: the file exists on return
     io_utils.save_CHW_RGB_img(torch.from_numpy(imgs[0]), str(tmp_path / "sync.png"))
     assert (tmp_path / "sync.png").exists()
+
+
+def test_o1_writers_vs_reference_golden(tmp_path):
+    """Row O1 pinned: bytes / pixels written by the reference's own savemeshtes2 (utils_3d.py:27-64), save_CHW_RGB(A)_img
+    (utils_2d.py:351-381) and demo.save_textured_mesh (demo.py:264-307), recorded by tools/gen_golden_r2.py."""
+    from conftest import load_golden
+    from pointdreamer_amd import demo
+    g = load_golden('o1_writers.npz')
+    p = str(tmp_path / 'model_normalized.obj')
+    io_utils.savemeshtes2(g['vertices'], g['uvs'], g['faces'], g['face_uv_idx'], p)
+    assert open(p, 'rb').read() == g['ref_obj'].tobytes()
+    assert open(str(tmp_path / 'model_normalized.mtl'), 'rb').read() == g['ref_mtl'].tobytes()
+    io_utils.save_CHW_RGB_img(g['img_rgb'].copy(), str(tmp_path / 'rgb.png'))
+    io_utils.save_CHW_RGBA_img(g['img_rgba'].copy(), str(tmp_path / 'rgba.png'))
+    a, b = PIL.Image.open(str(tmp_path / 'rgb.png')), PIL.Image.open(str(tmp_path / 'rgba.png'))
+    assert a.mode == 'RGB' and b.mode == 'RGBA'
+    assert np.array_equal(np.array(a), g['ref_rgb_pixels']) and np.array_equal(np.array(b), g['ref_rgba_pixels'])
+    assert np.array_equal(io_utils.load_CHW_RGB_img(str(tmp_path / 'rgba.png')).numpy(), g['ref_loaded_from_rgba'])
+    for d in ('models', 'others'):
+        os.makedirs(str(tmp_path / d))
+    T = torch.from_numpy
+    demo.save_textured_mesh(T(g['vertices']), T(g['uvs']), T(g['faces']), T(g['face_uv_idx']), T(g['atlas']), T(g['atlas_mask']), str(tmp_path))
+    assert open(str(tmp_path / 'models' / 'model_normalized.obj'), 'rb').read() == g['ref_obj2'].tobytes()
+    assert np.array_equal(np.array(PIL.Image.open(str(tmp_path / 'models' / 'model_normalized.png'))), g['ref_atlas_png'])
+    assert np.array_equal(np.array(PIL.Image.open(str(tmp_path / 'others' / 'atlas_wo_background.png'))), g['ref_atlas_rgba_png'])
+
+
+def test_reference_yaml_configs_load_verbatim(tmp_path):
+    """The reference's five configs/*.yaml (their parsed key -> value tables, tests/golden/reference_configs.json) go through the
+    driver's config loader unchanged: path keys are honoured, upstream keys (dataset / POCO / SPR / evaluation) are accepted and
+    ignored, a mistyped key is an error.  The shipped configs carry the same values for every key the path reads."""
+    import json
+    import yaml
+    from pointdreamer_amd import demo
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, 'tests', 'golden', 'reference_configs.json')))
+    assert sorted(ref) == ['default.yaml', 'geo_by_SPR.yaml', 'nearest.yaml', 'noisy.yaml', 'wo_NBF.yaml']
+    for name, table in ref.items():
+        p = str(tmp_path / name)
+        yaml.safe_dump(table, open(p, 'w'))
+        cfg = demo.load_config(p)
+        for k in demo.SUPPORTED_KEYS:
+            if k in table and k != 'optimize_from':
+                assert cfg[k] == table[k], (name, k)
+        assert cfg.optimize_from in (None, 'scratch', 'naive', 'ours')
+        kw = demo._pipeline_kwargs(cfg)
+        assert 'geo_from' not in kw and 'exp_name' not in kw and kw['view_num'] == table['view_num']
+        ours = demo.load_config(os.path.join(root, 'configs', name))            # the shipped twin
+        for k in demo.SUPPORTED_KEYS:
+            if k in table:
+                assert ours[k] == cfg[k], (name, k, ours[k], cfg[k])
+    bad = dict(ref['nearest.yaml'], edge_dilate_kernel=[21])
+    yaml.safe_dump(bad, open(str(tmp_path / 'bad.yaml'), 'w'))
+    with pytest.raises(KeyError):
+        demo.load_config(str(tmp_path / 'bad.yaml'))

@@ -163,3 +163,30 @@ def test_8f2_neighbor_completion_vs_reference(name):
     r1, c1 = mu.neighbour_csr(len(v), f)
     r2, c2 = onb.adjacency_csr(len(v), f)
     assert np.array_equal(r1, r2) and np.array_equal(c1, c2)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_p1_crop_arithmetic_vs_reference(tag):
+    """Row P1 pinned: the reference's own get_rendered_hard_mask_and_face_idx_batch (ours_utils.py:93-150, run by
+    tools/gen_golden_r2.py with the oracle camera and raster as the two third-party stand-ins) against the oracle."""
+    g = load_golden('p1_crop.npz')
+    G = lambda k: g[f'{tag}_{k}']
+    cams = [ocam.Camera(p, int(G('cam_res'))) for p in G('cam_params')]
+    o = oproj.project_batch(cams, G('vertices'), G('points'), bool(G('rescale')), float(G('padding')))
+    assert np.array_equal(o['pos'], G('ref_pos'))
+    assert np.array_equal(o['vertice_uvs'], G('ref_vertice_uvs'))
+    assert np.array_equal(o['point_uvs'], G('ref_point_uvs'))
+    assert np.array_equal(o['point_depths'], G('ref_point_depths'))
+    assert np.array_equal(np.asarray(o['uv_centers'], np.float32), G('ref_uv_centers'))
+    assert np.array_equal(np.asarray(o['uv_scales'], np.float32), G('ref_uv_scales'))
+    assert np.float32(o['padding']) == G('ref_padding')
+    hard, fid, depth = oproj.rasterize(o['pos'], G('faces'), int(G('cam_res')))
+    assert np.array_equal(hard, G('ref_hard')) and np.array_equal(fid, G('ref_face_idx')) and np.array_equal(depth, G('ref_depth'))
+
+
+def test_o1_shrink_triptychs_vs_reference_pngs():
+    """unproject.py:459-474 with the reference's own cat_images / save_CHW_RGB_img (decoded PNG pixels)."""
+    g = load_golden('triptych.npz')
+    ks = [int(k) for k in g['kernels']]
+    assert np.array_equal(onbf.shrink_visibility(g['mask'], g['vis'], ks), g['ref_shrinked'])
+    assert np.array_equal(onbf.shrink_triptychs(g['mask'], g['vis'], ks), g['ref_pngs'])

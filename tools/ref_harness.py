@@ -134,6 +134,8 @@ def install():
             """trimesh.grouping.unique_rows for small non-negative integer rows (trimesh 4.x: rows are bit-packed into one int64,
             column j shifted by j*floor(64/ncols), then np.unique(return_index, return_inverse))."""
             d = np.asanyarray(data).astype(np.int64)
+            if len(d) == 0:                                    # trimesh: hashable_rows([]) -> [], np.unique([]) -> empty index arrays
+                return np.zeros((0,), np.int64), np.zeros((0,), np.int64)
             prec = 64 // d.shape[1]
             assert np.abs(d).max() < 2 ** (prec - 1)
             h = np.zeros(len(d), np.int64)
