@@ -232,6 +232,15 @@ int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*
 int pdhip_groupnorm_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film /*[N][2C] or NULL*/, int N,
                              int H, int W, int C, int silu, int resample, void* y, float* stats_ws, float* ws,
                              long long ws_floats, void* stream);
+/* y = conv3x3( silu( GroupNorm32(x) [* (1 + scale) + shift] ) ) (+ residual): the in_layers / out_layers chain of a ResBlock
+ * (unet.py:183-252: normalization -> SiLU -> conv, FiLM scale-shift in between for out_layers) with the normalisation applied INSIDE
+ * the halo-resident conv kernel while it stages its input tile -- no stand-alone GroupNorm pass over the tensor.
+ * W in {32, 64, 128, 256}, H*W % 512 == 0, Cin % 32 == 0; ws: N*64 + N*64*ceil(H*W/256) + N*Cin*2 floats. */
+int pdhip_gn_silu_conv3x3_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film /*[N][2Cin] or NULL*/,
+                                   long long film_stride, const void* w_packed, const float* bias, const void* residual, void* y,
+                                   int N, int H, int W, int Cin, int Cout, int Cout_pad, const void* zero_page, float* ws,
+                                   long long ws_floats, void* stream);
+int pdhip_debug_set_fuse_gn(int on);   /* 1 (default): the UNet uses the fused form wherever the halo kernel serves a conv; 0: stand-alone passes */
 /* ---- complete_unseen_by='neighbor' (pointdreamer/unproject.py:93-196, demo.py:180-200).
  * The mesh subdivision stays on the host (as in the reference); these are the per-texel / per-vertex kernels. */
 /* flags[f] = 1 for every face f that owns a chart texel no view painted (demo.py:180-181). face_id [A*A] int64 (-1 = background). */

@@ -18,18 +18,21 @@ typedef __attribute__((ext_vector_type(4))) float float4_t;
 bool conv3x3_halo_eligible(int N, int H, int W, int Cin, int Cout_pad);
 int conv3x3_halo_splits(int N, int H, int W, int Cin, int Cout, int Cout_pad, size_t splitk_ws_floats);   // 1 direct, >1 split, 0 = do not use
 bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats);   // conv_igemm's routing (nn_gemm.hip)
+// apply_table != NULL: the input is silu(A x + B) of X per gn_table (zero padding applies to the TRANSFORMED image)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
                  int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
-                 float* splitk_ws, size_t splitk_ws_floats);
+                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table = nullptr);
 // fixed-order sum of split-K partials [splits][M][Cout] f32 + bias (+ residual) -> f16 Y, optional GroupNorm octet partials
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
 extern int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
+extern int g_fuse_gn;                                                   // tuning hook (nn_unet.hip)
 extern float* g_dbg_splitk_ws; extern size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
                float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr,
-               const half_t* X2 = nullptr, int Cin1 = 0);   // X2: second tensor of a never-materialised channel concat (1x1 only)
+               const half_t* X2 = nullptr, int Cin1 = 0,    // X2: second tensor of a never-materialised channel concat (1x1 only)
+               const float* apply_table = nullptr);         // input = silu(A x + B) per gn_table (layers the halo kernel takes only)
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
 // the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).
 int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,
@@ -43,6 +46,10 @@ int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, flo
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
              const half_t* XB = nullptr, int Ca = 0);     // XB: second tensor of a never-materialised channel concat
+// GroupNorm (+ FiLM) as one affine map per (image, channel): table [N][C/8][16] = (A0..A7, B0..B7) per channel octet, y = silu(A x + B) -- the
+// input transform of the APPLY variant of the halo conv (the stand-alone gn_apply pass disappears)
+int gn_table(const float* stats, const float* gamma, const float* beta, const float* film, long long film_stride, int N, int C,
+             float* table, hipStream_t s);
 int resample2x(const half_t* X, int N, int H, int W, int C, int mode, half_t* Y, hipStream_t s);
 int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long pixels, half_t* Y, hipStream_t s);
 

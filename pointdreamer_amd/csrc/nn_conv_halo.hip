@@ -33,12 +33,23 @@ __device__ __forceinline__ int swz_a(int hp) { return ((hp >> 2) & 1) << 1; }   
 
 // WLOG: log2 of the TILE width; ILOG >= WLOG: log2 of the image width.  ILOG > WLOG: the image is cut into column strips of the
 // tile width (a 512-pixel tile = 8 rows x 64 columns instead of 2 rows x 256: 660 halo pixels per chunk instead of 1 032).
-template <int WLOG, int ILOG>
+// APPLY: the conv's input is silu(A x + B) of X with one (A, B) per (image, channel) -- GroupNorm (+ FiLM) + SiLU folded by
+// gn_table() -- applied IN LDS after the halo pieces have landed, while the MFMAs of the current chunk run: the eight pieces
+// (128 halo pixels) staged in tap step T-1 are fetched behind the hand-over barrier of step T, transformed under groups 0-3 of
+// step T+1 and stored under group 4.  Work split: wave (o, h) = (wave & 3, wave >> 2) owns channel octet o of pixel half h of
+// every slot, one pixel per lane -- so the 16 constants of a chunk are WAVE-UNIFORM: they sit in lanes 0-15 of one VGPR
+// (one ds_read_b32 per chunk) and reach the VALU through v_readlane, no per-lane constant registers (the kernel has none to
+// spare).  The separate GroupNorm-apply pass over the tensor (read + write of every activation, 13 % of a DDNM step)
+// disappears.  Zero padding belongs to the TRANSFORMED image: a validity byte per halo pixel (LDS, written once per tile)
+// zeroes the out-of-image pixels again.  Duplicate tail pieces go to a scratch KiB per wave so that no raw copy can land on a
+// transformed piece.
+template <int WLOG, int ILOG, bool APPLY>
 __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__ X, const half_t* __restrict__ Wt,
                                                       const float* __restrict__ bias, const half_t* __restrict__ residual,
                                                       half_t* __restrict__ Y, int N, int H, int Cin, int Cout, int n_tiles,
                                                       int total_tiles, const half_t* __restrict__ zero_page,
-                                                      float* __restrict__ gn_part, int splits, float* __restrict__ partial) {
+                                                      float* __restrict__ gn_part, int splits, float* __restrict__ partial,
+                                                      const float* __restrict__ ap_table) {
     constexpr int W = 1 << WLOG, BMT = 512, BNT = 128, TM = 8, ROWB = 64, NWAVES = 8;
     constexpr int RT = BMT / W, HW2 = W + 2, HP = (RT + 2) * HW2;     // tile rows, halo row length, halo pixels
     constexpr int NPA = (HP + 15) / 16, PA = (NPA + 7) / 8;           // 1 KiB halo pieces per chunk, per wave
@@ -47,6 +58,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     constexpr int FPR = TM / RPW;                                     // A fragments per such row
     constexpr int CS_LD = BNT + 8;
     static_assert(PA <= 9 && RPW <= 4, "halo schedule: at most one halo piece per wave per tap, W >= 32");
+    static_assert(!APPLY || PA <= 7, "APPLY: piece T-1 is finished under step T+1 <= 8");
+    constexpr int SCR_OFF = 2 * AH_BYTES + 3 * B_BYTES;              // APPLY: 1 KiB per wave for the duplicate tail pieces
+    constexpr int TAB_OFF = SCR_OFF + NWAVES * 1024;                 // APPLY: (A0..A7, B0..B7) per channel octet of this image
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: keeps the piece / stage arithmetic on the scalar unit
@@ -93,13 +107,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     for (int t = 0; t < PA_TAB; ++t) aoff[t] = halo_off(t);
     const char* const Xb = reinterpret_cast<const char*>(X);
     auto halo_src = [&](int t, int chunk) -> const void* {
-        const uint32_t off = t < PA_TAB ? aoff[t < PA_TAB ? t : 0] : halo_off(t);
+        uint32_t off = t < PA_TAB ? aoff[t < PA_TAB ? t : 0] : halo_off(t);
+        if constexpr (APPLY) asm volatile("" : "+v"(off));           // form the 64-bit pointer when the piece is issued (no hoisted pairs)
         return off == ~0u ? (const void*)zero_page : (const void*)(Xb + off + (uint32_t)chunk * 64u);
     };
     const int brow = wave * 16 + (lane >> 2);
     const half_t* bp = Wt + (size_t)(n0 + brow) * K + cb * 32 + (((lane & 3) ^ swz_b(brow)) << 3);   // next weight slice to stage
     char* const ah_dst = smem;                                        // + buf * AH_BYTES + piece * 1024
     char* const b_dst = smem + 2 * AH_BYTES + wave * 1024;            // + stage * B_BYTES
+    // LDS byte offset of halo piece slot t in buffer buf (APPLY: a duplicate tail slot lands in the wave's scratch KiB)
+    auto piece_off = [&](int t, int buf) -> int {
+        const int pi = t * 8 + wave;
+        if (APPLY) return pi < NPA ? buf * AH_BYTES + pi * 1024 : SCR_OFF + wave * 1024;
+        return buf * AH_BYTES + min(pi, NPA - 1) * 1024;
+    };
 
     // ---- consumer role
     const int r16 = lane & 15, q4 = lane >> 4;
@@ -119,17 +140,83 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     (lds0 + (buf) * AH_BYTES + (uint32_t)((hpv + (toff) + (row2) * HW2) << 6) + (uint32_t)((q4 ^ swz_a(hpv + (toff) + (row2) * HW2)) << 4))
     half8 ar[4], bf[2][4];
 
+    // ---- APPLY role: wave (o, h) transforms channel octet o of halo pixels t * 128 + h * 64 + lane of every slot t
+    half8 ap_d;                                                       // the 8 channels being transformed
+    int ap_k = 0;                                                     // lanes 0-7: A of the chunk's octet, lanes 8-15: B (f32 bits)
+    uint32_t ap_lds = 0;                                              // where ap_d lives in LDS
+    uint32_t ap_v = 0;                                                // validity byte of the lane's halo pixel
+    const int ap_o = wave & 3, ap_h = wave >> 2;
+    const uint32_t val_lds = lds0 + (uint32_t)TAB_OFF + (uint32_t)Cin * 8u;
+    auto ap_fetch = [&](int t, int buf) {                             // issue the LDS reads of slot t (pixels beyond the last piece: scratch)
+        int hp = ap_h * 64 + lane;
+        asm volatile("" : "+v"(hp));                                  // (keeps the per-slot addresses out of loop-invariant registers)
+        hp += t * 128;
+        const bool real = hp < NPA * 16;
+        ap_lds = real ? lds0 + (uint32_t)(buf * AH_BYTES) + ((uint32_t)hp << 6) + (uint32_t)((ap_o ^ swz_a(hp)) << 4)
+                      : lds0 + (uint32_t)SCR_OFF + (uint32_t)(wave * 1024 + lane * 16);
+        HL_DSR(ap_d, ap_lds, 0);
+        asm volatile("ds_read_u8 %0, %1" : "=v"(ap_v) : "v"(val_lds + (uint32_t)(real ? hp : 0)));
+    };
+    auto ap_consts = [&](int chunk) {                                 // (A0..A7, B0..B7) of (chunk, octet o) -> lanes 0-15 of ap_k
+        asm volatile("ds_read_b32 %0, %1" : "=v"(ap_k) : "v"(lds0 + (uint32_t)TAB_OFF + (uint32_t)(((chunk * 4 + ap_o) * 16 + (lane & 15)) << 2)));
+    };
+    // y = silu(A x + B) on channel pair j: f32 arithmetic, one rounding to f16
+    auto ap_pair = [&](int j) {
+        int kk = ap_k;
+        asm volatile("" : "+v"(kk));                                  // read the lanes here (no 16 long-lived SGPRs)
+#pragma unroll
+        for (int e = 2 * j; e < 2 * j + 2; ++e) {
+            const float A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kk, e));
+            const float B = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kk, 8 + e));
+            float y = (float)ap_d[e] * A + B;
+            y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            ap_d[e] = (half_t)y;
+        }
+    };
+    auto ap_store = [&]() {                                           // zero padding belongs to the transformed image
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        u32x4 v = __builtin_bit_cast(u32x4, ap_d);
+        const bool ok = ap_v != 0;
+        v[0] = ok ? v[0] : 0u; v[1] = ok ? v[1] : 0u; v[2] = ok ? v[2] : 0u; v[3] = ok ? v[3] : 0u;
+        asm volatile("ds_write_b128 %0, %1" :: "v"(ap_lds), "v"(v) : "memory");
+    };
+
     // ---- prologue: halo of chunk 0, weight slices 0 and 1
 #pragma unroll
-    for (int t = 0; t < PA; ++t) glds16h(halo_src(t, cb), ah_dst + min(t * 8 + wave, NPA - 1) * 1024);
+    for (int t = 0; t < PA; ++t) glds16h(halo_src(t, cb), ah_dst + piece_off(t, 0));
     glds16h(bp, b_dst);
     bp += Cin;
     glds16h(bp, b_dst + B_BYTES);
     bp += Cin;
     if (PA == 9) {                                                    // keeps the issue order of the steady state (see HL_VMN)
-        glds16h(halo_src(PA - 1, cb), ah_dst + min((PA - 1) * 8 + wave, NPA - 1) * 1024);
+        glds16h(halo_src(PA - 1, cb), ah_dst + piece_off(PA - 1, 0));
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (APPLY) {
+        // the image's affine table and the validity bytes -> LDS (plain loads: the compiler drains every outstanding LDS-DMA
+        // first, which the transform below needs anyway); after the barrier every piece of chunk 0 is visible to every wave
+        const float4_t* tg = reinterpret_cast<const float4_t*>(ap_table) + (size_t)img * (Cin >> 1);
+        float4_t* tl = reinterpret_cast<float4_t*>(smem + TAB_OFF);
+        for (int i = tid; i < (Cin >> 1); i += NWAVES * 64) tl[i] = tg[i];
+        uint8_t* vl = reinterpret_cast<uint8_t*>(smem + TAB_OFF) + (size_t)Cin * 8;
+        for (int hp = tid; hp < NPA * 16; hp += NWAVES * 64) {
+            const int hy = hp / HW2, hx = hp - hy * HW2;
+            const int y = ty0 - 1 + hy, x = x0 + hx - 1;
+            vl[hp] = ((hp < HP) & (y >= 0) & (y < H) & (x >= 0) & (x < (1 << ILOG))) ? 1 : 0;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ap_consts(cb);
+#pragma unroll
+        for (int t = 0; t < PA; ++t) {
+            ap_fetch(t, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ap_d), "+v"(ap_v), "+v"(ap_k));
+            ap_pair(0); ap_pair(1); ap_pair(2); ap_pair(3);
+            ap_store();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
@@ -149,7 +236,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         // four weight fragments + A fragments 0..2 from the hand-over on.  LDS-DMA: weight slice s+2 after group 0, halo
         // piece T of chunk c+1 after group 1.  Hand-over in front of group 5: counted vmcnt (weight slice s+1 landed -- issued
         // after it: the previous step's halo piece, this step's weight and halo pieces), drain of my LDS reads, barrier.
-#define HL_VMN(T) (1 + ((T) < PA ? 1 : 0) + ((((T) + 8) % 9) < PA ? 1 : 0))
+    // APPLY: one fewer -- the previous step's halo piece must have landed too, it is fetched right behind the hand-over
+#define HL_VMN(T) (1 + ((T) < PA ? 1 : 0) + ((!APPLY && (((T) + 8) % 9) < PA) ? 1 : 0))
 #define HL_GROUP(P, T, g)                                                                                              \
     {                                                                                                                 \
         if constexpr ((g) + 3 < TM) {                                 /* A fragment g+3: row (g+3)/FPR of the wave's pixels */ \
@@ -168,6 +256,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
                 HL_DSR(bf[bn][0], b_nx, 0); HL_DSR(bf[bn][1], b_nx, 16 * ROWB);                                       \
                 HL_DSR(bf[bn][2], b_nx, 32 * ROWB); HL_DSR(bf[bn][3], b_nx, 48 * ROWB);                               \
                 HL_DSR(ar[0], a_nx0, 0);                                                                              \
+                if constexpr (APPLY && (T) >= 1 && (T) - 1 < PA) {    /* slot T-1 of chunk c+1 (landed: barrier above) */ \
+                    if constexpr ((T) == 1) ap_consts(cb + min(c + 1, NC - 1));                                       \
+                    ap_fetch((T) - 1, ab ^ 1);                                                                        \
+                }                                                                                                     \
             } else {                                                                                                  \
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]));                         \
             }                                                                                                         \
@@ -181,6 +273,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         } else {                                                                                                      \
             asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ar[(g) & 3]));                                                 \
             if constexpr ((g) == 0) asm volatile("" : "+v"(bf[bc][0]), "+v"(bf[bc][1]), "+v"(bf[bc][2]), "+v"(bf[bc][3])); \
+            if constexpr (APPLY && (g) == 0 && (T) >= 2 && (T) - 2 < PA)   /* fetched two groups before that wait: landed */ \
+                asm volatile("" : "+v"(ap_d), "+v"(ap_v), "+v"(ap_k));                                                \
+        }                                                                                                             \
+        if constexpr (APPLY && (T) >= 2 && (T) - 2 < PA) {            /* transform piece T-2 under this step's MFMAs */  \
+            if constexpr ((g) <= 3) ap_pair(g);                                                                       \
+            else if constexpr ((g) == 4) ap_store();                                                                  \
         }                                                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                 \
             acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[bc][j], ar[(g) & 3], acc[g][j], 0, 0, 0);           \
@@ -192,7 +290,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
             } else glds16h(zero_page, b_dst + st2 * B_BYTES);         /* past the end: harmless load, static counts */   \
         }                                                                                                             \
         if constexpr ((g) == 1 && (T) < PA) {                         /* halo piece T of chunk c + 1 */                 \
-            glds16h(halo_src(T, cb + min(c + 1, NC - 1)), ah_dst + (ab ^ 1) * AH_BYTES + min((T) * 8 + wave, NPA - 1) * 1024); \
+            glds16h(halo_src(T, cb + min(c + 1, NC - 1)), ah_dst + piece_off(T, ab ^ 1));                            \
         }                                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
     }
@@ -317,17 +415,34 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     }
 }
 
-template <int WLOG, int ILOG = WLOG>
-int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
-                int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int splits, float* partial) {
+template <int WLOG, int ILOG, bool APPLY>
+int launch_halo_v(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
+                  int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int splits, float* partial,
+                  const float* ap_table) {
     constexpr int W = 1 << WLOG, RT = 512 / W, HP = (RT + 2) * (W + 2), NPA = (HP + 15) / 16;
-    const size_t smem = std::max<size_t>((size_t)2 * NPA * 1024 + 3 * 8192, (size_t)512 * (128 + 8) * 2);
-    auto kern = k_conv3x3_halo<WLOG, ILOG>;
+    const size_t loop_bytes = (size_t)2 * NPA * 1024 + 3 * 8192 + (APPLY ? (size_t)8 * 1024 + (size_t)Cin * 8 + (size_t)NPA * 16 + 16 : 0);
+    const size_t smem = std::max<size_t>(loop_bytes, (size_t)512 * (128 + 8) * 2);
+    PD_REQUIRE(smem <= 160 * 1024, "conv3x3_halo: %zu bytes of LDS (Cin = %d)", smem, Cin);
+    auto kern = k_conv3x3_halo<WLOG, ILOG, APPLY>;
     PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int n_tiles = Cout_pad / 128;
     const int total = (int)(((long long)N * H * (1 << ILOG)) / 512) * n_tiles;
-    kern<<<dim3(total, splits), 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part, splits, partial);
+    kern<<<dim3(total, splits), 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part, splits,
+                                                partial, ap_table);
     return PDHIP_OK;
+}
+template <int WLOG, int ILOG = WLOG>
+int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
+                int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int splits, float* partial,
+                const float* ap_table) {
+    constexpr int W = 1 << WLOG, RT = 512 / W, HP = (RT + 2) * (W + 2), NPA = (HP + 15) / 16, PA = (NPA + 7) / 8;
+    if constexpr (PA <= 7) {
+        if (ap_table != nullptr)
+            return launch_halo_v<WLOG, ILOG, true>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part, splits, partial, ap_table);
+    } else {
+        PD_REQUIRE(ap_table == nullptr, "conv3x3_halo: the full-row 256-wide tile has no APPLY variant");
+    }
+    return launch_halo_v<WLOG, ILOG, false>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part, splits, partial, nullptr);
 }
 
 }  // namespace
@@ -354,7 +469,7 @@ int conv3x3_halo_splits(int N, int H, int W, int Cin, int Cout, int Cout_pad, si
 // epilogue, H*W/16 from the split reduce)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
                  int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
-                 float* splitk_ws, size_t splitk_ws_floats) {
+                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table) {
     PD_REQUIRE(conv3x3_halo_eligible(N, H, W, Cin, Cout_pad), "conv3x3_halo: unsupported geometry (N=%d H=%d W=%d Cin=%d)", N, H, W, Cin);
     int splits = conv3x3_halo_splits(N, H, W, Cin, Cout, Cout_pad, splitk_ws ? splitk_ws_floats : 0);
     if (splits < 1) splits = 1;
@@ -365,13 +480,14 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
     const bool fuse_sk = splits > 1 && gn_part != nullptr && (H * W) % 16 == 0;
     if (gn_fused) *gn_fused = gn_part ? (splits > 1 ? (fuse_sk ? (H * W) / 16 : 0) : (int)(((long long)H * W) / 512)) : 0;
     float* gnp = splits > 1 ? nullptr : gn_part;
-#define HL_LAUNCH(WL) launch_halo<WL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial)
+#define HL_LAUNCH(WL) launch_halo<WL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table)
     int rc;
-#define HL_LAUNCH2(WL, IL) launch_halo<WL, IL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial)
+#define HL_LAUNCH2(WL, IL) launch_halo<WL, IL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table)
     // 256-wide images: column strips of 128 (4 rows x 128 per tile: 780 halo pixels per chunk instead of 1 032) measured +2-3 %
     // over full rows, strips of 64 +1.5-3 %; at 128 wide strips do not pay.  g_halo_strips: 0 automatic, 1 full rows, 2 = 64 wide.
     if (W == 256 && g_halo_strips == 2 && H % 8 == 0) rc = HL_LAUNCH2(6, 8);
     else if (W == 256 && g_halo_strips != 1 && H % 4 == 0) rc = HL_LAUNCH2(7, 8);
+    else if (W == 256 && apply_table != nullptr) { set_error("conv3x3_halo: APPLY needs H %% 4 == 0 at W = 256"); return PDHIP_E_ARG; }
     else if (W == 256) rc = HL_LAUNCH(8);
     else if (W == 128) rc = HL_LAUNCH(7);
     else if (W == 64) rc = HL_LAUNCH(6);

@@ -132,6 +132,40 @@ int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB,
     return PDHIP_OK;
 }
 
+// ---- GroupNorm (+ FiLM) folded to one affine map per (image, channel) for the conv kernels that apply it while staging their
+// input (nn_conv_halo.hip, APPLY): y = silu(A x + B), A = rstd gamma t1, B = (beta - mean rstd gamma) t1 + sh with the FiLM terms
+// t1 = f16(1 + f16(scale)), sh = f16(shift) exactly as k_gn_apply forms them (1, 0 without FiLM).  The fused form rounds once
+// (after the SiLU) where the stand-alone kernel rounds after every op like the reference's f16 tensors do; the difference
+// is below the f16 resolution of the result and inside the U1 tolerance (tests compare both with the fp32 reference).
+// table [N][C/8][16] = (A0..A7, B0..B7) per channel octet: a wave of the conv owns one octet, so its 16 constants are
+// wave-uniform (lanes 0-15 of one register, read with v_readlane).
+__global__ __launch_bounds__(256) void k_gn_table(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ film,
+                                                  long long film_stride, int C, float* __restrict__ table) {
+    const int n = blockIdx.y, cg = C / 32;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        {
+            const int grp = c / cg;
+            const float mean = stats[((size_t)n * 32 + grp) * 2], rstd = stats[((size_t)n * 32 + grp) * 2 + 1];
+            const float ga = rstd * gamma[c], gb = beta[c] - mean * ga;
+            float t1 = 1.0f, sh = 0.0f;
+            if (film != nullptr) {
+                t1 = (float)(half_t)(1.0f + (float)(half_t)film[(size_t)n * film_stride + c]);
+                sh = (float)(half_t)film[(size_t)n * film_stride + C + c];
+            }
+            float* row = table + ((size_t)n * (C / 8) + (c >> 3)) * 16;
+            row[c & 7] = ga * t1; row[8 + (c & 7)] = gb * t1 + sh;
+        }
+    }
+}
+int gn_table(const float* stats, const float* gamma, const float* beta, const float* film, long long film_stride, int N, int C,
+             float* table, hipStream_t s) {
+    PD_REQUIRE(C % 32 == 0, "gn_table: C %% 32 != 0");
+    k_gn_table<<<dim3(cdiv(C, 256), N), 256, 0, s>>>(stats, gamma, beta, film, film_stride, C, table);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
 // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to f16 (or feeds the f32 head,
 // tolerance 1e-3) and the divide was half of this HBM-bound kernel's VALU work
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

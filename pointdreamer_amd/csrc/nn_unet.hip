@@ -28,6 +28,9 @@ struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chunks = 0; const float* gn_partB = nullptr; int Ca = 0; int gn_chunksB = 0;
              half_t* p2 = nullptr; };   // p2: virtual channel concat [p (Ca channels) | p2 (C - Ca channels)], never materialised
 
+}  // namespace
+namespace pdnn { int g_fuse_gn = 1; }           // tuning / test hook (pdhip_debug_set_fuse_gn): 0 = stand-alone GroupNorm-apply passes
+namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
 }  // namespace
@@ -49,6 +52,7 @@ struct pdhip_unet {
     // workspace
     char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
     float *stats = nullptr, *gn_ws = nullptr; size_t gn_ws_floats = 0;
+    float* ap_table = nullptr;                   // GroupNorm (+ FiLM) folded to (A, B) per (image, channel) for the conv that applies it while staging
     float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr;
     // DDNM sampler: the embeddings of all (<= 100) schedule steps, computed in ONE pass over the 180 MB of emb_layers weights
     // and kept until the weights change (every image of a sampling step shares t, so the per-step forward reads one row)
@@ -159,7 +163,8 @@ int prof_end(Ctx& c) {
     return PDHIP_OK;
 }
 
-int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false) {
+int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false,
+             const float* apply_table = nullptr) {
     *out = Act{nullptr, w.cout, x.H, x.W};
     out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
     // octet partials: [N][chunks][cout/8][2] floats, chunks <= HW/16 (split-K reduce) -- sized for the finest chunking
@@ -172,7 +177,7 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
     int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
-                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0);
+                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0, apply_table);
     if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = w.cout; }
     if (prof) PD_TRY(prof_end(c));
     return rc;
@@ -197,20 +202,42 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
     return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2, x.p2 ? x.Ca : 0);
 }
 
+// GroupNorm (+ FiLM) + SiLU of x folded into the conv that consumes it (the halo-resident kernel transforms its input tile in LDS,
+// nn_conv_halo.hip APPLY): statistics -> (A, B) table -> conv on the RAW tensor.  The stand-alone apply pass and its output
+// tensor disappear.  Taken for the 3x3 convs the halo kernel serves, single-source input, no resampling in between.
+bool can_fuse_gn(const Ctx& c, const Act& x, const ConvW& w) {
+    if (g_fuse_gn == 0 || x.p2 != nullptr || w.taps != 9 || (x.W == 256 && x.H % 4 != 0)) return false;
+    return conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats);
+}
+int run_gn_conv(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, const ConvW& w,
+                const half_t* residual, Act* out) {
+    if (!c.dry) {
+        PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
+        PD_TRY(run_gn_stats(c, x));
+        PD_TRY(gn_table(c.u->stats, n.g, n.b, film, film_stride, c.N, x.C, c.u->ap_table, c.s));
+    }
+    return run_conv(c, x, w, residual, out, true, c.dry ? nullptr : c.u->ap_table);
+}
+
 int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     Act h0, h1, h2, xr = x, sk;
-    PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, rb.mode, &h0));
+    const float* film = c.dry ? nullptr : c.film_base + rb.emb_off;
+    if (!c.dry) PD_REQUIRE(rb.have_ew && rb.have_eb, "unet: emb_layers of %s not loaded", rb.name.c_str());
+    if (rb.mode == 0 && can_fuse_gn(c, x, rb.c1)) {
+        PD_TRY(run_gn_conv(c, x, rb.n1, nullptr, 0, rb.c1, nullptr, &h1));
+    } else {
+        PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, rb.mode, &h0));
+        PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
+    }
     if (rb.mode != 0) {
-        xr.H = h0.H; xr.W = h0.W;
+        xr.H = h1.H; xr.W = h1.W;
         xr.p = arena_take(c.u, (size_t)c.N * xr.H * xr.W * x.C);
         if (!c.dry) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
     }
-    PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
-    const float* film = c.dry ? nullptr : c.film_base + rb.emb_off;
-    if (!c.dry) PD_REQUIRE(rb.have_ew && rb.have_eb, "unet: emb_layers of %s not loaded", rb.name.c_str());
-    PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
     sk = xr;
     if (rb.has_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
+    if (can_fuse_gn(c, h1, rb.c2)) return run_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, out);
+    PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
     return run_conv(c, h2, rb.c2, sk.p, out, true);
 }
 
@@ -419,6 +446,7 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     }
     u->gn_ws_floats = (size_t)max_batch * ((S2 + 255) / 256) * 64;
     chk(dalloc(u, &u->stats, (size_t)max_batch * 64)); chk(dalloc(u, &u->gn_ws, u->gn_ws_floats));
+    { int cmax = 0; for (const ResB& rb : u->res) cmax = std::max(cmax, std::max(rb.cin, rb.cout)); chk(dalloc(u, &u->ap_table, (size_t)max_batch * cmax * 2)); }
     chk(dalloc(u, &u->emb_silu, (size_t)max_batch * u->ted)); chk(dalloc(u, &u->emb_tmp, (size_t)max_batch * (u->mc + u->ted)));
     chk(dalloc(u, &u->emb_all, (size_t)max_batch * emb_rows));
     chk(dalloc(u, &u->steps_t, 128)); chk(dalloc(u, &u->steps_silu, (size_t)100 * u->ted));
@@ -712,6 +740,25 @@ extern "C" int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int sp
     int old = pdnn::g_force_splits;
     pdnn::g_dbg_splitk_ws = (float*)ws; pdnn::g_dbg_splitk_floats = ws ? (size_t)ws_floats : 0; pdnn::g_force_splits = splits;
     return old;
+}
+/* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
+extern "C" int pdhip_debug_set_fuse_gn(int on) { int old = pdnn::g_fuse_gn; pdnn::g_fuse_gn = on; return old; }
+/* stand-alone: y = conv3x3( silu( GroupNorm32(x) [* (1 + scale) + shift] ) ) (+ residual) with the transform applied inside the
+ * conv (halo-resident kernel; W in {32, 64, 128, 256}, H * W % 512 == 0, Cin % 32 == 0).  ws: N*64 + N*64*ceil(HW/256) + N*Cin*2 floats. */
+extern "C" int pdhip_gn_silu_conv3x3_nhwc_f16(const void* x, const float* gamma, const float* beta, const float* film,
+                                              long long film_stride, const void* w_packed, const float* bias, const void* residual,
+                                              void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, const void* zero_page,
+                                              float* ws, long long ws_floats, void* stream) {
+    PD_REQUIRE(x && gamma && beta && w_packed && y && zero_page && ws, "pdhip_gn_silu_conv3x3_nhwc_f16: null argument");
+    const size_t gws = (size_t)N * 64 * ((H * W + 255) / 256);
+    PD_REQUIRE((size_t)ws_floats >= (size_t)N * 64 + gws + (size_t)N * Cin * 2, "pdhip_gn_silu_conv3x3_nhwc_f16: workspace too small");
+    hipStream_t s = as_stream(stream);
+    float* stats = ws;
+    float* table = ws + (size_t)N * 64 + gws;
+    PD_TRY(gn_stats((const half_t*)x, N, H * W, Cin, 1e-5f, stats, ws + (size_t)N * 64, gws, s));
+    PD_TRY(gn_table(stats, gamma, beta, film, film_stride, N, Cin, table, s));
+    return conv3x3_halo((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
+                        Cout_pad, (const half_t*)zero_page, s, nullptr, nullptr, pdnn::g_dbg_splitk_ws, pdnn::g_dbg_splitk_floats, table);
 }
 extern "C" int pdhip_debug_set_conv_tile(int wmw) { int old = pdnn::g_force_wmw; pdnn::g_force_wmw = wmw; return old; }
 extern "C" int pdhip_debug_set_conv_stages(int st) { int old = pdnn::g_force_stages; pdnn::g_force_stages = st; return old; }

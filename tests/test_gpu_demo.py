@@ -69,9 +69,14 @@ def test_demo_with_supplied_mesh_obj_builds_and_caches_the_atlas(tmp_path):
     assert 0.5 < d["mask"].float().mean() < 1.0
     a1 = np.array(PIL.Image.open(os.path.join(out, "models/model_normalized.png")))
     assert a1.std() > 5
-    out2 = demo.main(args)[0]                                   # second run: cached dict
-    a2 = np.array(PIL.Image.open(os.path.join(out2, "models/model_normalized.png")))
-    assert np.array_equal(a1, a2)
+    out2 = demo.main(args)[0]                                   # second run: cached dict AND the {i}_inpainted.png of the first run
+    a2 = np.array(PIL.Image.open(os.path.join(out2, "models/model_normalized.png")))   # (demo.py:138-147: loaded back in 8 bits)
+    assert (np.abs(a1.astype(int) - a2.astype(int)) <= 3).mean() > 0.98
+    for k in range(8):
+        os.remove(os.path.join(out, "others", f"{k}_inpainted.png"))
+    out3 = demo.main(args)[0]                                   # cached dict only: bit-identical to the first run
+    a3 = np.array(PIL.Image.open(os.path.join(out3, "models/model_normalized.png")))
+    assert np.array_equal(a1, a3)
 
 
 def test_demo_directory_run_batches_shapes_and_matches_one_at_a_time(tmp_path):

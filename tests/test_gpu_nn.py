@@ -360,3 +360,65 @@ def test_conv_igemm_all_kernel_variants(nn, bk, stages, wmw):
             assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item() + 1e-3
     finally:
         L.pdhip_debug_set_conv_bk(old[0]); L.pdhip_debug_set_conv_stages(old[1]); L.pdhip_debug_set_conv_tile(old[2])
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,film,res,splits", [
+    (2, 16, 32, 64, 128, False, False, 0), (1, 32, 32, 96, 256, True, True, 0), (2, 8, 64, 64, 128, True, False, 0),
+    (1, 16, 64, 160, 128, False, True, 0), (2, 8, 128, 64, 256, True, True, 0), (1, 4, 128, 32, 128, False, False, 0),
+    (1, 4, 256, 64, 128, True, False, 0), (2, 8, 256, 96, 256, False, True, 0), (1, 16, 64, 128, 128, True, True, 2),
+    (3, 16, 32, 64, 128, True, False, 3)])
+def test_gn_silu_fused_into_halo_conv_vs_torch_fp32(nn, N, H, W, Cin, Cout, film, res, splits):
+    """The APPLY variant of the halo-resident 3x3 kernel: y = conv3x3(silu(GroupNorm32(x) [* (1 + scale) + shift])) (+ residual)
+    with the normalisation applied in LDS while the input tile is staged (in_layers / out_layers of a ResBlock, unet.py:183-252)
+    against plain torch fp32 on the same f16-rounded inputs: image borders (zero padding of the TRANSFORMED image), tile borders,
+    several images with different statistics and FiLM rows, odd chunk counts, residual, the split over channel chunks."""
+    L = nn['L']
+    g = torch.Generator().manual_seed(N * 1000 + H + W + Cin)
+    x = (torch.randn((N, Cin, H, W), generator=g) * (1.0 + torch.rand((N, Cin, 1, 1), generator=g)) + torch.randn((N, Cin, 1, 1), generator=g)).half().float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / math.sqrt(9 * Cin)).half().float()
+    b = (torch.randn((Cout,), generator=g) * 0.1).half().float()
+    gamma = 1.0 + 0.2 * torch.randn((Cin,), generator=g)
+    beta = 0.2 * torch.randn((Cin,), generator=g)
+    fl = (0.3 * torch.randn((N, 2 * Cin), generator=g)) if film else None
+    r = torch.randn((N, Cout, H, W), generator=g).half().float() if res else None
+    # fp32 reference
+    h = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if film:
+        h = h * (1 + fl[:, :Cin, None, None].half().float()) + fl[:, Cin:, None, None].half().float()
+    ref = F.conv2d(F.silu(h), w, b, padding=1)
+    if res:
+        ref = ref + r
+    pad = ((Cout + 127) // 128) * 128
+    xd = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    wp = torch.zeros((pad, 9 * Cin), dtype=torch.float16, device=DEV)
+    assert L.pdhip_pack_conv_weight_f16(_ptr(w.to(DEV)), Cout, Cin, 9, _ptr(wp), _stream()) == 0
+    bd, gd, be = b.to(DEV), gamma.to(DEV), beta.to(DEV)
+    fd = fl.to(DEV).contiguous() if film else None
+    rd = r.permute(0, 2, 3, 1).contiguous().half().to(DEV) if res else None
+    y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=DEV)
+    zp = torch.zeros((128,), dtype=torch.float16, device=DEV)
+    nws = N * 64 + N * 64 * ((H * W + 255) // 256) + N * Cin * 2
+    ws = torch.empty((nws,), device=DEV)
+    skws = torch.empty((max(splits, 1) * N * H * W * Cout,), device=DEV)
+    old = L.pdhip_debug_set_conv_splitk(_ptr(skws), skws.numel(), splits)
+    try:
+        rc = L.pdhip_gn_silu_conv3x3_nhwc_f16(_ptr(xd), _ptr(gd), _ptr(be), _ptr(fd) if film else None, 2 * Cin, _ptr(wp), _ptr(bd),
+                                              _ptr(rd) if res else None, _ptr(y), N, H, W, Cin, Cout, pad, _ptr(zp), _ptr(ws), nws, _stream())
+    finally:
+        L.pdhip_debug_set_conv_splitk(None, 0, 0)
+    assert rc == 0, L.pdhip_last_error()
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-3, err
+    # and it agrees with the two-pass form (stand-alone GroupNorm kernel, then the plain conv) to f16 rounding
+    hn = torch.empty((N, H, W, Cin), dtype=torch.float16, device=DEV)
+    st = torch.empty((N * 64,), device=DEV)
+    gws = torch.empty((N * 64 * ((H * W + 255) // 256),), device=DEV)
+    assert L.pdhip_groupnorm_nhwc_f16(_ptr(xd), _ptr(gd), _ptr(be), _ptr(fd) if film else None, N, H, W, Cin, 1, 0, _ptr(hn), _ptr(st),
+                                      _ptr(gws), gws.numel(), _stream()) == 0
+    y2 = torch.empty_like(y)
+    assert L.pdhip_conv2d_nhwc_f16(_ptr(hn), _ptr(wp), _ptr(bd), _ptr(rd) if res else None, _ptr(y2), N, H, W, Cin, Cout, pad, 9, _ptr(zp),
+                                   _stream()) == 0
+    torch.cuda.synchronize()
+    assert (y.float() - y2.float()).abs().max().item() / ref.abs().max().item() <= 3e-3
