@@ -154,14 +154,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         const bool real = hp < NPA * 16;
         ap_lds = real ? lds0 + (uint32_t)(buf * AH_BYTES) + ((uint32_t)hp << 6) + (uint32_t)((ap_o ^ swz_a(hp)) << 4)
                       : lds0 + (uint32_t)SCR_OFF + (uint32_t)(wave * 1024 + lane * 16);
+#ifndef PD_LAB_AP_NOFETCH
         HL_DSR(ap_d, ap_lds, 0);
         asm volatile("ds_read_u8 %0, %1" : "=v"(ap_v) : "v"(val_lds + (uint32_t)(real ? hp : 0)));
+#endif
     };
     auto ap_consts = [&](int chunk) {                                 // (A0..A7, B0..B7) of (chunk, octet o) -> lanes 0-15 of ap_k
         asm volatile("ds_read_b32 %0, %1" : "=v"(ap_k) : "v"(lds0 + (uint32_t)TAB_OFF + (uint32_t)(((chunk * 4 + ap_o) * 16 + (lane & 15)) << 2)));
     };
     // y = silu(A x + B) on channel pair j: f32 arithmetic, one rounding to f16
     auto ap_pair = [&](int j) {
+#ifdef PD_LAB_AP_NOCOMPUTE                                  // (lab builds only: the transform's LDS traffic without its arithmetic)
+        return;
+#endif
         int kk = ap_k;
         asm volatile("" : "+v"(kk));                                  // read the lanes here (no 16 long-lived SGPRs)
 #pragma unroll
@@ -169,7 +174,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
             const float A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kk, e));
             const float B = __builtin_bit_cast(float, __builtin_amdgcn_readlane(kk, 8 + e));
             float y = (float)ap_d[e] * A + B;
+#ifndef PD_LAB_AP_NOTRANS                                   // (lab builds only: affine map without the SiLU's transcendentals)
             y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+#endif
             ap_d[e] = (half_t)y;
         }
     };
@@ -178,7 +185,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         u32x4 v = __builtin_bit_cast(u32x4, ap_d);
         const bool ok = ap_v != 0;
         v[0] = ok ? v[0] : 0u; v[1] = ok ? v[1] : 0u; v[2] = ok ? v[2] : 0u; v[3] = ok ? v[3] : 0u;
+#ifndef PD_LAB_AP_NOSTORE
         asm volatile("ds_write_b128 %0, %1" :: "v"(ap_lds), "v"(v) : "memory");
+#endif
     };
 
     // ---- prologue: halo of chunk 0, weight slices 0 and 1
@@ -237,7 +246,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         // piece T of chunk c+1 after group 1.  Hand-over in front of group 5: counted vmcnt (weight slice s+1 landed -- issued
         // after it: the previous step's halo piece, this step's weight and halo pieces), drain of my LDS reads, barrier.
     // APPLY: one fewer -- the previous step's halo piece must have landed too, it is fetched right behind the hand-over
+#ifdef PD_LAB_AP_LOOSEVM
+#define HL_VMN(T) (1 + ((T) < PA ? 1 : 0) + (((((T) + 8) % 9) < PA) ? 1 : 0))
+#else
 #define HL_VMN(T) (1 + ((T) < PA ? 1 : 0) + ((!APPLY && (((T) + 8) % 9) < PA) ? 1 : 0))
+#endif
 #define HL_GROUP(P, T, g)                                                                                              \
     {                                                                                                                 \
         if constexpr ((g) + 3 < TM) {                                 /* A fragment g+3: row (g+3)/FPR of the wave's pixels */ \

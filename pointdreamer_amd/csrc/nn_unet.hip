@@ -29,7 +29,11 @@ struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chun
              half_t* p2 = nullptr; };   // p2: virtual channel concat [p (Ca channels) | p2 (C - Ca channels)], never materialised
 
 }  // namespace
-namespace pdnn { int g_fuse_gn = 1; }           // tuning / test hook (pdhip_debug_set_fuse_gn): 0 = stand-alone GroupNorm-apply passes
+// tuning / test hook (pdhip_debug_set_fuse_gn).  Default 0 = stand-alone GroupNorm-apply passes: MEASURED faster.  The in-conv
+// transform removes 9.4 ms of gn_apply per batch-32 forward but costs the halo conv 23 % (tools/bench_conv.py --apply, lab builds:
+// fetch of the staged pieces -4.5 %, the in-place ds_write_b128 -10 % -- a store occupies the SIMD's LDS path for 13 cycles in
+// front of the fragment reads the MFMAs wait for -- arithmetic -8 %): 76.2 vs 71.4 ms per DDNM step at batch 32.
+namespace pdnn { int g_fuse_gn = 0; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
@@ -50,7 +54,7 @@ struct pdhip_unet {
     NormW out_norm; float* out_w = nullptr; float* out_b = nullptr; bool have_ow = false, have_ob = false;
     half_t* zero_page = nullptr;
     // workspace
-    char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0;
+    char* arena = nullptr; size_t arena_bytes = 0, arena_off = 0; bool arena_overflow = false;
     float *stats = nullptr, *gn_ws = nullptr; size_t gn_ws_floats = 0;
     float* ap_table = nullptr;                   // GroupNorm (+ FiLM) folded to (A, B) per (image, channel) for the conv that applies it while staging
     float *emb_silu = nullptr, *emb_tmp = nullptr, *emb_all = nullptr;
@@ -137,6 +141,7 @@ int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 409
 half_t* arena_take(pdhip_unet* u, size_t halfs) {
     size_t bytes = (halfs * sizeof(half_t) + 255) & ~(size_t)255;
     if (u->arena == nullptr) { u->arena_off += bytes; return nullptr; }      // dry run (sizing)
+    if (u->arena_off + bytes > u->arena_bytes) { u->arena_overflow = true; return reinterpret_cast<half_t*>(u->arena); }   // (reported by forward_impl)
     half_t* p = reinterpret_cast<half_t*>(u->arena + u->arena_off);
     u->arena_off += bytes;
     return p;
@@ -206,6 +211,7 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
 // nn_conv_halo.hip APPLY): statistics -> (A, B) table -> conv on the RAW tensor.  The stand-alone apply pass and its output
 // tensor disappear.  Taken for the 3x3 convs the halo kernel serves, single-source input, no resampling in between.
 bool can_fuse_gn(const Ctx& c, const Act& x, const ConvW& w) {
+    if (c.dry) return false;                     // the sizing pass takes the two-pass form: it needs the larger arena
     if (g_fuse_gn == 0 || x.p2 != nullptr || w.taps != 9 || (x.W == 256 && x.H % 4 != 0)) return false;
     return conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats);
 }
@@ -289,6 +295,7 @@ int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* ou
                  const float* shared_emb = nullptr) {
     Ctx c{u, N, s, dry, shared_emb ? shared_emb : u->emb_all, shared_emb ? 0 : u->emb_rows};
     u->arena_off = 0;
+    u->arena_overflow = false;
     if (!dry && shared_emb == nullptr) {
         PD_REQUIRE(u->have_te[0] && u->have_te[1] && u->have_te[2] && u->have_te[3], "unet: time_embed not loaded");
         PD_TRY(timestep_mlp(t, N, u->mc, u->te_w0, u->te_b0, u->te_w2, u->te_b2, u->emb_silu, u->emb_tmp, s));
@@ -323,6 +330,7 @@ int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* ou
         PD_TRY(run_blocks(c, blk, &h, x));
     }
     if (!dry) {
+        PD_REQUIRE(!u->arena_overflow, "unet: activation arena too small for this routing (sized at create())");
         PD_REQUIRE(u->out_norm.have_g && u->out_norm.have_b && u->have_ow && u->have_ob, "unet: output head not loaded");
         PD_TRY(run_gn_stats(c, h));
         PD_TRY(head_gn_silu_conv3x3(h.p, u->stats, u->out_norm.g, u->out_norm.b, u->head_wz, u->out_b, out, N, h.H, h.W, h.C,
@@ -759,6 +767,13 @@ extern "C" int pdhip_gn_silu_conv3x3_nhwc_f16(const void* x, const float* gamma,
     PD_TRY(gn_table(stats, gamma, beta, film, film_stride, N, Cin, table, s));
     return conv3x3_halo((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
                         Cout_pad, (const half_t*)zero_page, s, nullptr, nullptr, pdnn::g_dbg_splitk_ws, pdnn::g_dbg_splitk_floats, table);
+}
+/* tuning hook: the APPLY conv on a ready-made (A, B) table [N][Cin/8][16] (tools/bench_conv.py --apply) */
+extern "C" int pdhip_debug_conv3x3_apply(const void* x, const float* table, const void* w_packed, const float* bias, const void* residual,
+                                         void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, const void* zero_page, void* stream) {
+    PD_REQUIRE(x && table && w_packed && y && zero_page, "pdhip_debug_conv3x3_apply: null argument");
+    return conv3x3_halo((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
+                        Cout_pad, (const half_t*)zero_page, as_stream(stream), nullptr, nullptr, nullptr, 0, table);
 }
 extern "C" int pdhip_debug_set_conv_tile(int wmw) { int old = pdnn::g_force_wmw; pdnn::g_force_wmw = wmw; return old; }
 extern "C" int pdhip_debug_set_conv_stages(int st) { int old = pdnn::g_force_stages; pdnn::g_force_stages = st; return old; }

@@ -222,10 +222,15 @@ def test_unet_full_256_vs_reference_golden(nn):
     m = nn['di'].UNetModel(max_batch=1, device=DEV, **nn['di'].IMAGENET_256)
     m.load_state_dict(w, strict=True)
     del w
-    out = m(torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV)).cpu()
     st = int(g['stride'])
-    linf, l2 = _rel(out[:, :, ::st, ::st], torch.from_numpy(g['ref_out']))
-    assert linf <= 2e-2 and l2 <= 5e-3, (linf, l2)
+    for fuse in (0, 1):                                     # stand-alone GroupNorm passes / GroupNorm applied inside the halo conv
+        old = nn['L'].pdhip_debug_set_fuse_gn(fuse)
+        try:
+            out = m(torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV)).cpu()
+        finally:
+            nn['L'].pdhip_debug_set_fuse_gn(old)
+        linf, l2 = _rel(out[:, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+        assert linf <= 2e-2 and l2 <= 5e-3, (fuse, linf, l2)
 
 
 def test_ddnm_schedule_and_step_vs_reference_sampler_golden(nn):

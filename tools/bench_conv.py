@@ -15,6 +15,7 @@ ap.add_argument('--custom', type=int, nargs='*', default=None, help='extra shape
 ap.add_argument('--zeros', action='store_true', help='zero activations and weights (DVFS reference)')
 ap.add_argument('--stamps', action='store_true', help='lab_stamp build: print per-phase cycle averages of the last launch')
 ap.add_argument('--res', action='store_true', help='pass a residual tensor (the out_layers conv of a ResBlock)')
+ap.add_argument('--apply', action='store_true', help='time the APPLY (GroupNorm + SiLU in LDS) variant of the halo kernel on 3x3 shapes')
 ap.add_argument('--lib', default=None, help='alternative libpdhip.so (lab builds)')
 a = ap.parse_args()
 if a.lib:
@@ -41,13 +42,21 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
     for cfg in a.cfg:
         bk, st, wm = (int(v) for v in cfg.split('x'))
         L.pdhip_debug_set_conv_bk(bk); L.pdhip_debug_set_conv_stages(st); L.pdhip_debug_set_conv_tile(wm)
+        if a.apply and taps == 9:
+            tab = torch.randn((N, Cin // 8, 16), device=dev) * 0.5 + 1.0
+            if a.zeros: tab.zero_()
+            fn = C.CDLL(_lib.LIB_PATH).pdhip_debug_conv3x3_apply
+            fn.argtypes = [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p] * 2
+            call = lambda st: fn(P(x), P(tab), P(w), P(b), rs, P(y), N, H, W, Cin, Cout, pad, P(zp), st)
+        else:
+            call = lambda st: L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), rs, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), st)
         for _ in range(3):
-            L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), rs, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), None)
+            call(None)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            L.pdhip_conv2d_nhwc_f16(P(x), P(w), P(b), rs, P(y), N, H, W, Cin, Cout, pad, taps, P(zp), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            call(C.c_void_p(torch.cuda.current_stream().cuda_stream))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         res.append(f"{cfg}: {fl/ms/1e9:6.0f}")

@@ -33,7 +33,7 @@ for N in a.batches:
     row = dict(batch=N, forward_ms=round(ms, 3), ms_per_image=round(ms / N, 3), tflops_effective=round(2.2397 * N / ms, 1))
     if a.sampler_steps:
         inp = di.Inpainter.__new__(di.Inpainter)
-        inp.device, inp.model, inp.seed, inp.n_steps, inp._calls, inp.max_batch = dev, m, 1234, a.sampler_steps, 0, N
+        inp.device, inp.model, inp.seed, inp.n_steps, inp._images, inp.max_batch = dev, m, 1234, a.sampler_steps, 0, N
         imgs = torch.rand((N, 3, 256, 256), device=dev); masks = (torch.rand((N, 256, 256), device=dev) > 0.5).float()
         inp.inpaint_views(imgs * masks[:, None], masks)
         torch.cuda.synchronize()
