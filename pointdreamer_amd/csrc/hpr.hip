@@ -461,18 +461,18 @@ template <typename T> __device__ bool closest_simplex(Simplex<T>& S, v3<T>& v) {
     return true;
 }
 
-// ---- exact fallback: one 256-lane block per query the f64 pass could not certify.  Same iteration, double-double state and
+// ---- exact fallback: one 512-lane block per query the f64 pass could not certify.  Same iteration, double-double state and
 // double-double support values over the same support set (any superset of the hull vertices), duplicates of the query with a
 // larger cloud index excluded from S_i (of coinciding points the smallest index is the hull vertex), up to 512 rounds.
-__global__ __launch_bounds__(256) void k_hpr_exact(const double* __restrict__ flipped, int N, const int* __restrict__ unc_count,
+__global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ flipped, int N, const int* __restrict__ unc_count,
                                                    const int* __restrict__ unc_list, uint8_t* __restrict__ vis,
                                                    const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
                                                    const int* __restrict__ scount, const unsigned long long* __restrict__ maxabs,
                                                    int* __restrict__ counters /*[V][4]: exact queries, unresolved, rounds, -*/) {
     const int v = blockIdx.y;
     const int nq = unc_count[v];
-    __shared__ double s_hi[4], s_lo[4];
-    __shared__ int s_i[4];
+    __shared__ double s_hi[8], s_lo[8];
+    __shared__ int s_i[8];
     const double* fx = ss + (size_t)v * 3 * scap;
     const double* fy = fx + scap;
     const double* fz = fy + scap;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_hpr_exact(const double* __restrict__ fl
             // support scan in double-double: (dx x + dy y) + dz z with exact inputs x, y, z
             dd best = {-1.0e300, 0.0};
             int bi = 0x7fffffff;
-            for (int j = threadIdx.x; j < NS; j += 256) {
+            for (int j = threadIdx.x; j < NS; j += 512) {
                 const double x = fx[j], y = fy[j], zz = fz[j];
                 const int jo = sidx[j];
                 if (jo == q || (jo > q && x == px && y == py && zz == pz)) continue;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_hpr_exact(const double* __restrict__ fl
             __syncthreads();
             best = dd{s_hi[0], s_lo[0]}; bi = s_i[0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < 8; ++w) {
                 const double oh = s_hi[w], ol = s_lo[w];
                 const int oi = s_i[w];
                 if (oh > best.hi || (oh == best.hi && (ol > best.lo || (ol == best.lo && oi < bi)))) { best = dd{oh, ol}; bi = oi; }
@@ -738,13 +738,13 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
         k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
         k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist);
         k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist);
-        k_hpr_exact<<<gx, 256, 0, s>>>(flipped, N, ucount, ulist, visibility, ss, sidx, N, scount, maxabs, counters);
+        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, visibility, ss, sidx, N, scount, maxabs, counters);
     } else {                         // one level: support set = the whole cloud
         k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
         k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
         k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist);
         k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist);
-        k_hpr_exact<<<gx, 256, 0, s>>>(flipped, N, ucount, ulist, visibility, flipped, sidx, N, scount, maxabs, counters);
+        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, visibility, flipped, sidx, N, scount, maxabs, counters);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
