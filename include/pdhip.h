@@ -131,6 +131,18 @@ int pdhip_nearest_fill(const float* img, float* out, int B, int C, int H, int W,
                        const void* mask, int mask_is_f32, int64_t mask_batch_stride,
                        int32_t* ws, void* stream);
 
+/* ---- I0, texture_gen_method='linear': ours_utils.naive_inpainting(method='linear') (ours_utils.py:610-643), i.e.
+ *      scipy.interpolate.griddata(method='linear'): Delaunay triangulation of the sites + barycentric interpolation, NaN outside
+ *      the sites' convex hull.  Every unknown pixel finds its own Delaunay triangle (lifted lower-hull facet over the pixel) with
+ *      exact integer predicates evaluated in float64; where co-circular sites admit several triangulations a valid one is used.
+ *      img/out [B,C,H,W] f32 contiguous, mask per image H*W (f32: site iff != 0, else uint8), H, W <= 2048.
+ *      ws: pdhip_linear_fill_ws_bytes(B,H,W).  tri (may be NULL): [B,H,W,3] int32, the triangle's site indices (row-major site
+ *      order), -1 at sites, -2 outside the hull.  pdhip_linear_fill_unresolved (synchronises): queries that hit the round cap (0). */
+size_t pdhip_linear_fill_ws_bytes(int B, int H, int W);
+int pdhip_linear_fill(const float* img, float* out, int B, int C, int H, int W, const void* mask, int mask_is_f32,
+                      int64_t mask_batch_stride, void* ws, int32_t* tri, void* stream);
+int pdhip_linear_fill_unresolved(const void* ws, int B, int H, int W, int* out, void* stream);
+
 /* ---- Uq1+Uq2: unproject.unproject texel transform + depth visibility (unproject.py:219-284).
  *      visibility[V,A,A] u8 (0 outside the chart mask). */
 int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos /*[A,A,3]*/,

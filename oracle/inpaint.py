@@ -82,3 +82,43 @@ def reference_nearest_inpaint_scipy(img, no_need_inpaint_mask2):
     xx, yy = np.meshgrid(np.arange(img.shape[2]), np.arange(res), indexing='xy')
     out = griddata(valid_coords, valid_pixels.T, (xx, yy), method='nearest')
     return out.transpose(2, 0, 1)
+
+
+def reference_linear_inpaint_scipy(img, no_need_inpaint_mask2):
+    """ours_utils.py:617-643 with method='linear': scipy.interpolate.griddata -> qhull Delaunay + LinearNDInterpolator
+    (float64 barycentric interpolation, NaN outside the hull).  Returns [C,H,W] float64 like the reference."""
+    from scipy.interpolate import griddata
+    img = np.asarray(img)
+    m = np.asarray(no_need_inpaint_mask2)[0]
+    need = ~(m.astype(np.bool_))
+    y_coords, x_coords = np.indices(img.shape[1:])
+    coords = np.column_stack((x_coords.ravel(), y_coords.ravel()))
+    img_flat = img.reshape(img.shape[0], -1)
+    mask_flat = need.ravel().astype(np.bool_)
+    xx, yy = np.meshgrid(np.arange(img.shape[2]), np.arange(img.shape[1]), indexing='xy')
+    out = griddata(coords[~mask_flat], img_flat[:, ~mask_flat].T, (xx, yy), method='linear')
+    return out.transpose(2, 0, 1)
+
+
+def delaunay_triangle_is_valid(sites_xy, tri, q):
+    """Is (sites_xy[tri]) a triangle of SOME Delaunay triangulation of the sites that contains pixel q?  Exact integer
+    arithmetic: q inside or on the triangle, no site strictly inside its circumcircle.  (Pixels are a degenerate input --
+    co-circular sites everywhere -- so several triangulations are valid; qhull's pick is a property of its merge order.)"""
+    P = np.asarray(sites_xy, np.int64)
+    a, b, c = (P[int(t)] for t in tri)
+    q = np.asarray(q, np.int64)
+
+    def orient(u, v, w):
+        return (v[0] - u[0]) * (w[1] - u[1]) - (v[1] - u[1]) * (w[0] - u[0])
+    o = orient(a, b, c)
+    if o == 0:
+        return False
+    if o < 0:
+        b, c = c, b
+    if orient(a, b, q) < 0 or orient(b, c, q) < 0 or orient(c, a, q) < 0:
+        return False
+    ax, ay = a[0] - P[:, 0], a[1] - P[:, 1]
+    bx, by = b[0] - P[:, 0], b[1] - P[:, 1]
+    cx, cy = c[0] - P[:, 0], c[1] - P[:, 1]
+    det = (ax * ax + ay * ay) * (bx * cy - cx * by) - (bx * bx + by * by) * (ax * cy - cx * ay) + (cx * cx + cy * cy) * (ax * by - bx * ay)
+    return bool((det <= 0).all())

@@ -37,6 +37,9 @@ _SIGS = {
     'pdhip_sparse_views': (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
     'pdhip_nearest_fill_ws_ints': (sz, [i32, i32, i32]),
     'pdhip_nearest_fill': (C.c_int, [vp, vp, i32, i32, i32, i32, i64, i64, i64, vp, i32, i64, vp, vp]),
+    'pdhip_linear_fill_ws_bytes': (sz, [i32, i32, i32]),
+    'pdhip_linear_fill': (C.c_int, [vp, vp, i32, i32, i32, i32, vp, i32, i64, vp, vp, vp]),
+    'pdhip_linear_fill_unresolved': (C.c_int, [vp, i32, i32, i32, vp, vp]),
     'pdhip_texel_visibility': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, f64, vp, i32, f32, vp, vp]),
     'pdhip_nbf_shrink': (C.c_int, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
     'pdhip_nbf_triptych': (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -185,15 +185,44 @@ def nearest_fill(img, site_mask, layout='CHW'):
     return out
 
 
+def linear_fill(img, site_mask, return_triangles=False):
+    """Batched Delaunay-linear fill (scipy griddata method='linear' per image): img [B,C,H,W] float32, site_mask [B,H,W]
+    bool / uint8 / float (site iff != 0).  Unknown pixels outside the convex hull of the sites become NaN, as with scipy.
+    return_triangles: also the [B,H,W,3] int32 site indices of the triangle used per pixel (tests)."""
+    L = _lib.lib()
+    img = img.float().contiguous()
+    dev = _dev(img)
+    B, Cn, H, W = img.shape
+    site_mask = site_mask.contiguous()
+    is_f32 = 1 if site_mask.dtype == torch.float32 else 0
+    if not is_f32:
+        site_mask = as_u8(site_mask)
+        if site_mask.dtype != torch.uint8:
+            raise _lib.PdhipError("site mask must be bool, uint8 or float32")
+    out = torch.empty_like(img)
+    ws = torch.empty((L.pdhip_linear_fill_ws_bytes(B, H, W),), dtype=torch.uint8, device=dev)
+    tri = torch.empty((B, H, W, 3), dtype=torch.int32, device=dev) if return_triangles else None
+    check(L.pdhip_linear_fill(ptr(img), ptr(out), B, Cn, H, W, ptr(site_mask), is_f32, H * W, ptr(ws), ptr(tri, allow_none=True),
+                              stream()), 'pdhip_linear_fill')
+    if return_triangles:
+        n = C.c_int(0)
+        check(L.pdhip_linear_fill_unresolved(ptr(ws), B, H, W, C.byref(n), stream()), 'pdhip_linear_fill_unresolved')
+        if n.value:
+            raise _lib.PdhipError(f"linear_fill: {n.value} pixels hit the round cap")
+        return out, tri
+    return out
+
+
 def naive_inpainting(img, no_need_inpaint_mask2, method='linear'):
     """ours_utils.py:610-643.  img[C,H,W], mask2[C,H,W] (channel 0 used) -> [C,H,W] float32 on the GPU.
-    Only method='nearest' is built (exact, tie rule in DESIGN.md); 'linear' needs a Delaunay
-    triangulation and is out of scope for this round."""
-    if method != 'nearest':
-        raise NotImplementedError("texture_gen_method='linear' (scipy Delaunay) is not built; use 'nearest' or 'DDNM_inpaint'")
+    'nearest': exact nearest site (tie rule in DESIGN.md); 'linear': Delaunay-linear (csrc/linear.hip)."""
+    if method not in ('nearest', 'linear'):
+        raise ValueError(f"naive_inpainting: method {method!r} (scipy griddata knows 'cubic' too; the reference never uses it)")
     m = no_need_inpaint_mask2[0:1].contiguous()
     if m.dtype not in (torch.float32, torch.bool, torch.uint8):
         m = m.float()
+    if method == 'linear':
+        return linear_fill(img.unsqueeze(0), m)[0]
     return nearest_fill(img.unsqueeze(0), m, 'CHW')[0]
 
 
@@ -227,8 +256,10 @@ def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpai
         out = inpainter.inpaint_views(sparse_imgs, hard_mask2s[:, 0].contiguous(), first_key=first_key, advance=advance)
     elif method == 'nearest':
         out = nearest_fill(sparse_imgs, hard_mask2s[:, 0].contiguous(), 'CHW')
+    elif method == 'linear':
+        out = linear_fill(sparse_imgs, hard_mask2s[:, 0].contiguous())
     else:
-        raise NotImplementedError(f"texture_gen_method={method!r} is not built (DDNM_inpaint | nearest)")
+        raise NotImplementedError(f"texture_gen_method={method!r} is not built (DDNM_inpaint | nearest | linear)")
     if save_path is not None:
         save_inpainted_images(out, hard_mask0s, save_path, view_num, method, view_offset)
     return out

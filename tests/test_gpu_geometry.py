@@ -569,3 +569,67 @@ def test_degenerate_sizes_do_not_break_the_entry_points(pd):
     assert int(out[0].sum()) == 0 and bool((out[1] == -1).all()) and bool((out[2] == 0).all())
     out = pd['ou'].get_rendered_hard_mask_and_face_idx_batch(cams, T(verts), T(faces), T(np.zeros((0, 3), np.float32)), None, True, 0.05)
     assert tuple(out[7].shape) == (3, 0, 2) and int(out[0].sum()) > 0
+
+
+def _site_list(mask):
+    ys, xs = np.nonzero(mask)                                   # row-major order == the kernel's site order
+    return np.stack([xs, ys], 1)
+
+
+@pytest.mark.parametrize("case", ["random64", "ring_only", "no_corners", "golden_view"])
+def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case):
+    """texture_gen_method='linear' (ours_utils.py:610-643 -> scipy griddata linear = qhull Delaunay + barycentric interpolation).
+    The device finds, per unknown pixel, its Delaunay triangle exactly (integer predicates).  Equality with scipy is required
+    wherever the values agree to 1e-5; every other pixel must sit in a co-circular configuration where the device's triangle is
+    still a valid Delaunay triangle containing the pixel (exact brute-force check), and NaN (outside the hull) must coincide."""
+    rng = np.random.default_rng(11)
+    if case == "golden_view":
+        g = load_golden("proj_sparse_dense.npz")
+        img, m2 = g['ref_sparse'][0].astype(np.float32), g['ref_mask2'][0]
+    else:
+        H = W = 64
+        m = rng.uniform(0, 1, (H, W)) > (0.9 if case != "ring_only" else 2.0)
+        if case != "no_corners":
+            m[0, :] = m[-1, :] = m[:, 0] = m[:, -1] = True      # the reference's images: background border = sites
+        else:
+            m[:6, :] = False; m[:, :5] = False                  # queries outside the hull -> NaN
+        img = rng.uniform(0, 1, (3, H, W)).astype(np.float32) * m[None]
+        m2 = np.repeat(m[None].astype(np.float32), 3, 0)
+    sites = m2[0] != 0
+    want = oinp.reference_linear_inpaint_scipy(img, m2)
+    got, tri = pd['ou'].linear_fill(T(img[None]), T(sites[None]), return_triangles=True)
+    got, tri = N_(got)[0], N_(tri)[0]
+    assert np.array_equal(got[:, sites], img[:, sites])                     # sites keep their values
+    nan_w, nan_g = np.isnan(want).any(0), np.isnan(got).any(0)
+    P = _site_list(sites)
+    qs = np.argwhere(~sites)
+    diff = np.abs(np.nan_to_num(got) - np.nan_to_num(want)).max(0)
+    bad = (diff > 1e-5) | (nan_w != nan_g)
+    assert bad[sites].sum() == 0
+    frac = bad[~sites].mean() if (~sites).any() else 0.0
+    if case != "ring_only":                                                 # (a bare square ring of sites is co-circular through and through)
+        assert frac < 0.35, frac                                           # co-circular ambiguity only; most pixels agree outright
+    checked = 0
+    for (y, x) in qs:
+        t = tri[y, x]
+        if nan_g[y, x]:
+            assert (t == -2).all()
+            continue
+        if not bad[y, x] and case != "random64":
+            continue                                                       # (random64: check EVERY pixel's triangle)
+        assert (t >= 0).all()
+        if t[1] == t[2]:                                                   # on a segment between two sites
+            a, b = P[t[0]], P[t[1]]
+            assert (b[0] - a[0]) * (y - a[1]) == (b[1] - a[1]) * (x - a[0])
+        else:
+            assert oinp.delaunay_triangle_is_valid(P, t, (x, y)), (case, y, x, t)
+        checked += 1
+        if checked > 1500:
+            break
+    if case == "no_corners":
+        assert nan_g.any() and (nan_g & ~nan_w).sum() <= 8                  # NaN set == scipy's up to hull-boundary pixels
+    # through the reference-signature entry points
+    one = pd['ou'].naive_inpainting(T(img), T(m2), method='linear')
+    assert np.array_equal(np.nan_to_num(N_(one), nan=-1), np.nan_to_num(got, nan=-1))
+    views = pd['ou'].get_inpainted_images(T(img[None]), T(m2[None]), T(m2[None]), None, None, 1, method='linear')
+    assert np.array_equal(np.nan_to_num(N_(views)[0], nan=-1), np.nan_to_num(got, nan=-1))
