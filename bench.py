@@ -220,8 +220,10 @@ def main():
         inpainter.model.profile(False)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_conv.json')
-        if os.path.exists(pmc):          # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_conv.json')))
+        pmc = cands[-1] if cands else ''
+        if pmc:          # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh)
             pj = json.load(open(pmc))                 # per-launch bytes depend on the UNet batch: only quoted for the batch it was measured at
             traffic = pj.get('hbm_bytes_per_launch') if pj.get('shapes_per_step', 1) == SPS else None
         roofline = dict(bound="mfma", kernel="k_conv3x3_halo (3x3 conv of the 64^2/128^2/256^2 levels, LDS-resident activation halo, f16 in / f32 acc)", achieved=achieved,

@@ -42,6 +42,7 @@ pp = ou.get_point_pixels(puv, r)
 us, sp = timed(lambda: ou.get_sparse_images(pp, g['colors'], pv2, hard_r, None, V, r, 1, 1, 0.82)); add('P4-P6 sparse views', us, V * r * r * 20)
 sparse, m0, m2, sf = sp
 us, inp = timed(lambda: ou.get_inpainted_images(sparse, m0, m2, None, None, V, method='nearest')); add('I0 nearest inpaint', us, V * r * r * 28)
+us, _ = timed(lambda: ou.get_inpainted_images(sparse, m0, m2, None, None, V, method='linear'), 5); add("I0 linear inpaint (per-pixel Delaunay triangle, f64 integer predicates; VALU-bound)", us, V * r * r * 28)
 us, vis = timed(lambda: up.texel_visibility(cams, g['gb_pos'], g['mask'], uvc, uvs, pad, depth, R)); add('Uq1+Uq2 texel visibility', us, 57 * P)
 pm = g['mask'][0, :, :, 0].contiguous()
 us, shr = timed(lambda: up.shrink_visibility(pm, vis, [21] * 4)); add('N1-N3 NBF shrink (4 levels as the reference)', us, 8 * A * A * V)
@@ -56,6 +57,12 @@ vv, ff, xd = standin_geometry(g['points'], A, dev, logging.getLogger('x'))
 us, oc = timed(lambda: popt.optimize_color(dil.permute(2, 0, 1).flip(1), inp, vv, ff, xd['uvs'], xd['mesh_tex_idx'], cams, None, None, None,
                                            uvc, uvs, pad, sf, None, un[1]), 3)
 add('8f-1 optimize_color (100 Adam iterations, res 1024)', us, 100 * V * 1024 * 1024 * (8 + 12 + 12))
+_, st = hpr.hidden_point_removal(g['points'], eyes, 100, already_valid=pv[0], return_stats=True)
+rows.append(dict(stage='P3b certificate statistics (8 views x 30k points)', **st))
+tot = [r_ for r_ in rows if r_['stage'].split()[0] in ('P1+P2', 'P2b', 'P3', 'P4-P6', 'I0', 'Uq1-Uq4', 'Uq5') and 'linear' not in r_['stage']]
+rows.append(dict(stage='P1-P6 + I0(nearest) + Uq1-Uq5 without P3b: sum', us=round(sum(r_['us'] for r_ in tot), 1),
+                 algorithmic_MB=round(sum(r_['algorithmic_MB'] for r_ in tot), 2),
+                 GBps=round(sum(r_['algorithmic_MB'] for r_ in tot) * 1e3 / sum(r_['us'] for r_ in tot), 1)))
 print(json.dumps(rows, indent=1))
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump(rows, open('gpurun_out/stage_times.json', 'w'), indent=1)
