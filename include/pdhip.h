@@ -16,6 +16,8 @@
  *     message.  Nothing throws across the ABI;
  *   - the library holds no global mutable state; scratch memory is passed in by the caller
  *     (workspace pointers) or lives in an opaque handle created by *_create and freed by *_destroy.
+ *     The pdhip_debug_set_* tuning / test hooks are THREAD-LOCAL switches (they steer the calling thread's
+ *     subsequent launches only), so concurrent callers never see each other's settings.
  *   - camera parameters: 16 float32 per view = R(9, row-major world->camera) t(3) fx fy A B,
  *     NDC = (fx*xc/-zc, fy*yc/-zc, (A*zc+B)/-zc); see DESIGN.md "Arithmetic contract".
  */

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void k_hpr_gjk(const doub
                                                  const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
                                                  const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi,
                                                     const uint8_t* __restrict__ skip, const unsigned long long* __restrict__ maxabs,
-                                                    int* __restrict__ unc_count, int* __restrict__ unc_list) {
+                                                    int* __restrict__ unc_count, int* __restrict__ unc_list, int* __restrict__ unc_seed) {
     __shared__ double s_dir[NW][Q][3];
     __shared__ int s_q[NW][Q];
     __shared__ double s_rv[2][NW][Q];                            // COOP: per-wave partial argmax of the round (double-buffered)
@@ -369,7 +369,12 @@ __global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void k_hpr_gjk(const doub
         if (owner) {
             vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
             if (state == 0 || state == 3)                             // round cap reached / not certifiable: exact fallback
-                unc_list[(size_t)v * N + atomicAdd(&unc_count[v], 1)] = q;
+            {
+                    const int pos = atomicAdd(&unc_count[v], 1);
+                    unc_list[(size_t)v * N + pos] = q;
+                    int* sd = unc_seed + ((size_t)v * N + pos) * 4;          // the simplex it stopped at seeds the fallback
+                    sd[0] = g.dim >= 1 ? g.ic : -2; sd[1] = g.dim >= 2 ? g.ib : -2; sd[2] = g.dim >= 3 ? g.id : -2; sd[3] = -2;
+                }
         }
     } else {
         if (owner) outside[(size_t)v * N + q] = state != 2;           // 0: CERTIFIED enclosed by the coarse hull (hidden, and never a support
@@ -465,7 +470,7 @@ template <typename T> __device__ bool closest_simplex(Simplex<T>& S, v3<T>& v) {
 // double-double support values over the same support set (any superset of the hull vertices), duplicates of the query with a
 // larger cloud index excluded from S_i (of coinciding points the smallest index is the hull vertex), up to 512 rounds.
 __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ flipped, int N, const int* __restrict__ unc_count,
-                                                   const int* __restrict__ unc_list, uint8_t* __restrict__ vis,
+                                                   const int* __restrict__ unc_list, const int* __restrict__ unc_seed, uint8_t* __restrict__ vis,
                                                    const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
                                                    const int* __restrict__ scount, const unsigned long long* __restrict__ maxabs,
                                                    int* __restrict__ counters /*[V][4]: exact queries, unresolved, rounds, -*/) {
@@ -489,6 +494,24 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
         v3<dd> vclose = dir;
         int state = 0;                  // 0 running, 1 visible (certified), 2 hidden (certified), 3 not certifiable
         int rounds = 0;
+        {   // seed: the vertices the f64 iteration stopped at (cloud indices, -1 = the eye) -- its closest point is the start
+            const int* sd = unc_seed + ((size_t)v * N + u) * 4;
+            const double* cx = flipped + (size_t)v * 3 * N;
+            for (int k = 0; k < 3; ++k) {
+                const int id = sd[k];
+                if (id == -2 || id == q) continue;
+                bool dup = false;
+                for (int m = 0; m < S.n; ++m) dup = dup || S.idx[m] == id;
+                if (dup) continue;
+                v3<dd> a = id >= 0 ? v3<dd>{dd_diff(cx[id], px), dd_diff(cx[N + id], py), dd_diff(cx[2 * (size_t)N + id], pz)}
+                                   : v3<dd>{dd_from(-px), dd_from(-py), dd_from(-pz)};
+                if (zero3(a)) continue;
+                for (int m = S.n; m > 0; --m) { S.w[m] = S.w[m - 1]; S.idx[m] = S.idx[m - 1]; }
+                S.w[0] = a; S.idx[0] = id; ++S.n;
+            }
+            if (S.n > 0 && closest_simplex(S, vclose) && !zero3(vclose)) dir = neg(vclose);
+            else { S.n = 0; vclose = dir; }
+        }
         for (; rounds < 512 && state == 0; ++rounds) {
             // support scan in double-double: (dx x + dy y) + dz z with exact inputs x, y, z
             dd best = {-1.0e300, 0.0};
@@ -692,7 +715,7 @@ static size_t flipped_bytes(int V, int N) { return a256((size_t)V * 3 * (size_t)
 static size_t lists_bytes(int V, int N) { return a256((size_t)V * ((size_t)N + 64) * sizeof(int)); }
 #define HPR_HEAD_BYTES 2048      // workspace head: counters int[64][4] (exact-fallback queries, unresolved, rounds, -) + maxabs u64[64]
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
-    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 4 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * 3 * HPR_KC * sizeof(double)) +
+    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 8 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * 3 * HPR_KC * sizeof(double)) +
            a256((size_t)V * HPR_KC * sizeof(int));
 }
 
@@ -717,6 +740,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     int* count2 = reinterpret_cast<int*>(p); int* list2 = count2 + 64; p += lists_bytes(V, N);
     int* scount = reinterpret_cast<int*>(p); int* sidx = scount + 64; p += lists_bytes(V, N);
     int* ucount = reinterpret_cast<int*>(p); int* ulist = ucount + 64; p += lists_bytes(V, N);      // queries for the exact fallback
+    int* useed = reinterpret_cast<int*>(p); p += 4 * lists_bytes(V, N);                               // ... and the simplex each stopped at
     uint8_t* outside = reinterpret_cast<uint8_t*>(p); p += a256((size_t)V * N);
     double* cs = reinterpret_cast<double*>(p); p += a256((size_t)V * 3 * HPR_KC * sizeof(double));
     int* cidx = reinterpret_cast<int*>(p);
@@ -734,17 +758,17 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
         dim3 ge(cdiv(KC, QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
         k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, cs, cidx, outside);
-        k_hpr_gjk<true, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip, maxabs, nullptr, nullptr);
+        k_hpr_gjk<true, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip, maxabs, nullptr, nullptr, nullptr);
         k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
-        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist);
-        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist);
-        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, visibility, ss, sidx, N, scount, maxabs, counters);
+        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist, useed);
+        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist, useed);
+        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, maxabs, counters);
     } else {                         // one level: support set = the whole cloud
         k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
         k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
-        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist);
-        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist);
-        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, visibility, flipped, sidx, N, scount, maxabs, counters);
+        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist, useed);
+        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist, useed);
+        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, flipped, sidx, N, scount, maxabs, counters);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

@@ -25,9 +25,9 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
 // fixed-order sum of split-K partials [splits][M][Cout] f32 + bias (+ residual) -> f16 Y, optional GroupNorm octet partials
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
-extern int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
-extern int g_fuse_gn;                                                   // tuning hook (nn_unet.hip)
-extern float* g_dbg_splitk_ws; extern size_t g_dbg_splitk_floats;
+extern thread_local int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
+extern thread_local int g_fuse_gn;                                                   // tuning hook (nn_unet.hip)
+extern thread_local float* g_dbg_splitk_ws; extern thread_local size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
                float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr,

@@ -18,7 +18,7 @@
 #include "nn_common.h"
 using namespace pdhip;
 namespace pdnn {
-int g_halo_strips = 0;                                    // tuning / test hook (pdhip_debug_set_conv_halo_strips)
+thread_local int g_halo_strips = 0;                                    // tuning / test hook (pdhip_debug_set_conv_halo_strips)
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_h;

@@ -531,11 +531,11 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     }
 }
 
-int g_force_bk = 0;       // tuning hook: 32 / 64 forces the K-step, 0 = automatic
-int g_force_stages = 0;   // tuning hook: 2 / 3 / 4 LDS stages, 0 = automatic
-int g_force_splits = 0;   // tuning hook: >= 1 forces the split-K factor, 0 = automatic
-float* g_dbg_splitk_ws = nullptr; size_t g_dbg_splitk_floats = 0;   // split-K workspace for the stand-alone conv entry point
-int g_force_wmw = 0;      // tuning hook, tile geometry: 2 = 128x128/4 waves, 4 = 256x128/8 waves, 8 = 256x256/8 waves, 0 = automatic
+thread_local int g_force_bk = 0;       // tuning hook: 32 / 64 forces the K-step, 0 = automatic
+thread_local int g_force_stages = 0;   // tuning hook: 2 / 3 / 4 LDS stages, 0 = automatic
+thread_local int g_force_splits = 0;   // tuning hook: >= 1 forces the split-K factor, 0 = automatic
+thread_local float* g_dbg_splitk_ws = nullptr; thread_local size_t g_dbg_splitk_floats = 0;   // split-K workspace for the stand-alone conv entry point
+thread_local int g_force_wmw = 0;      // tuning hook, tile geometry: 2 = 128x128/4 waves, 4 = 256x128/8 waves, 8 = 256x256/8 waves, 0 = automatic
 
 template <int TAPS, int BKT, int NSTAGE, int WM, int WN, int TM>
 static int launch_conv(dim3 grid, size_t smem, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias,

@@ -33,7 +33,7 @@ struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chun
 // transform removes 9.4 ms of gn_apply per batch-32 forward but costs the halo conv 23 % (tools/bench_conv.py --apply, lab builds:
 // fetch of the staged pieces -4.5 %, the in-place ds_write_b128 -10 % -- a store occupies the SIMD's LDS path for 13 cycles in
 // front of the fragment reads the MFMAs wait for -- arithmetic -8 %): 76.2 vs 71.4 ms per DDNM step at batch 32.
-namespace pdnn { int g_fuse_gn = 0; }
+namespace pdnn { thread_local int g_fuse_gn = 0; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 

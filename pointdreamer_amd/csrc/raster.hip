@@ -275,7 +275,7 @@ __global__ void k_raster_resolve(const uint64_t* __restrict__ zkey, long long n,
     }
 }
 
-static int g_raster_path = 0;                    // 0 automatic, 1 force the global-atomic fallback
+static thread_local int g_raster_path = 0;                    // 0 automatic, 1 force the global-atomic fallback
 extern "C" int pdhip_debug_set_raster_path(int path) { int old = g_raster_path; g_raster_path = path; return old; }
 
 extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t* faces, int F, int R,

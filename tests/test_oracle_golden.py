@@ -190,3 +190,54 @@ def test_o1_shrink_triptychs_vs_reference_pngs():
     ks = [int(k) for k in g['kernels']]
     assert np.array_equal(onbf.shrink_visibility(g['mask'], g['vis'], ks), g['ref_shrinked'])
     assert np.array_equal(onbf.shrink_triptychs(g['mask'], g['vis'], ks), g['ref_pngs'])
+
+
+def test_c0_camera_hand_computed_cases():
+    """kaolin is absent (C0 parity unpinned): pin the oracle's restatement of its documented pinhole / OpenGL-NDC convention
+    (kaolin 0.15 `Camera.from_args(eye, at, up, fov=pi/4, near=1e-2, far=1e2)`) with values computed by hand, independent of the
+    code under test: x_ndc = f x_c / -z_c with f = 1 / tan(fov / 2), z_ndc = -1 at the near plane, +1 at the far plane,
+    increasing with distance; row/column orientation: +x right, +y up in NDC."""
+    import math
+    cam = ocam.Camera(ocam.camera_params(np.array([0.0, 0.0, 1.6]), np.zeros(3), np.array([0.0, 1.0, 0.0])), 512)
+    f = 1.0 / math.tan(math.pi / 8)
+    pts = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.25, 0], [0, 0, 1.6 - 1e-2], [0, 0, 1.6 - 1e2], [0.3, -0.2, 0.4]], np.float32)
+    got = cam.transform(pts).astype(np.float64)
+    n, fa = 1e-2, 1e2
+    zndc = lambda d: ((fa + n) / (fa - n) * d - 2 * fa * n / (fa - n)) / d          # d = distance along the view axis
+    want = np.array([[0, 0, zndc(1.6)], [f * 0.5 / 1.6, 0, zndc(1.6)], [0, f * 0.25 / 1.6, zndc(1.6)], [0, 0, -1.0], [0, 0, 1.0],
+                     [f * 0.3 / 1.2, f * -0.2 / 1.2, zndc(1.2)]])
+    assert np.allclose(got, want, atol=2e-6), (got, want)
+    assert abs(zndc(1.6) - 0.98769877) < 1e-6                                         # (1.0002 * 1.6 - 0.020002) / 1.6
+    # a camera off the axis: the look-at rotation keeps the target in the image centre and `up` upright
+    eye = np.array([1.0, 0.8, -0.6]) * (1.6 / np.linalg.norm([1.0, 0.8, -0.6]))
+    cam2 = ocam.Camera(ocam.camera_params(eye, np.zeros(3), ocam.calculate_up_vector(eye, np.zeros(3))), 512)
+    c = cam2.transform(np.array([[0, 0, 0], [0, 0.1, 0]], np.float32))
+    assert np.allclose(c[0, :2], 0, atol=1e-6) and abs(c[1, 0]) < 1e-6 and c[1, 1] > 0
+
+
+def test_p2_raster_hand_computed_cases():
+    """nvdiffrast is absent (P2 parity unpinned): pin the documented contract with cases small enough to do by hand --
+    pixel (row i, col j) samples NDC ((j + 0.5) / R * 2 - 1, (i + 0.5) / R * 2 - 1) (row 0 = y -1), a pixel centre exactly on a
+    shared edge belongs to exactly one of the two triangles, depth = barycentric z, nearest z wins, output face id / depth 0
+    where empty."""
+    R = 4
+    # one triangle covering the lower-left half of the square [-1, 1]^2 (vertices at NDC corners), z = 0.25 everywhere
+    pos = np.array([[[-1, -1, 0.25, 1], [1, -1, 0.25, 1], [-1, 1, 0.25, 1], [1, 1, 0.75, 1]]], np.float32)
+    hard, fid, depth = oproj.rasterize(pos, np.array([[0, 1, 2]]), R)
+    cx = (np.arange(R) + 0.5) / R * 2 - 1
+    inside = (cx[None, :] + cx[:, None]) < 0                                        # x + y < 0 strictly below the diagonal
+    on = np.isclose(cx[None, :] + cx[:, None], 0)
+    assert np.array_equal(hard[0] & ~on, inside & ~on)                               # (the diagonal's own pixels: tie rule, next)
+    assert np.allclose(depth[0][hard[0]], 0.25) and (depth[0][~hard[0]] == 0).all() and (fid[0][~hard[0]] == -1).all()
+    # both halves: every pixel covered exactly once, the diagonal's pixel centres go to one triangle only (watertight)
+    hard2, fid2, depth2 = oproj.rasterize(pos, np.array([[0, 1, 2], [1, 3, 2]]), R)
+    assert hard2.all() and set(np.unique(fid2)) == {0, 1}
+    assert np.array_equal(fid2[0][inside & ~on], np.zeros(int((inside & ~on).sum()), fid2.dtype))
+    # second triangle's depth is the plane through z = 0.25, 0.75, 0.25 at its corners: z = 0.25 + 0.25 (x + y) on x + y >= 0
+    yy, xx = np.meshgrid(cx, cx, indexing='ij')
+    m = fid2[0] == 1
+    assert np.allclose(depth2[0][m], 0.25 + 0.25 * (xx + yy)[m], atol=1e-6)
+    # a nearer triangle in front wins the depth test
+    pos3 = np.concatenate([pos[0], np.array([[-1, -1, -0.5, 1], [1, -1, -0.5, 1], [-1, 1, -0.5, 1]], np.float32)])[None]
+    _, fid3, depth3 = oproj.rasterize(pos3, np.array([[0, 1, 2], [1, 3, 2], [4, 5, 6]]), R)
+    assert (fid3[0][inside & ~on] == 2).all() and np.allclose(depth3[0][inside & ~on], -0.5)

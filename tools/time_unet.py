@@ -8,7 +8,7 @@ import pointdreamer_amd.ddnm_inpainting as di
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='*', default=[1, 2, 4, 8, 32])
 ap.add_argument('--iters', type=int, default=10)
-ap.add_argument('--fuse', type=int, default=1, help='pdhip_debug_set_fuse_gn')
+ap.add_argument('--fuse', type=int, default=0, help='pdhip_debug_set_fuse_gn')
 ap.add_argument('--sampler-steps', type=int, default=10, help='also time this many DDNM steps through pdhip_ddnm_sample (0 = skip)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -30,7 +30,7 @@ for N in a.batches:
         m(x, t)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
-    row = dict(batch=N, forward_ms=round(ms, 3), ms_per_image=round(ms / N, 3), tflops_effective=round(2.2397 * N / ms, 1))
+    row = dict(batch=N, forward_ms=round(ms, 3), ms_per_image=round(ms / N, 3), tflops_effective=round(2239.7 * N / ms, 1))
     if a.sampler_steps:
         inp = di.Inpainter.__new__(di.Inpainter)
         inp.device, inp.model, inp.seed, inp.n_steps, inp._images, inp.max_batch = dev, m, 1234, a.sampler_steps, 0, N
