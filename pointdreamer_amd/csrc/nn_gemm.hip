@@ -486,16 +486,28 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
         for (int j = 0; j < SK_ROWS / 4; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[j][e] = 0.f;
-        for (int sp = 0; sp < splits; ++sp) {
+        // four splits' loads in flight per row (the sum order stays sp = 0, 1, 2, ...: deterministic); one split at a time was a
+        // chain of L2 round trips -- 10-14 us per launch at batch 1, where 68 of these run per forward
+        for (int sp0 = 0; sp0 < splits; sp0 += 4) {
 #pragma unroll
             for (int j = 0; j < SK_ROWS / 4; ++j) {
                 const long long m = m0 + q + 4 * j;
                 if (m < M) {
-                    const float* src = partial + (size_t)sp * MC + (size_t)m * Cout + (size_t)oct * 8;
-                    const float4 v0 = *reinterpret_cast<const float4*>(src);
-                    const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-                    a[j][0] += v0.x; a[j][1] += v0.y; a[j][2] += v0.z; a[j][3] += v0.w;
-                    a[j][4] += v1.x; a[j][5] += v1.y; a[j][6] += v1.z; a[j][7] += v1.w;
+                    float4 v0[4], v1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int sp = min(sp0 + u, splits - 1);
+                        const float* src = partial + (size_t)sp * MC + (size_t)m * Cout + (size_t)oct * 8;
+                        v0[u] = *reinterpret_cast<const float4*>(src);
+                        v1[u] = *reinterpret_cast<const float4*>(src + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (sp0 + u < splits) {
+                            a[j][0] += v0[u].x; a[j][1] += v0[u].y; a[j][2] += v0[u].z; a[j][3] += v0[u].w;
+                            a[j][4] += v1[u].x; a[j][5] += v1[u].y; a[j][6] += v1[u].z; a[j][7] += v1[u].w;
+                        }
+                    }
                 }
             }
         }
@@ -598,7 +610,12 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const int KI = taps * (Cin / bk);
     int splits = 1;
     if (splitk_ws != nullptr && taps == 9 && total <= 256) {
-        splits = std::min(std::min((512 + total / 2) / total, KI / 2), 8);
+        // up to 8 splits in general; tiny-M layers (the 8x8 / 16x16 levels at batch 1-2: 8-16 tiles, a weight stream of 19-38 MB
+        // per conv) go on splitting while the f32 partials stay small (<= 8 MB: L2-resident), up to 32 -- measured at batch 1
+        // (tools/time_unet.py): 22-24 us -> see DESIGN section 8
+        int cap = 8;
+        while (cap < 32 && total * cap < 256 && (size_t)(2 * cap) * M * Cout * sizeof(float) <= (size_t)8 << 20) cap *= 2;
+        splits = std::min(std::min((512 + total / 2) / total, KI / 2), cap);
         while (splits > 1 && (size_t)splits * M * Cout > splitk_ws_floats) --splits;
     }
     if (g_force_splits >= 1 && splitk_ws != nullptr)
