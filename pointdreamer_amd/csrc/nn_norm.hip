@@ -182,10 +182,16 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
     const int opp = C >> 3, cg = C / 32;
     const int pps = max(1, 256 / opp);
     const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
-    const int n = blockIdx.y;
+    // (lab: descending image / chunk order so that the pass starts on what the producing conv wrote last and ends on what the
+    // consuming conv reads first -- measured 1 % slower per DDNM step than the plain order; PD_LAB_GN_REV)
+#ifdef PD_LAB_GN_REV
+    const int n = gridDim.y - 1 - blockIdx.y, bx = gridDim.x - 1 - blockIdx.x;
+#else
+    const int n = blockIdx.y, bx = blockIdx.x;
+#endif
     const int sub = threadIdx.x / opp;
     if (sub >= pps) return;
-    const int p_begin = blockIdx.x * (pps * iters), p_end = min(Ho * Wo, p_begin + pps * iters);
+    const int p_begin = bx * (pps * iters), p_end = min(Ho * Wo, p_begin + pps * iters);
     for (int oc = threadIdx.x - sub * opp; oc < opp; oc += 256) {
         const int c0 = oc * 8;
         // input of a never-materialised channel concat: channels [0, Ca) live in X (pixel stride Ca), the rest in XB
@@ -241,7 +247,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
                 half8 hv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) hv[e] = (half_t)r[e];
+                // (a streaming / nontemporal store makes this pass 10-14 % faster on its own -- tools/bench_gn.py -- and the DDNM step
+                // 3.6 % SLOWER: the conv that consumes the tensor then misses the part of it the caches would have kept)
+#ifdef PD_LAB_GN_NT
+                __builtin_nontemporal_store(hv, reinterpret_cast<half8*>(reinterpret_cast<half_t*>(Yv) + o));
+#else
                 *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(Yv) + o) = hv;
+#endif
             }
         };
         if (RES == 0) {
@@ -250,7 +262,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
             for (; p + 3 * pps < p_end; p += 4 * pps) {
                 half8 v[4];
 #pragma unroll
+#ifdef PD_LAB_GN_NTL                                       // (lab builds only: streaming loads -- no effect on the step)
+                for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs));
+#else
                 for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs);
+#endif
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { float r[8]; finish(v[u], r); store(p + u * pps, r); }
             }

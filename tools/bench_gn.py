@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pointdreamer_amd import _lib
 import pointdreamer_amd.ddnm_inpainting  # noqa
+if len(sys.argv) > 1: _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 L = _lib.lib()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 dev = 'cuda:0'
