@@ -312,7 +312,7 @@ def _free_port():
     return p
 
 
-def _vp_worker(rank, world, port, outdir, method):
+def _vp_worker(rank, world, port, outdir, method, full=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -325,8 +325,9 @@ def _vp_worker(rank, world, port, outdir, method):
         inputs = torch.load(os.path.join(outdir, 'inputs.pt'))
         dev = torch.device('cuda', 0)
         g = {k: v.to(dev) for k, v in inputs.items()}
-        verts, faces, xd = demo._standin_geometry(256, dev)
-        cams, base_dirs, eyes, ups = cu.create_cameras(5, 1.6, 128, device=dev)
+        A_, V_, R_, r_ = (1024, 8, 512, 256) if full else (256, 5, 128, 64)
+        verts, faces, xd = demo._standin_geometry(A_, dev)
+        cams, base_dirs, eyes, ups = cu.create_cameras(V_, 1.6, R_, device=dev)
         ci = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
         fn = torch.from_numpy(synthetic.face_normals(verts.cpu().numpy(), faces.cpu().numpy())).to(dev)
         inpainter = None
@@ -344,7 +345,7 @@ def _vp_worker(rank, world, port, outdir, method):
             return orig(local.cpu(), n_views, rank_, world_, group).to(local.device)
         pdist.all_gather_views = gather_via_host
         atlas = pdist.colorize_one_mesh_view_parallel(
-            g['xyz'], g['rgb'], verts, faces, fn, xd, ci, 5, 64, 128, rank, world, inpainter=inpainter, texture_gen_method=method,
+            g['xyz'], g['rgb'], verts, faces, fn, xd, ci, V_, r_, R_, rank, world, inpainter=inpainter, texture_gen_method=method,
             complete_unseen_by='neighbor', optimize_from='ours' if method == 'nearest' else None,
             save_img_path=os.path.join(outdir, 'others'), shape_key=0)
         from pointdreamer_amd import io_utils
@@ -354,7 +355,7 @@ def _vp_worker(rank, world, port, outdir, method):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method", ["nearest", "DDNM_inpaint"])
+@pytest.mark.parametrize("method", ["nearest", "DDNM_inpaint", "nearest-full"])
 def test_view_parallel_two_ranks_real_hip_stages(pd, tmp_path, method):
     """SURVEY 8e with the TRUE stages: two processes (gloo, both on cuda:0) split the 5 views 3 + 2; each rank projects,
     inpaints and computes texel visibility / NBF for its views only, one all_gather of the packed per-view records, the blend
@@ -363,10 +364,13 @@ def test_view_parallel_two_ranks_real_hip_stages(pd, tmp_path, method):
     different batch sizes, hence the U1 tolerance), and the per-view files carry global view indices."""
     import torch.multiprocessing as mp
     from pointdreamer_amd import pipeline, synthetic, demo
-    xyz, rgb = synthetic.sphere_points(6000, seed=31)
+    full = method.endswith('-full')                       # BASELINE configs[3] sizes: 30k points, 8 x 256^2 views, atlas 1024 (4 + 4)
+    method = method.split('-')[0]
+    A_, V_, R_, r_ = (1024, 8, 512, 256) if full else (256, 5, 128, 64)
+    xyz, rgb = synthetic.sphere_points(30000 if full else 6000, seed=31)
     torch.save(dict(xyz=torch.from_numpy(xyz), rgb=torch.from_numpy(rgb)), str(tmp_path / 'inputs.pt'))
-    verts, faces, xd = demo._standin_geometry(256, DEV)
-    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(5, 1.6, 128, device=DEV)
+    verts, faces, xd = demo._standin_geometry(A_, DEV)
+    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(V_, 1.6, R_, device=DEV)
     ci = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
     fn = T(synthetic.face_normals(N_(verts), N_(faces)))
     inpainter = None
@@ -377,17 +381,56 @@ def test_view_parallel_two_ranks_real_hip_stages(pd, tmp_path, method):
         inpainter = di.Inpainter(DEV, ckpt_path=None, model_kwargs=dict(image_size=64, num_channels=32, num_head_channels=32),
                                  max_batch=5, state_dict=w, seed=5)
         inpainter.n_steps = 3
-    ref = pipeline.colorize_one_mesh(T(xyz), T(rgb), verts, faces, fn, xd, ci, view_num=5, res=64, cam_res=128, inpainter=inpainter,
+    ref = pipeline.colorize_one_mesh(T(xyz), T(rgb), verts, faces, fn, xd, ci, view_num=V_, res=r_, cam_res=R_, inpainter=inpainter,
                                      texture_gen_method=method, complete_unseen_by='neighbor',
                                      optimize_from='ours' if method == 'nearest' else None)[4].cpu()
-    mp.spawn(_vp_worker, args=(2, _free_port(), str(tmp_path), method), nprocs=2, join=True)
+    mp.spawn(_vp_worker, args=(2, _free_port(), str(tmp_path), method, full), nprocs=2, join=True)
     a0, a1 = torch.load(str(tmp_path / 'atlas_0.pt')), torch.load(str(tmp_path / 'atlas_1.pt'))
     assert torch.equal(a0, a1), "every rank holds the same atlas"
     if method == 'nearest':
         assert torch.equal(a0, ref), "view-parallel result must equal the single-process result"
     else:
         assert (a0 - ref).abs().max().item() < 3e-2
-    for k in range(5):
+    for k in range(V_):
         for s in ('sparse', 'mask0', 'mask2', 'inpainted'):
             assert os.path.exists(str(tmp_path / 'others' / f'{k}_{s}.png')), (k, s)
         assert os.path.exists(str(tmp_path / 'others' / 'shrink_per_view_edge' / f'{k}.png'))
+
+
+# ---------------------------------------------------------------------------------------------- configs[4]: 8 shapes per GPU
+def test_config4_eight_full_size_shapes_per_gpu(pd):
+    """BASELINE configs[4] as one GPU sees it: 8 independent 30k-point shapes (8 x 256^2 views each, atlas 1024) textured in one
+    pass -- 64 views through the full 552.8 M-parameter UNet in ONE batch (max_batch 64).  'nearest': every atlas bit-identical
+    to colorize_one_mesh shape by shape; DDNM (3 steps, keyed noise): each shape's inpainted views within the U1 tolerance of
+    the same shape sampled alone at batch 8, and the atlas index rows identical."""
+    import pointdreamer_amd.ddnm_inpainting as di
+    from pointdreamer_amd import pipeline
+    syn = pd['syn']
+    V, RES, CAM, A, S = 8, 256, 512, 1024, 8
+    base = syn.make_shape(30000, A, seed=0)
+    g = {k: T(v) for k, v in base.items()}
+    cams, base_dirs, eyes, ups = pd['cu'].create_cameras(V, 1.6, CAM, device=DEV)
+    ci = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    xat = dict(gb_pos=g['gb_pos'], mask=g['mask'], per_atlas_pixel_face_id=g['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
+    clouds = [syn.sphere_points(30000, seed=100 + k) for k in range(S)]
+    shapes = [dict(coords=T(x), colors=T(c), vertices=g['vertices'], faces=g['faces'], f_normals=g['f_normals'], xatlas=xat) for x, c in clouds]
+    kw = dict(view_num=V, res=RES, cam_res=CAM, point_validation_by_o3d=True, point_size=1, edge_point_size=1, crop_img=True,
+              crop_padding=0.05, mask_ratio_thresh=0.82, edge_dilate_kernels=[21])
+    got = pipeline.colorize_meshes_batched(shapes, ci, texture_gen_method='nearest', **kw)
+    for sh, atlas in zip(shapes[:3] + shapes[-1:], got[:3] + got[-1:]):
+        one = pipeline.colorize_one_mesh(sh['coords'], sh['colors'], sh['vertices'], sh['faces'], sh['f_normals'], xat, ci,
+                                         texture_gen_method='nearest', complete_unseen_by='unproject', optimize_from=None, **kw)[4]
+        assert torch.equal(atlas, one)
+    # DDNM: one UNet batch of 64 views
+    inp = di.Inpainter(DEV, ckpt_path=None, allow_random_weights=True, max_batch=V * S, seed=9)
+    inp.n_steps = 3
+    pres = [pipeline._before_inpaint(sh['coords'], sh['colors'], sh['vertices'], sh['faces'], ci, V, RES, CAM, None, True, 100, 1, 1,
+                                     True, 0.05, 0.82) for sh in shapes]
+    cat = lambda k: torch.cat([p[k] for p in pres], 0).contiguous()
+    all64 = pd['ou'].get_inpainted_images(cat('sparse'), cat('mask0'), cat('mask2'), None, inp, V * S, method='DDNM_inpaint')
+    assert all64.shape == (V * S, 3, RES, RES) and inp._images == V * S
+    for k in (0, 5, 7):
+        alone = pd['ou'].get_inpainted_images(pres[k]['sparse'], pres[k]['mask0'], pres[k]['mask2'], None, inp, V, method='DDNM_inpaint',
+                                              first_key=k * V, advance=0)
+        d = (all64[k * V:(k + 1) * V] - alone).abs()
+        assert d.max().item() < 3e-2 and d.mean().item() < 2e-3, (k, d.max().item(), d.mean().item())
