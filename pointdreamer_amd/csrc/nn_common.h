@@ -21,18 +21,19 @@ bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
 // apply_table != NULL: the input is silu(A x + B) of X per gn_table (zero padding applies to the TRANSFORMED image)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
                  int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
-                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table = nullptr);
+                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table = nullptr, int res_up = 0);   // res_up: residual = half-resolution tensor, nearest x2 on the fly
 // fixed-order sum of split-K partials [splits][M][Cout] f32 + bias (+ residual) -> f16 Y, optional GroupNorm octet partials
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
 extern thread_local int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
-extern thread_local int g_fuse_gn;                                                   // tuning hook (nn_unet.hip)
+extern thread_local int g_fuse_gn, g_fold_resample;                                                   // tuning hook (nn_unet.hip)
 extern thread_local float* g_dbg_splitk_ws; extern thread_local size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
                float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr,
                const half_t* X2 = nullptr, int Cin1 = 0,    // X2: second tensor of a never-materialised channel concat (1x1 only)
-               const float* apply_table = nullptr);         // input = silu(A x + B) per gn_table (layers the halo kernel takes only)
+               const float* apply_table = nullptr,          // input = silu(A x + B) per gn_table (layers the halo kernel takes only)
+               int res_up = 0);                             // residual = half-resolution tensor read with nearest x2 (unsplit halo layers only)
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
 // the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).
 int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,
@@ -45,7 +46,8 @@ int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, flo
 // film: rows of (scale[C] | shift[C]) f32, row n at film + n*film_stride, or null.  Output f16 NHWC (or f32 when out_f32).
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
-             const half_t* XB = nullptr, int Ca = 0);     // XB: second tensor of a never-materialised channel concat
+             const half_t* XB = nullptr, int Ca = 0,      // XB: second tensor of a never-materialised channel concat
+             half_t* Yraw = nullptr);                     // resample 1 only: also AvgPool2d(2) of the RAW input (the x branch of a down-ResBlock)
 // GroupNorm (+ FiLM) as one affine map per (image, channel): table [N][C/8][16] = (A0..A7, B0..B7) per channel octet, y = silu(A x + B) -- the
 // input transform of the APPLY variant of the halo conv (the stand-alone gn_apply pass disappears)
 int gn_table(const float* stats, const float* gamma, const float* beta, const float* film, long long film_stride, int N, int C,

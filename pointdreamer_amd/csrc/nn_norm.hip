@@ -178,7 +178,8 @@ template <int RES, bool OUT_F32, bool FILM>
 __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ film, long long film_stride, int H, int W,
-                                                  int C, int silu, void* __restrict__ Yv, const half_t* __restrict__ XB, int Ca, int iters) {
+                                                  int C, int silu, void* __restrict__ Yv, const half_t* __restrict__ XB, int Ca, int iters,
+                                                  half_t* __restrict__ Yraw) {
     const int opp = C >> 3, cg = C / 32;
     const int pps = max(1, 256 / opp);
     const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
@@ -210,8 +211,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
                 sh[e] = (float)(half_t)film[(size_t)n * film_stride + C + c];
             }
         }
+        float raw[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[e] = 0.f;
         auto act = [&](int yi, int xi, float* o) {
             const half8 v = *reinterpret_cast<const half8*>(Xs + (((size_t)n * H + yi) * W + xi) * cs);
+            if (RES == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) raw[e] += (float)v[e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float f = (float)v[e] * ga[e] + gb[e];
@@ -283,6 +291,14 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
                     act(2 * yo, 2 * xo, a); act(2 * yo, 2 * xo + 1, b); act(2 * yo + 1, 2 * xo, c); act(2 * yo + 1, 2 * xo + 1, d);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) r[e] = (a[e] + b[e] + c[e] + d[e]) * 0.25f;
+                    if (Yraw != nullptr) {                 // the block's x branch: AvgPool2d(2) of the raw input, same pixels, same sum order as k_resample
+                        half8 hv;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { hv[e] = (half_t)(raw[e] * 0.25f); }
+                        *reinterpret_cast<half8*>(Yraw + ((size_t)n * Ho * Wo + p) * C + c0) = hv;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) raw[e] = 0.f;
                 } else {
                     act(yo >> 1, xo >> 1, r);
                 }
@@ -294,7 +310,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
 
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
-             const half_t* XB, int Ca) {
+             const half_t* XB, int Ca, half_t* Yraw) {
+    PD_REQUIRE(Yraw == nullptr || (resample == 1 && XB == nullptr), "gn_apply: the raw avg-pool output belongs to resample 1");
     PD_REQUIRE(XB == nullptr || (Ca > 0 && Ca < C && Ca % 8 == 0), "gn_apply: bad two-source split");
     PD_REQUIRE(C % 32 == 0 && resample >= 0 && resample <= 2, "gn_apply: bad arguments");
     PD_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avgpool needs even H, W");
@@ -307,11 +324,11 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     int iters = GNA_ITERS;
     while (iters > 1 && (long long)cdiv((long long)Ho * Wo, pps * iters) * N < 2048) iters >>= 1;
     dim3 grid(cdiv((long long)Ho * Wo, pps * iters), N);
-    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
-    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
-    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
-    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
-    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters);
+    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
+    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
+    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
+    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
+    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -34,6 +34,10 @@ struct Act { half_t* p; int C, H, W; const float* gn_part = nullptr; int gn_chun
 // fetch of the staged pieces -4.5 %, the in-place ds_write_b128 -10 % -- a store occupies the SIMD's LDS path for 13 cycles in
 // front of the fragment reads the MFMAs wait for -- arithmetic -8 %): 76.2 vs 71.4 ms per DDNM step at batch 32.
 namespace pdnn { thread_local int g_fuse_gn = 0; }
+// tuning / test hook (pdhip_debug_set_fold_resample): 1 (default) = the x branch of up / down ResBlocks is never materialised by a
+// k_resample pass: AvgPool2d(2) of the raw input comes out of the GroupNorm-apply kernel that reads the same pixels anyway, the
+// nearest x2 copy is replaced by index arithmetic in the residual read of the consuming conv (unsplit halo layers)
+namespace pdnn { thread_local int g_fold_resample = 1; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
@@ -169,7 +173,7 @@ int prof_end(Ctx& c) {
 }
 
 int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false,
-             const float* apply_table = nullptr) {
+             const float* apply_table = nullptr, int res_up = 0) {
     *out = Act{nullptr, w.cout, x.H, x.W};
     out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
     // octet partials: [N][chunks][cout/8][2] floats, chunks <= HW/16 (split-K reduce) -- sized for the finest chunking
@@ -182,7 +186,7 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
     int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
-                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0, apply_table);
+                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0, apply_table, res_up);
     if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = w.cout; }
     if (prof) PD_TRY(prof_end(c));
     return rc;
@@ -196,7 +200,8 @@ int run_gn_stats(Ctx& c, const Act& x) {
     return gn_stats(x.p, c.N, x.H * x.W, x.C, 1e-5f, c.u->stats, c.u->gn_ws, c.u->gn_ws_floats, c.s);
 }
 
-int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, int silu, int resample, Act* out) {
+int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, int silu, int resample, Act* out,
+           half_t* raw_pool = nullptr) {
     *out = Act{nullptr, x.C, 0, 0};
     out->H = resample == 1 ? x.H / 2 : (resample == 2 ? x.H * 2 : x.H);
     out->W = resample == 1 ? x.W / 2 : (resample == 2 ? x.W * 2 : x.W);
@@ -204,7 +209,8 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
     PD_TRY(run_gn_stats(c, x));
-    return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2, x.p2 ? x.Ca : 0);
+    return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2, x.p2 ? x.Ca : 0,
+                    raw_pool);
 }
 
 // GroupNorm (+ FiLM) + SiLU of x folded into the conv that consumes it (the halo-resident kernel transforms its input tile in LDS,
@@ -216,35 +222,42 @@ bool can_fuse_gn(const Ctx& c, const Act& x, const ConvW& w) {
     return conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats);
 }
 int run_gn_conv(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, const ConvW& w,
-                const half_t* residual, Act* out) {
+                const half_t* residual, Act* out, int res_up = 0) {
     if (!c.dry) {
         PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
         PD_TRY(run_gn_stats(c, x));
         PD_TRY(gn_table(c.u->stats, n.g, n.b, film, film_stride, c.N, x.C, c.u->ap_table, c.s));
     }
-    return run_conv(c, x, w, residual, out, true, c.dry ? nullptr : c.u->ap_table);
+    return run_conv(c, x, w, residual, out, true, c.dry ? nullptr : c.u->ap_table, res_up);
 }
 
 int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     Act h0, h1, h2, xr = x, sk;
     const float* film = c.dry ? nullptr : c.film_base + rb.emb_off;
     if (!c.dry) PD_REQUIRE(rb.have_ew && rb.have_eb, "unet: emb_layers of %s not loaded", rb.name.c_str());
+    const int Ho = rb.mode == 1 ? x.H / 2 : (rb.mode == 2 ? x.H * 2 : x.H), Wo = rb.mode == 1 ? x.W / 2 : (rb.mode == 2 ? x.W * 2 : x.W);
+    // x branch of an up / down block (unet.py:190-195, 237-242: h and x go through the same Upsample / Downsample)
+    const bool fold = g_fold_resample != 0 && !c.dry && x.p2 == nullptr && !rb.has_skip;
+    const bool fold_down = fold && rb.mode == 1;                     // AvgPool2d(2)(x): second output of the GroupNorm-apply pass
+    const bool fold_up = fold && rb.mode == 2 && Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&      // nearest x2: index arithmetic in conv2's
+                         conv_uses_halo(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) &&   // residual read
+                         conv3x3_halo_splits(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, c.u->splitk_floats) == 1;
+    if (rb.mode != 0) {
+        xr.H = Ho; xr.W = Wo;
+        xr.p = arena_take(c.u, (size_t)c.N * Ho * Wo * x.C);     // (the sizing pass always reserves it: routing may differ later)
+    }
     if (rb.mode == 0 && can_fuse_gn(c, x, rb.c1)) {
         PD_TRY(run_gn_conv(c, x, rb.n1, nullptr, 0, rb.c1, nullptr, &h1));
     } else {
-        PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, rb.mode, &h0));
+        PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, rb.mode, &h0, fold_down ? xr.p : nullptr));
         PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
     }
-    if (rb.mode != 0) {
-        xr.H = h1.H; xr.W = h1.W;
-        xr.p = arena_take(c.u, (size_t)c.N * xr.H * xr.W * x.C);
-        if (!c.dry) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
-    }
-    sk = xr;
+    if (rb.mode != 0 && !c.dry && !fold_down && !fold_up) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
+    sk = fold_up ? x : xr;
     if (rb.has_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
-    if (can_fuse_gn(c, h1, rb.c2)) return run_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, out);
+    if (can_fuse_gn(c, h1, rb.c2)) return run_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, out, fold_up ? 1 : 0);
     PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
-    return run_conv(c, h2, rb.c2, sk.p, out, true);
+    return run_conv(c, h2, rb.c2, sk.p, out, true, nullptr, fold_up ? 1 : 0);
 }
 
 int run_att(Ctx& c, const Act& x, AttB& ab, Act* out) {
@@ -750,6 +763,8 @@ extern "C" int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int sp
     return old;
 }
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
+/* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
+extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }
 extern "C" int pdhip_debug_set_fuse_gn(int on) { int old = pdnn::g_fuse_gn; pdnn::g_fuse_gn = on; return old; }
 /* stand-alone: y = conv3x3( silu( GroupNorm32(x) [* (1 + scale) + shift] ) ) (+ residual) with the transform applied inside the
  * conv (halo-resident kernel; W in {32, 64, 128, 256}, H * W % 512 == 0, Cin % 32 == 0).  ws: N*64 + N*64*ceil(HW/256) + N*Cin*2 floats. */

@@ -224,14 +224,17 @@ def test_unet_full_256_vs_reference_golden(nn):
     m.load_state_dict(w, strict=True)
     del w
     st = int(g['stride'])
-    for fuse in (0, 1):                                     # stand-alone GroupNorm passes / GroupNorm applied inside the halo conv
-        old = nn['L'].pdhip_debug_set_fuse_gn(fuse)
+    outs = {}
+    for fuse, fold in ((0, 1), (1, 1), (0, 0)):             # GroupNorm stand-alone / inside the halo conv; resample folded / as passes
+        old, oldf = nn['L'].pdhip_debug_set_fuse_gn(fuse), nn['L'].pdhip_debug_set_fold_resample(fold)
         try:
             out = m(torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV)).cpu()
         finally:
-            nn['L'].pdhip_debug_set_fuse_gn(old)
+            nn['L'].pdhip_debug_set_fuse_gn(old); nn['L'].pdhip_debug_set_fold_resample(oldf)
         linf, l2 = _rel(out[:, :, ::st, ::st], torch.from_numpy(g['ref_out']))
-        assert linf <= 2e-2 and l2 <= 5e-3, (fuse, linf, l2)
+        assert linf <= 2e-2 and l2 <= 5e-3, (fuse, fold, linf, l2)
+        outs[(fuse, fold)] = out
+    assert torch.equal(outs[(0, 1)], outs[(0, 0)]), "folding the resampled x branch into its consumers is bit-neutral"
 
 
 def test_ddnm_schedule_and_step_vs_reference_sampler_golden(nn):

@@ -8,12 +8,13 @@ import pointdreamer_amd.ddnm_inpainting as di
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='*', default=[1, 2, 4, 8, 32])
 ap.add_argument('--iters', type=int, default=10)
+ap.add_argument('--fold', type=int, default=1, help='pdhip_debug_set_fold_resample')
 ap.add_argument('--fuse', type=int, default=0, help='pdhip_debug_set_fuse_gn')
 ap.add_argument('--sampler-steps', type=int, default=10, help='also time this many DDNM steps through pdhip_ddnm_sample (0 = skip)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 from pointdreamer_amd import _lib
-_lib.lib().pdhip_debug_set_fuse_gn(a.fuse)
+_lib.lib().pdhip_debug_set_fuse_gn(a.fuse); _lib.lib().pdhip_debug_set_fold_resample(a.fold)
 sd = di.random_state_dict(dict(di.IMAGENET_256), seed=0)
 rows = []
 for N in a.batches:
