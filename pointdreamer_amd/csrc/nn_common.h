@@ -21,7 +21,8 @@ bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
 // apply_table != NULL: the input is silu(A x + B) of X per gn_table (zero padding applies to the TRANSFORMED image)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
                  int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
-                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table = nullptr, int res_up = 0);   // res_up: residual = half-resolution tensor, nearest x2 on the fly
+                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table = nullptr, int res_up = 0,    // res_up: residual = half-resolution tensor, nearest x2 on the fly
+                 int in_up = 0);                                          // in_up: X = half-resolution tensor, the conv sees its nearest x2
 // fixed-order sum of split-K partials [splits][M][Cout] f32 + bias (+ residual) -> f16 Y, optional GroupNorm octet partials
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
@@ -33,7 +34,8 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
                float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, float* gn_part = nullptr, int* gn_fused = nullptr,
                const half_t* X2 = nullptr, int Cin1 = 0,    // X2: second tensor of a never-materialised channel concat (1x1 only)
                const float* apply_table = nullptr,          // input = silu(A x + B) per gn_table (layers the halo kernel takes only)
-               int res_up = 0);                             // residual = half-resolution tensor read with nearest x2 (unsplit halo layers only)
+               int res_up = 0,                              // residual = half-resolution tensor read with nearest x2 (unsplit halo layers only)
+               int in_up = 0);                              // X = half-resolution tensor, input = its nearest x2 (halo layers only)
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
 // the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).
 int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
                                                       half_t* __restrict__ Y, int N, int H, int Cin, int Cout, int n_tiles,
                                                       int total_tiles, const half_t* __restrict__ zero_page,
                                                       float* __restrict__ gn_part, int splits, float* __restrict__ partial,
-                                                      const float* __restrict__ ap_table, int res_up) {
+                                                      const float* __restrict__ ap_table, int res_up, int in_up) {
     constexpr int W = 1 << WLOG, BMT = 512, BNT = 128, TM = 8, ROWB = 64, NWAVES = 8;
     constexpr int RT = BMT / W, HW2 = W + 2, HP = (RT + 2) * HW2;     // tile rows, halo row length, halo pixels
     constexpr int NPA = (HP + 15) / 16, PA = (NPA + 7) / 8;           // 1 KiB halo pieces per chunk, per wave
@@ -100,7 +100,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         const int hy = hp / HW2, hx = hp - hy * HW2;
         const int y = ty0 - 1 + hy, x = x0 + hx - 1;
         const bool ok = (hp < HP) & (y >= 0) & (y < H) & (x >= 0) & (x < (1 << ILOG));
-        return ok ? (uint32_t)((((((img * H + y) << ILOG) + x) * Cin) + ((cq ^ swz_a(hp)) << 3)) * 2) : ~0u;   // < 2^32 (host check)
+        // in_up (0 / 1): X is the HALF-resolution tensor and the conv's input is its nearest x2 up-sampling (the in_layers conv of an
+        // up-ResBlock, unet.py:190-192, 237-238) -- index arithmetic here instead of a 4x larger tensor in HBM
+        const int spix = ((img * (H >> in_up) + (y >> in_up)) << (ILOG - in_up)) + (x >> in_up);          // source pixel
+        return ok ? (uint32_t)((spix * Cin + ((cq ^ swz_a(hp)) << 3)) * 2) : ~0u;   // < 2^32 (host check)
     };
     uint32_t aoff[PA_TAB];
 #pragma unroll
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
 template <int WLOG, int ILOG, bool APPLY>
 int launch_halo_v(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
                   int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int splits, float* partial,
-                  const float* ap_table, int res_up) {
+                  const float* ap_table, int res_up, int in_up) {
     constexpr int W = 1 << WLOG, RT = 512 / W, HP = (RT + 2) * (W + 2), NPA = (HP + 15) / 16;
     const size_t loop_bytes = (size_t)2 * NPA * 1024 + 3 * 8192 + (APPLY ? (size_t)8 * 1024 + (size_t)Cin * 8 + (size_t)NPA * 16 + 16 : 0);
     const size_t smem = std::max<size_t>(loop_bytes, (size_t)512 * (128 + 8) * 2);
@@ -447,21 +450,21 @@ int launch_halo_v(const half_t* X, const half_t* Wt, const float* bias, const ha
     const int n_tiles = Cout_pad / 128;
     const int total = (int)(((long long)N * H * (1 << ILOG)) / 512) * n_tiles;
     kern<<<dim3(total, splits), 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part, splits,
-                                                partial, ap_table, res_up);
+                                                partial, ap_table, res_up, in_up);
     return PDHIP_OK;
 }
 template <int WLOG, int ILOG = WLOG>
 int launch_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin,
                 int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int splits, float* partial,
-                const float* ap_table, int res_up) {
+                const float* ap_table, int res_up, int in_up) {
     constexpr int W = 1 << WLOG, RT = 512 / W, HP = (RT + 2) * (W + 2), NPA = (HP + 15) / 16, PA = (NPA + 7) / 8;
     if constexpr (PA <= 7) {
         if (ap_table != nullptr)
-            return launch_halo_v<WLOG, ILOG, true>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part, splits, partial, ap_table, res_up);
+            return launch_halo_v<WLOG, ILOG, true>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part, splits, partial, ap_table, res_up, in_up);
     } else {
         PD_REQUIRE(ap_table == nullptr, "conv3x3_halo: the full-row 256-wide tile has no APPLY variant");
     }
-    return launch_halo_v<WLOG, ILOG, false>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part, splits, partial, nullptr, res_up);
+    return launch_halo_v<WLOG, ILOG, false>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gn_part, splits, partial, nullptr, res_up, in_up);
 }
 
 }  // namespace
@@ -488,7 +491,8 @@ int conv3x3_halo_splits(int N, int H, int W, int Cin, int Cout, int Cout_pad, si
 // epilogue, H*W/16 from the split reduce)
 int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
                  int Cin, int Cout, int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_fused,
-                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table, int res_up) {
+                 float* splitk_ws, size_t splitk_ws_floats, const float* apply_table, int res_up, int in_up) {
+    PD_REQUIRE(in_up == 0 || (apply_table == nullptr && H % 2 == 0), "conv3x3_halo: an up-sampled input excludes the in-conv GroupNorm");
     PD_REQUIRE(conv3x3_halo_eligible(N, H, W, Cin, Cout_pad), "conv3x3_halo: unsupported geometry (N=%d H=%d W=%d Cin=%d)", N, H, W, Cin);
     int splits = conv3x3_halo_splits(N, H, W, Cin, Cout, Cout_pad, splitk_ws ? splitk_ws_floats : 0);
     if (splits < 1) splits = 1;
@@ -500,9 +504,9 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
     const bool fuse_sk = splits > 1 && gn_part != nullptr && (H * W) % 16 == 0;
     if (gn_fused) *gn_fused = gn_part ? (splits > 1 ? (fuse_sk ? (H * W) / 16 : 0) : (int)(((long long)H * W) / 512)) : 0;
     float* gnp = splits > 1 ? nullptr : gn_part;
-#define HL_LAUNCH(WL) launch_halo<WL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table, res_up)
+#define HL_LAUNCH(WL) launch_halo<WL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table, res_up, in_up)
     int rc;
-#define HL_LAUNCH2(WL, IL) launch_halo<WL, IL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table, res_up)
+#define HL_LAUNCH2(WL, IL) launch_halo<WL, IL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table, res_up, in_up)
     // 256-wide images: column strips of 128 (4 rows x 128 per tile: 780 halo pixels per chunk instead of 1 032) measured +2-3 %
     // over full rows, strips of 64 +1.5-3 %; at 128 wide strips do not pay.  g_halo_strips: 0 automatic, 1 full rows, 2 = 64 wide.
     if (W == 256 && g_halo_strips == 2 && H % 8 == 0) rc = HL_LAUNCH2(6, 8);

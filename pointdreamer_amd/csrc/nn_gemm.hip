@@ -580,7 +580,7 @@ int splitk_reduce(const float* partial, int splits, long long M, int Cout, const
 
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* splitk_ws,
-               size_t splitk_ws_floats, float* gn_part, int* gn_fused, const half_t* X2, int Cin1, const float* apply_table, int res_up) {
+               size_t splitk_ws_floats, float* gn_part, int* gn_fused, const half_t* X2, int Cin1, const float* apply_table, int res_up, int in_up) {
     PD_REQUIRE(taps == 1 || taps == 9, "conv_igemm: taps must be 1 or 9");
     if (X2 == nullptr) Cin1 = Cin;
     PD_REQUIRE(X2 == nullptr || (taps == 1 && Cin1 > 0 && Cin1 < Cin && Cin1 % 64 == 0 && (Cin - Cin1) % 64 == 0),
@@ -592,7 +592,8 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     // (tuning hook: tile geometry 32 forces it, any other forced geometry disables it)
     if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0))
         return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused, splitk_ws,
-                            splitk_ws_floats, apply_table, res_up);
+                            splitk_ws_floats, apply_table, res_up, in_up);
+    PD_REQUIRE(in_up == 0, "conv_igemm: an up-sampled input needs a layer the halo-resident kernel takes");
     PD_REQUIRE(res_up == 0, "conv_igemm: an up-sampled residual needs a layer the halo-resident kernel takes unsplit");
     PD_REQUIRE(apply_table == nullptr, "conv_igemm: an input transform needs a layer the halo-resident kernel takes");
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;

@@ -173,20 +173,22 @@ int prof_end(Ctx& c) {
 }
 
 int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* out, bool want_gn = false,
-             const float* apply_table = nullptr, int res_up = 0) {
-    *out = Act{nullptr, w.cout, x.H, x.W};
-    out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
+             const float* apply_table = nullptr, int res_up = 0, int in_up = 0) {
+    // in_up: x is the half-resolution input, the conv runs on its nearest x2 (out has twice x's height / width)
+    const int cH = x.H << in_up, cW = x.W << in_up;
+    *out = Act{nullptr, w.cout, cH, cW};
+    out->p = arena_take(c.u, (size_t)c.N * cH * cW * w.cout);
     // octet partials: [N][chunks][cout/8][2] floats, chunks <= HW/16 (split-K reduce) -- sized for the finest chunking
-    float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 15) / 16) * (w.cout / 8) * 2 * 2)) : nullptr;
+    float* part = want_gn ? reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((cH * cW + 15) / 16) * (w.cout / 8) * 2 * 2)) : nullptr;
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(w.have_w && w.have_b, "unet: conv weights not loaded");
     // profile hook (bench.py roofline): the dominant kernel only -- the halo-resident 3x3 conv
-    const bool prof = x.p2 == nullptr && conv_uses_halo(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats) &&
-                      conv3x3_halo_splits(c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, c.u->splitk_floats) == 1;
-    if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * x.H * x.W * (double)w.cout * 9.0 * w.cin));
+    const bool prof = x.p2 == nullptr && conv_uses_halo(c.N, cH, cW, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats) &&
+                      conv3x3_halo_splits(c.N, cH, cW, w.cin, w.cout, w.cout_pad, c.u->splitk_floats) == 1;
+    if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * cH * cW * (double)w.cout * 9.0 * w.cin));
     int fused = 0;
-    int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, x.H, x.W, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
-                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0, apply_table, res_up);
+    int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, cH, cW, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
+                        c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0, apply_table, res_up, in_up);
     if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = w.cout; }
     if (prof) PD_TRY(prof_end(c));
     return rc;
@@ -246,8 +248,14 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
         xr.H = Ho; xr.W = Wo;
         xr.p = arena_take(c.u, (size_t)c.N * Ho * Wo * x.C);     // (the sizing pass always reserves it: routing may differ later)
     }
+    // nearest x2 of the normalised input: index arithmetic in conv1's halo staging, the GroupNorm pass stays at half resolution
+    const bool fold_in_up = fold && rb.mode == 2 && Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&
+                            conv_uses_halo(c.N, Ho, Wo, rb.c1.cin, rb.c1.cout, rb.c1.cout_pad, 9, c.u->splitk_floats);
     if (rb.mode == 0 && can_fuse_gn(c, x, rb.c1)) {
         PD_TRY(run_gn_conv(c, x, rb.n1, nullptr, 0, rb.c1, nullptr, &h1));
+    } else if (fold_in_up) {
+        PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, 0, &h0));
+        PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true, nullptr, 0, 1));
     } else {
         PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, rb.mode, &h0, fold_down ? xr.p : nullptr));
         PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
