@@ -30,10 +30,10 @@ using namespace pdhip;
 
 #define QPW 16                 // query points per wavefront
 #define GJK_MAX_ROUNDS 64
-#define GJK_COARSE_ROUNDS 32
+#ifndef GJK_COARSE_ROUNDS
+#define GJK_COARSE_ROUNDS 16
+#endif
 #define HPR_KC 1024            // coarse support set size
-#define HPR_COOP_WAVES 4       // waves that share one group of 4 queries in the short-list geometry (8: -6 %, 16: -13 %)
-#define HPR_NARROW_BELOW 4096   // query lists shorter than this (per view) run 4 queries per wavefront instead of 16
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
 __device__ unsigned long long g_hpr_stats[2][16];             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
@@ -147,12 +147,41 @@ template <typename T> __device__ __forceinline__ void gjk_step(Gjk<T>& g, v3<T> 
     (void)zero;
 }
 
+// ---- wave-level reductions on the DPP network (no LDS round trip: a __shfl_xor butterfly is six dependent ds_bpermute pairs)
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }
+template <int CTRL, int ROWS> __device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL, ROWS>(__double2hiint(v)), dpp_i32<CTRL, ROWS>(__double2loint(v)));
+}
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror 0x141, row_mirror 0x140: every lane of a 16-lane row holds the row's
+// result; row_bcast15 (rows 1, 3) and row_bcast31 (rows 2, 3) then carry it to lane 63.  Lanes a step does not write keep their value.
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64<0xB1, 0xf>(v)); v = fmax(v, dpp_f64<0x4E, 0xf>(v)); v = fmax(v, dpp_f64<0x141, 0xf>(v)); v = fmax(v, dpp_f64<0x140, 0xf>(v));
+    v = fmax(v, dpp_f64<0x142, 0xa>(v)); v = fmax(v, dpp_f64<0x143, 0xc>(v));
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_i32<0xB1, 0xf>(v)); v = min(v, dpp_i32<0x4E, 0xf>(v)); v = min(v, dpp_i32<0x141, 0xf>(v)); v = min(v, dpp_i32<0x140, 0xf>(v));
+    v = min(v, dpp_i32<0x142, 0xa>(v)); v = min(v, dpp_i32<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double lane_f64(double v, int l) {        // l wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+__device__ __forceinline__ unsigned long long f64_key(double x) {            // order-preserving map to u64
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
 __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* __restrict__ eyes, double radius,
-                           double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/) {
+                           double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/,
+                           unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/) {
     // open3d PointCloud::HiddenPointRemoval: p' = q + 2 (radius - |q|) q / |q| evaluated as q + ((2 (radius - n)) q) / n
     const int v = blockIdx.y;
     const double ex = eyes[3 * v], ey = eyes[3 * v + 1], ez = eyes[3 * v + 2];
-    double m = 0.0;
+    double m = 0.0, b[6] = {-1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
         const double qx = (double)pts[3 * i] - ex, qy = (double)pts[3 * i + 1] - ey, qz = (double)pts[3 * i + 2] - ez;
         double n = sqrt(qx * qx + qy * qy + qz * qz);
@@ -162,10 +191,16 @@ __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* _
         const double x = qx + (k * qx) / n, y = qy + (k * qy) / n, z = qz + (k * qz) / n;
         f[i] = x; f[N + i] = y; f[2 * (size_t)N + i] = z;
         m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+        b[0] = fmax(b[0], -x); b[1] = fmax(b[1], -y); b[2] = fmax(b[2], -z); b[3] = fmax(b[3], x); b[4] = fmax(b[4], y); b[5] = fmax(b[5], z);
     }
+    m = wave_max_f64(m);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&maxabs[v], (unsigned long long)__double_as_longlong(m));   // non-negative f64: bit order = value order
+    for (int k = 0; k < 6; ++k) b[k] = wave_max_f64(b[k]);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&maxabs[v], (unsigned long long)__double_as_longlong(m));   // non-negative f64: bit order = value order
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicMax(&bbox[6 * v + k], f64_key(b[k]));
+    }
 }
 
 // queries that still need the hull test: all points, or only those a cheaper test (`skip`) has not already accepted
@@ -192,194 +227,455 @@ __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __re
     }
 }
 
-// Support set = ss[v][3][scap] (first `ns` entries valid) with original cloud indices sidx[v][scap].
-// Q = queries per wavefront (16 when there are enough queries to fill the chip; short lists -- where the kernel time is the
-// longest query's rounds x the scan length -- use Q = 4 with COOP: 4 queries per 256-lane block, 16x shorter scans).
-// COARSE: every point of the cloud is a query (ns = scap = KC extreme points); writes outside[v][q] = origin not enclosed.
-// !COARSE: queries from list / count, support set = the points outside the coarse hull (ns = scount[v]); writes vis.
-template <bool COARSE, int Q, bool COOP, int NW>
-__global__ __launch_bounds__(NW * 64, NW <= 4 ? 2 : 1) void k_hpr_gjk(const double* __restrict__ flipped, int N, const int* __restrict__ count,
-                                                 const int* __restrict__ list, uint8_t* __restrict__ vis,
-                                                 const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
-                                                 const int* __restrict__ scount, uint8_t* __restrict__ outside, int q_lo, int q_hi,
-                                                    const uint8_t* __restrict__ skip, const unsigned long long* __restrict__ maxabs,
-                                                    int* __restrict__ unc_count, int* __restrict__ unc_list, int* __restrict__ unc_seed) {
-    __shared__ double s_dir[NW][Q][3];
-    __shared__ int s_q[NW][Q];
-    __shared__ double s_rv[2][NW][Q];                            // COOP: per-wave partial argmax of the round (double-buffered)
-    __shared__ int s_ri[2][NW][Q];
+// what a query lane does with the support point of its round: myv = the largest support value over the real points (real_pt: one
+// was found; sp / sp_idx = that point and its cloud index).  The support of S_i is that point or the eye (value 0).
+// "The support does not pass the origin"  <=>  p'_i is the strict maximiser of dir over the cloud and the eye: position form, every
+// value evaluated as fma(dz, z, fma(dy, y, dx x)), so that the rounding bound rb covers both sides.
+__device__ __forceinline__ void gjk_round(Gjk<double>& g, const d3 pi, const double myv, const bool real_pt, const d3 sp, const int sp_idx,
+                                          const double rb) {
+    const bool real = real_pt && myv > 0.0;
+    const double di = fma(g.dir.z, pi.z, fma(g.dir.y, pi.y, g.dir.x * pi.x));
+    const double gap = di - (real ? myv : 0.0);
+    const double tol = rb * (fabs(g.dir.x) + fabs(g.dir.y) + fabs(g.dir.z));
+    if (gap > tol) g.state = 1;                                       // certified visible
+    else if (gap > 0.0 && g.dim >= 1) g.state = 3;                    // visible in f64, but inside the rounding bound
+    else {
+        // a support point that is already a vertex of the simplex: the origin lies on that face within rounding (exactly, the
+        // support of a face's own normal would not pass the origin) -- the boolean iteration would only cycle from here
+        const int ai = real ? sp_idx : -1;
+        if ((g.dim >= 1 && ai == g.ic) || (g.dim >= 2 && ai == g.ib) || (g.dim >= 3 && ai == g.id)) g.state = 3;
+        else gjk_step(g, real ? sp - pi : neg(pi), ai);
+    }
+}
+
+// ---- level 1: is the query enclosed by the hull of the coarse set (<= KC points of the cloud, no repeats)?  One LANE per query.
+// Only "enclosed" (certified by the four f64 determinants on the true coordinates) is a verdict of this level; everything else
+// -- also a query still running at the round cap, also a member of the coarse set itself -- goes on to level 2.  That makes the
+// support SCAN free to be approximate, and it is a small GEMM: values[point][query] = P[point][xyz] . D[xyz][query].  It runs on
+// the matrix cores in f32 (v_mfma_f32_32x32x2_f32, K = x, y | z, 0): A = 32 coarse points, B = the directions of 32 of the
+// wave's 64 queries, so that a lane receives 16 points' values for ONE query (its own column) and keeps a running maximum --
+// no cross-lane work except joining the two half-waves at the end.  The VALU is left with the compare / select (3 per pair
+// instead of 7 with the products) and the GJK step; the chosen support point is then re-evaluated in f64.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float tile_max(const f32x16 a) {          // (v_max3_f32: eight instructions)
+    const float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]), m1 = fmaxf(fmaxf(a[3], a[4]), a[5]), m2 = fmaxf(fmaxf(a[6], a[7]), a[8]),
+                m3 = fmaxf(fmaxf(a[9], a[10]), a[11]), m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
+    return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), a[15]));
+}
+__global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+                                                    const int* __restrict__ list, const float4* __restrict__ csf /*[V][KC]*/,
+                                                    const double* __restrict__ csd /*[V][KC][4]*/, const int* __restrict__ cidx /*[V][KC]*/,
+                                                    const int* __restrict__ kcount, uint8_t* __restrict__ outside,
+                                                    const unsigned long long* __restrict__ maxabs) {
     const int v = blockIdx.y;
-    const double* qfx = flipped + (size_t)v * 3 * N;          // the queries' own coordinates
-    const double* qfy = qfx + N;
-    const double* qfz = qfy + N;
-    const double* fx = ss + (size_t)v * 3 * scap;             // the support set
-    const double* fy = fx + scap;
-    const double* fz = fy + scap;
-    const int* sidx = sidx_all + (size_t)v * scap;
-    const int NS = COARSE ? scap : scount[v];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // COOP: the four waves of the block own the SAME Q queries, scan a quarter of the support set each and merge through LDS
-    // (all four run the identical state machine on the merged result): a round is 4x shorter, which is what bounds the
-    // kernel when the query list is short and a few queries need 40-60 rounds.
-    const int q0 = COOP ? blockIdx.x * Q : (blockIdx.x * NW + wave) * Q;
-    const int nq = COARSE ? N : count[v];
-    if (q0 >= nq || nq < q_lo || nq >= q_hi) return;        // (q_lo, q_hi: which launch geometry serves this view's query count)
-    // query k of the wave lives in lane k * ST (the lane the halving reduction below leaves its support point in)
-    constexpr int ST = 64 / Q;
-    const int kq = lane / ST;
-    const bool slot = (lane % ST) == 0;
-    bool owner = slot && q0 + kq < nq;
-    const int q = owner ? (COARSE ? q0 + kq : list[(size_t)v * N + q0 + kq]) : -1;
-    // coarse pass: a point of the coarse set itself is an extreme point of the cloud -- a certain hull vertex, marked 2 by
-    // k_hpr_extremes, never queried (so no query of this pass is a member of its own support set)
-    if (COARSE && owner && outside[(size_t)v * N + q] == 2) owner = false;
-    // ... and a point the cheaper test already accepted needs no verdict of its own: it joins the second-level support set
-    // unexamined (any superset of the outside set inside the cloud is a valid support set; depth-visible points are almost all
-    // outside anyway), which removes a third of the coarse queries
-    if (COARSE && owner && skip != nullptr && skip[(size_t)v * N + q]) { outside[(size_t)v * N + q] = 1; owner = false; }
-    if (slot) s_q[wave][kq] = q;
-    __builtin_amdgcn_wave_barrier();
-    int qk[Q];
-#pragma unroll
-    for (int k = 0; k < Q; ++k) qk[k] = s_q[wave][k];
-    // ---- per-query GJK state (meaningful in the slot lanes)
+    const int nq = count[v];
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if ((qi & ~63) >= nq) return;
+    const float4* c = csf + (size_t)v * HPR_KC;
+    const int KS = min(kcount[v], HPR_KC), KT = (KS + 31) >> 5;       // (the set is padded with the eye (0, 0, 0) to whole tiles)
+    const double* qf = flipped + (size_t)v * 3 * N;
+    const double rb = __longlong_as_double((long long)maxabs[v]) * (8.0 * 1.1102230246251565e-16);
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    const bool hi = lane >= 32;
+    const bool owner = qi < nq;
+    const int q = owner ? list[(size_t)v * N + qi] : 0;
     d3 pi = {0, 0, 0};
     Gjk<double> g;
     g.sa = g.sb = g.sc = g.sd = d3{0, 0, 0}; g.dir = d3{0, 0, 1};
     g.ia = g.ib = g.ic = g.id = -1;
-    g.dim = 0;                     // simplex size; phases: 0 -> fetch c, 1 -> fetch b, >= 2 -> main loop
-    g.state = owner ? 0 : 2;       // 0 running, 1 visible (certified), 2 hidden (certified) / not a query, 3 not certifiable in f64
-    int& state = g.state;
-    d3& dir = g.dir;
-    if (owner) {
-        pi = {qfx[q], qfy[q], qfz[q]};
-        dir = pi;                  // start looking straight out along the point's own ray
-    }
-    // rounding bound of one support value (dx x + dy y) + dz z in f64: <= 3.01 u (|dx| + |dy| + |dz|) max|coordinate|
-    const double rb = __longlong_as_double((long long)maxabs[v]) * (8.0 * 1.1102230246251565e-16);
+    g.dim = 0;
+    g.state = owner ? 0 : 2;
+    if (owner) { pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]}; g.dir = pi; }
 #ifdef PD_HPR_STATS
     int my_rounds = 0, wave_rounds = 0;
 #endif
-    for (int round = 0; round < (COARSE ? GJK_COARSE_ROUNDS : GJK_MAX_ROUNDS); ++round) {
-        if (__ballot(state == 0) == 0ull) break;
+    for (int round = 0; round < GJK_COARSE_ROUNDS; ++round) {
+        if (__ballot(g.state == 0) == 0ull) break;
 #ifdef PD_HPR_STATS
-        ++wave_rounds; if (state == 0) ++my_rounds;
+        ++wave_rounds; if (g.state == 0) ++my_rounds;
 #endif
-        if (slot) { s_dir[wave][kq][0] = dir.x; s_dir[wave][kq][1] = dir.y; s_dir[wave][kq][2] = dir.z; }
-        __builtin_amdgcn_wave_barrier();
-        double dx[Q], dy[Q], dz[Q], best[Q];
-        int bi[Q];                                                 // position in the support set
-#pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            dx[k] = s_dir[wave][k][0]; dy[k] = s_dir[wave][k][1]; dz[k] = s_dir[wave][k][2];
-            best[k] = -1.0e300; bi[k] = 0x7fffffff;
+        // directions only matter up to scale: bring them into f32 range by their own magnitude (a power of two)
+        const double mag = fmax(fabs(g.dir.x), fmax(fabs(g.dir.y), fabs(g.dir.z)));
+        const double sc = mag > 0.0 ? __longlong_as_double((long long)((0x7feull - ((unsigned long long)__double_as_longlong(mag) >> 52)) << 52)) : 1.0;
+        const float dx = (float)(g.dir.x * sc), dy = (float)(g.dir.y * sc), dz = (float)(g.dir.z * sc);
+        // B operands (lane l: B[k = l >> 5][query column l & 31]) for the wave's two columns of 32 queries
+        const float x0 = __shfl(dx, l31), y0 = __shfl(dy, l31), z0 = __shfl(dz, l31);
+        const float x1 = __shfl(dx, 32 + l31), y1 = __shfl(dy, 32 + l31), z1 = __shfl(dz, 32 + l31);
+        const float b1_0 = hi ? y0 : x0, b2_0 = hi ? 0.0f : z0, b1_1 = hi ? y1 : x1, b2_1 = hi ? 0.0f : z1;
+        float best0 = -3.0e38f, best1 = -3.0e38f;
+        int code0 = -1, code1 = -1;                               // tile * 16 + accumulator entry
+        // two tiles in flight: the matrix cores work on one while the VALU reduces the other (KT2 even: the pad tiles are the eye)
+        const f32x16 zero = {0};
+#define HPR_TILE_MFMA(ACC0, ACC1, PT)                                                                              \
+        {                                                                                                          \
+            const float a1 = hi ? (PT).y : (PT).x, a2 = hi ? 0.0f : (PT).z;      /* lane l: A[point l & 31][k = l >> 5] */ \
+            ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0);                                  \
+            ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);                                  \
+            ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, ACC0, 0, 0, 0);                                  \
+            ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, ACC1, 0, 0, 0);                                  \
         }
-        // ---- support scan: every lane streams points j = lane, lane+64, ...  The support set is in ascending cloud order, a
-        // lane keeps its FIRST maximum and the butterfly prefers the smaller position: equal values resolve to the smallest
-        // cloud index without an index compare per pair (8 VALU per pair instead of 15).
-        // (the next point is requested before the current one is evaluated: two waves per SIMD do not hide an L2 round trip)
-        double nx = 0.0, ny = 0.0, nz = 0.0;
-        int njo = -1;
-        constexpr int JS = COOP ? NW * 64 : 64;
-        const int j0 = COOP ? wave * 64 + lane : lane;
-        if (j0 < NS) { nx = fx[j0]; ny = fy[j0]; nz = fz[j0]; if (!COARSE) njo = sidx[j0]; }
-        for (int j = j0; j < NS; j += JS) {
-            const double x = nx, y = ny, z = nz;
-            const int jo = njo;
-            const int jn = j + JS;
-            if (jn < NS) { nx = fx[jn]; ny = fy[jn]; nz = fz[jn]; if (!COARSE) njo = sidx[jn]; }
-            if (COARSE) {
+#define HPR_TILE_REDUCE(ACC0, ACC1, T)                                                                             \
+        {   /* per tile only WHICH tile holds the lane's maximum; the position inside it is found once, after the scan */ \
+            const float m0 = tile_max(ACC0), m1 = tile_max(ACC1);                                                  \
+            if (m0 > best0) { best0 = m0; code0 = (T); }                                                           \
+            if (m1 > best1) { best1 = m1; code1 = (T); }                                                           \
+        }
+        const int KT2 = (KT + 1) & ~1, TMAX = HPR_KC / 32 - 1;
+        f32x16 A0, A1, B0, B1;
+        float4 pa = c[l31], pb = c[32 + l31];
+        HPR_TILE_MFMA(A0, A1, pa)
+        for (int t = 0; t < KT2; t += 2) {
+            pa = c[min(t + 2, TMAX) * 32 + l31];
+            HPR_TILE_MFMA(B0, B1, pb)
+            HPR_TILE_REDUCE(A0, A1, t)
+            pb = c[min(t + 3, TMAX) * 32 + l31];
+            HPR_TILE_MFMA(A0, A1, pa)
+            HPR_TILE_REDUCE(B0, B1, t + 1)
+        }
+#undef HPR_TILE_MFMA
+#undef HPR_TILE_REDUCE
+        // accumulator entry i of lane l is point row 8 (i / 4) + 4 (l >> 5) + (i % 4) of the tile: the lane re-evaluates its 16 rows of
+        // the tile its maximum came from (the same fmaf chain as the matrix core: bitwise the same values), for both query columns
+        int j0 = -1, j1 = -1;
+        {
+            float r0 = -3.0e38f, r1 = -3.0e38f;
+            const int base0 = max(code0, 0) * 32 + (hi ? 4 : 0), base1 = max(code1, 0) * 32 + (hi ? 4 : 0);
 #pragma unroll
-                for (int k = 0; k < Q; ++k) {
-                    const double val = dx[k] * x + dy[k] * y + dz[k] * z;
-                    if (val > best[k]) { best[k] = val; bi[k] = j; }
-                }
-            } else {                                                 // jo = index in the cloud: S_i excludes the point itself
-#pragma unroll
-                for (int k = 0; k < Q; ++k) {
-                    const double val = dx[k] * x + dy[k] * y + dz[k] * z;
-                    if ((val > best[k]) & (jo != qk[k])) { best[k] = val; bi[k] = j; }
-                }
+            for (int i = 0; i < 16; ++i) {
+                const int row = 8 * (i / 4) + (i % 4);
+                const float4 u0 = c[base0 + row], u1 = c[base1 + row];
+                const float w0 = fmaf(u0.z, z0, fmaf(u0.y, y0, u0.x * x0)), w1 = fmaf(u1.z, z1, fmaf(u1.y, y1, u1.x * x1));
+                if (w0 > r0) { r0 = w0; j0 = base0 + row; }
+                if (w1 > r1) { r1 = w1; j1 = base1 + row; }
             }
         }
-        // ---- Q argmax reductions over the 64 lanes at once: every step swaps one half of the still-live queries with the
-        // partner lane and keeps the other half (Q-1 exchanged items instead of 6 Q), then plain butterflies inside the ST
-        // lanes that end up holding the same query.  Equal values: smaller position.
-#define HPR_HALVE(I)                                                                                                  \
-        if constexpr ((Q >> (I)) > 1) {                                                                               \
-            constexpr int off = 32 >> (I), n = Q >> (I);                                                              \
-            const bool hi = (lane & off) != 0;                                                                        \
-            _Pragma("unroll") for (int k = 0; k < n / 2; ++k) {                                                       \
-                const double send = hi ? best[k] : best[k + n / 2], keep = hi ? best[k + n / 2] : best[k];            \
-                const int sendi = hi ? bi[k] : bi[k + n / 2], keepi = hi ? bi[k + n / 2] : bi[k];                     \
-                const double ob = __shfl_xor(send, off);                                                              \
-                const int oi = __shfl_xor(sendi, off);                                                                \
-                const bool take = ob > keep || (ob == keep && oi < keepi);                                            \
-                best[k] = take ? ob : keep; bi[k] = take ? oi : keepi;                                                \
-            }                                                                                                         \
-        }
-        HPR_HALVE(0) HPR_HALVE(1) HPR_HALVE(2) HPR_HALVE(3)
-#undef HPR_HALVE
-#pragma unroll
-        for (int off = ST / 2; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best[0], off);
-            const int oi = __shfl_xor(bi[0], off);
-            if (ob > best[0] || (ob == best[0] && oi < bi[0])) { best[0] = ob; bi[0] = oi; }
-        }
-        if (COOP) {                                                  // merge the four quarters (ties: smaller position)
-            const int pb = round & 1;
-            if (slot) { s_rv[pb][wave][kq] = best[0]; s_ri[pb][wave][kq] = bi[0]; }
-            __syncthreads();
-            best[0] = s_rv[pb][0][kq]; bi[0] = s_ri[pb][0][kq];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const double ob = s_rv[pb][w][kq];
-                const int oi = s_ri[pb][w][kq];
-                if (ob > best[0] || (ob == best[0] && oi < bi[0])) { best[0] = ob; bi[0] = oi; }
+        // join the two half-waves
+        const float ob0 = __shfl_xor(best0, 32), ob1 = __shfl_xor(best1, 32);
+        const int oj0 = __shfl_xor(j0, 32), oj1 = __shfl_xor(j1, 32);
+        if (ob0 > best0) j0 = oj0;
+        if (ob1 > best1) j1 = oj1;
+        int bi = hi ? j1 : j0;                                    // query lane l is column l & 31 of query tile l >> 5
+        if (bi >= KS) bi = -1;                                    // a pad entry: the eye
+        if (g.state == 0) {
+            d3 sp = {0, 0, 0};
+            int si = -1;
+            double myv = 0.0;
+            if (bi >= 0) {
+                si = cidx[(size_t)v * HPR_KC + bi];
+                const double* cd = csd + ((size_t)v * HPR_KC + bi) * 4;
+                sp = {cd[0], cd[1], cd[2]};
+                myv = fma(g.dir.z, sp.z, fma(g.dir.y, sp.y, g.dir.x * sp.x));
             }
-        }
-        const double myv = best[0];
-        const int myi = bi[0];
-        if (state == 0) {
-            // support point of S_i in direction dir: best flipped point, or the origin of the flipped space (value 0)
-            const bool real = myv > 0.0 && myi < NS;
-            // "the support does not pass the origin"  <=>  p'_i is the strict maximiser of dir over the cloud and the eye.
-            // Position form with the scan's own op order, so that the rounding bound rb applies to both sides.
-            const double di = dir.x * pi.x + dir.y * pi.y + dir.z * pi.z;
-            const double gap = di - (real ? myv : 0.0);
-            const double tol = rb * (fabs(dir.x) + fabs(dir.y) + fabs(dir.z));
-            if (gap > tol) state = 1;                                     // certified visible
-            else if (gap > 0.0 && g.dim >= 1) state = 3;                  // visible in f64, but inside the rounding bound
-            else {
-                d3 a;
-                int ai = -1;
-                if (real) { a = d3{fx[myi], fy[myi], fz[myi]} - pi; ai = sidx[myi]; }
-                else a = neg(pi);
-                gjk_step(g, a, ai);
-            }
+            if (si == q) g.state = 3;                             // the query is itself a member of the coarse set: level 2 decides
+            else gjk_round(g, pi, myv, bi >= 0, sp, si, rb);
         }
     }
 #ifdef PD_HPR_STATS
-    if (lane == 0) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][0], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][1], (unsigned long long)wave_rounds); }
-    if (owner) { atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][2], 1ull); atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][3], (unsigned long long)my_rounds);
-                 if (state == 0) atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][4], 1ull);
-                 atomicAdd(&g_hpr_stats[COARSE ? 0 : 1][8 + min(my_rounds, 63) / 8], 1ull); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&g_hpr_stats[0][0], 1ull); atomicAdd(&g_hpr_stats[0][1], (unsigned long long)wave_rounds); }
+    if (owner) { atomicAdd(&g_hpr_stats[0][2], 1ull); atomicAdd(&g_hpr_stats[0][3], (unsigned long long)my_rounds);
+                 if (g.state == 0) atomicAdd(&g_hpr_stats[0][4], 1ull);
+                 atomicAdd(&g_hpr_stats[0][8 + min(my_rounds, 63) / 8], 1ull); }
 #endif
-    if (!COARSE) {
-        if (owner) {
-            vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
-            if (state == 0 || state == 3)                             // round cap reached / not certifiable: exact fallback
-            {
-                    const int pos = atomicAdd(&unc_count[v], 1);
-                    unc_list[(size_t)v * N + pos] = q;
-                    int* sd = unc_seed + ((size_t)v * N + pos) * 4;          // the simplex it stopped at seeds the fallback
-                    sd[0] = g.dim >= 1 ? g.ic : -2; sd[1] = g.dim >= 2 ? g.ib : -2; sd[2] = g.dim >= 3 ? g.id : -2; sd[3] = -2;
-                }
+    if (owner) outside[(size_t)v * N + q] = g.state != 2;        // 0: CERTIFIED enclosed by the coarse hull: hidden, and never a support point
+}
+
+// ---- level 2: the queries the coarse hull cannot enclose, against the points outside the coarse hull, which are sorted by a
+// 3-D Morton cell of their position and cut into chunks of 64 with an oriented bounding box each (axes: the chunk's mean
+// direction from the eye and two tangents -- the flipped cloud is a thin shell around the eye, its patches are flat in that
+// frame).  A support scan in direction d only has to look into the chunks whose box bound  sum_k max((d.e_k) lo_k, (d.e_k) hi_k)
+// reaches a value that some point of S_i certainly attains: the largest support value of the query's current simplex vertices,
+// or, before there is a simplex, of its neighbour in the sorted order.  That is a handful of chunks out of hundreds.  The bounds
+// are evaluated in f32 with a slack that covers their rounding (and the rounding of the stored axes); the support values
+// themselves in f64.  Equal support values: the smaller cloud index, so the result does not depend on the order inside a cell.
+#define HPR_BOX_FLOATS 16        // e0, e1, e2, lo, hi (3 each), pad
+#define HPR_BOUND_SLACK 1.0e-5   // x |d|_1 max|coordinate|: f32 evaluation of the bound (<= 3e-6) with margin
+struct Support { double val, x, y, z; int pos, idx; };      // wave-uniform; pos < 0: no point of S_i reaches the threshold
+// DUPX: also exclude the points that coincide with the query and have a larger cloud index (the distance iteration's rule)
+template <bool DUPX>
+__device__ __forceinline__ Support support_scan(const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
+                                                const int* __restrict__ sidx, const int NS, const float4* __restrict__ boxes,
+                                                const double dx, const double dy, const double dz, const double th, const int qk,
+                                                const double px, const double py, const double pz, int* s_cand /*[256], this wave's*/,
+                                                const int lane, unsigned long long* n_cand) {
+    const int NCH = (NS + 63) >> 6;
+    // the direction in f32, scaled into range by a power of two (the bound is homogeneous in d; th is scaled alike)
+    const double mag = fmax(fabs(dx), fmax(fabs(dy), fabs(dz)));
+    const double sc = mag > 0.0 ? __longlong_as_double((long long)((0x3ffull + 0x3ffull - (((unsigned long long)__double_as_longlong(mag) >> 52) & 0x7ffull)) << 52)) : 1.0;
+    const float dxf = (float)(dx * sc), dyf = (float)(dy * sc), dzf = (float)(dz * sc);
+    const double ths = th * sc;
+    double best = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0;
+    int bidx = 0x7fffffff, bpos = -1;
+    for (int g0 = 0; g0 < NCH; g0 += 256) {
+        bool cand[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cc = g0 + u * 64 + lane;
+            cand[u] = false;
+            if (cc < NCH) {
+                const float4* b = boxes + (size_t)cc * (HPR_BOX_FLOATS / 4);
+                const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];          // e0.xyz e1.x | e1.yz e2.xy | e2.z lo.xyz | hi.xyz -
+                const float p0 = fmaf(dzf, b0.z, fmaf(dyf, b0.y, dxf * b0.x)), p1 = fmaf(dzf, b1.y, fmaf(dyf, b1.x, dxf * b0.w)),
+                            p2 = fmaf(dzf, b2.x, fmaf(dyf, b1.w, dxf * b1.z));
+                const float bound = (fmaxf(p0 * b2.y, p0 * b3.x) + fmaxf(p1 * b2.z, p1 * b3.y)) + fmaxf(p2 * b2.w, p2 * b3.z);
+                cand[u] = (double)bound >= ths;
+            }
         }
-    } else {
-        if (owner) outside[(size_t)v * N + q] = state != 2;           // 0: CERTIFIED enclosed by the coarse hull (hidden, and never a support
-                                                                      // point); anything else -- also an uncertified verdict -- goes on to the
-                                                                      // second level (entries marked 2 -- coarse-set members -- are left alone)
+        int nc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long bal = __ballot(cand[u]);
+            if (cand[u]) s_cand[nc + __popcll(bal & ((1ull << lane) - 1ull))] = g0 + u * 64 + lane;
+            nc += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (n_cand) *n_cand += nc;
+        for (int b0 = 0; b0 < nc; b0 += 8) {                      // eight candidate chunks per trip: their loads are in flight together
+            int jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) jj[u] = (s_cand[min(b0 + u, nc - 1)] << 6) + lane;   // (a repeated chunk cannot change the result)
+            double x[8], y[8], z[8];
+            int jo[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = min(jj[u], NS - 1);
+                x[u] = fx[j]; y[u] = fy[j]; z[u] = fz[j]; jo[u] = sidx[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double val = fma(dz, z[u], fma(dy, y[u], dx * x[u]));
+                bool ok = jj[u] < NS && jo[u] != qk;
+                if (DUPX) ok = ok && !(jo[u] > qk && x[u] == px && y[u] == py && z[u] == pz);
+                if (ok && (val > best || (val == best && jo[u] < bidx))) { best = val; bidx = jo[u]; bpos = jj[u]; bx = x[u]; by = y[u]; bz = z[u]; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    Support r;
+    r.val = wave_max_f64(best);
+    r.idx = wave_min_i32(best == r.val ? bidx : 0x7fffffff);
+    const unsigned long long who = __ballot(best == r.val && bidx == r.idx && bpos >= 0);
+    r.pos = -1; r.x = r.y = r.z = 0.0;
+    if (who != 0ull) {
+        const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(who));
+        r.pos = __builtin_amdgcn_readlane(bpos, src);
+        r.x = lane_f64(bx, src); r.y = lane_f64(by, src); r.z = lane_f64(bz, src);
+    }
+    return r;
+}
+
+// Q queries per wavefront live in lanes 0..Q-1; their scans run one after the other on all 64 lanes (direction, threshold and
+// query index wave-uniform in SGPRs), the GJK step then runs on the Q lanes at once.  Q = 1 for short query lists (the pipeline's
+// case: only depth-rejected points are queried), where the kernel time is the longest query's chain of dependent rounds.
+template <int Q>
+__global__ __launch_bounds__(256) void k_hpr_fine(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+                                                  const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
+                                                  const int* __restrict__ sidx_all, const int* __restrict__ scount,
+                                                  const float4* __restrict__ boxes_all, const int* __restrict__ pos_of, int q_lo, int q_hi,
+                                                  const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
+                                                  int* __restrict__ unc_list, int* __restrict__ unc_seed) {
+    __shared__ int s_cand[4][256];
+    const int v = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = count[v];
+    const int q0 = (blockIdx.x * 4 + wave) * Q;
+    if (q0 >= nq || nq < q_lo || nq >= q_hi) return;
+    const double* qf = flipped + (size_t)v * 3 * N;
+    const double* fx = ss + (size_t)v * 3 * N;
+    const double* fy = fx + N;
+    const double* fz = fy + N;
+    const int* sidx = sidx_all + (size_t)v * N;
+    const int NS = scount[v];
+    const float4* boxes = boxes_all + (size_t)v * ((N + 63) >> 6) * (HPR_BOX_FLOATS / 4);
+    const bool owner = lane < Q && q0 + lane < nq;
+    const int q = owner ? list[(size_t)v * N + q0 + lane] : -1;
+    d3 pi = {0, 0, 0};
+    Gjk<double> g;
+    g.sa = g.sb = g.sc = g.sd = d3{0, 0, 0}; g.dir = d3{0, 0, 1};
+    g.ia = g.ib = g.ic = g.id = -1;
+    g.dim = 0;
+    g.state = owner ? 0 : 2;
+    const double ma = __longlong_as_double((long long)maxabs[v]);
+    const double rb = ma * (8.0 * 1.1102230246251565e-16);
+    double nbx = 0.0, nby = 0.0, nbz = 0.0;                       // the neighbour in the sorted order: seeds the first round's bound
+    bool have_nb = false;
+    if (owner) {
+        pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]};
+        g.dir = pi;                                               // start looking straight out along the point's own ray
+        const int pq = pos_of[(size_t)v * N + q];
+        int nb = pq ^ 1;
+        if (nb >= NS) nb = pq - 1;
+        if (nb >= 0 && nb != pq) { nbx = fx[nb]; nby = fy[nb]; nbz = fz[nb]; have_nb = true; }
+    }
+#ifdef PD_HPR_STATS
+    int my_rounds = 0, wave_rounds = 0;
+    unsigned long long cand_chunks = 0;
+#endif
+    for (int round = 0; round < GJK_MAX_ROUNDS; ++round) {
+        const unsigned long long run = __ballot(g.state == 0);
+        if (run == 0ull) break;
+#ifdef PD_HPR_STATS
+        ++wave_rounds; if (g.state == 0) ++my_rounds;
+#endif
+        // a value some point of S_i certainly attains in this direction (0: the eye), less the rounding of that estimate and of the bound
+        double thr = 0.0;
+        {
+            const double dpi = fma(g.dir.z, pi.z, fma(g.dir.y, pi.y, g.dir.x * pi.x));
+            if (g.dim == 0) { if (have_nb) thr = fmax(thr, fma(g.dir.z, nbz, fma(g.dir.y, nby, g.dir.x * nbx))); }
+            else {
+                thr = fmax(thr, dot(g.dir, g.sc) + dpi);
+                if (g.dim >= 2) thr = fmax(thr, dot(g.dir, g.sb) + dpi);
+                if (g.dim >= 3) thr = fmax(thr, dot(g.dir, g.sd) + dpi);
+            }
+            thr -= (4.0 * rb + HPR_BOUND_SLACK * ma) * (fabs(g.dir.x) + fabs(g.dir.y) + fabs(g.dir.z));
+        }
+        double myv = -1.0e300;
+        d3 sp = {0, 0, 0};
+        int si = -1;
+        bool have = false;
+        for (unsigned long long rm = run; rm != 0ull; rm &= rm - 1ull) {
+            const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rm));
+#ifdef PD_HPR_STATS
+            unsigned long long* ncp = &cand_chunks;
+#else
+            unsigned long long* ncp = nullptr;
+#endif
+            const Support r = support_scan<false>(fx, fy, fz, sidx, NS, boxes, lane_f64(g.dir.x, k), lane_f64(g.dir.y, k), lane_f64(g.dir.z, k),
+                                                  lane_f64(thr, k), __builtin_amdgcn_readlane(q, k), 0.0, 0.0, 0.0, s_cand[wave], lane, ncp);
+            if (lane == k) { myv = r.val; sp = d3{r.x, r.y, r.z}; si = r.idx; have = r.pos >= 0; }
+        }
+        if (g.state == 0) gjk_round(g, pi, myv, have, sp, si, rb);
+    }
+#ifdef PD_HPR_STATS
+    if (lane == 0) { atomicAdd(&g_hpr_stats[1][0], 1ull); atomicAdd(&g_hpr_stats[1][1], (unsigned long long)wave_rounds); atomicAdd(&g_hpr_stats[1][5], cand_chunks); }
+    if (owner) { atomicAdd(&g_hpr_stats[1][2], 1ull); atomicAdd(&g_hpr_stats[1][3], (unsigned long long)my_rounds);
+                 if (g.state == 0) atomicAdd(&g_hpr_stats[1][4], 1ull);
+                 atomicAdd(&g_hpr_stats[1][8 + min(my_rounds, 63) / 8], 1ull); }
+#endif
+    if (owner) {
+        vis[(size_t)v * N + q] = (g.state == 1) ? 1 : 0;
+        if (g.state == 0 || g.state == 3) {                           // round cap reached / not certifiable: the fallback passes
+            const int pos = atomicAdd(&unc_count[v], 1);
+            unc_list[(size_t)v * N + pos] = q;
+            int* sd = unc_seed + ((size_t)v * N + pos) * 4;           // the simplex it stopped at seeds the fallback
+            sd[0] = g.dim >= 1 ? g.ic : -2; sd[1] = g.dim >= 2 ? g.ib : -2; sd[2] = g.dim >= 3 ? g.id : -2; sd[3] = -2;
+        }
+    }
+}
+
+// ---- level 2 for SHORT query lists (the pipeline's case: only depth-rejected points are queried; a few hundred per view).
+// There the kernel time is the longest query's chain of dependent rounds, so a round must not wait on memory: one wavefront
+// per query keeps a WORKING SET in registers -- the 256 support points around the query in the sorted order, four per lane,
+// plus every point a global scan has returned -- and the GJK iteration takes its support points from that set.  Any point of
+// S_i that passes the origin is a legitimate next vertex, and "enclosed" is certified on real points as always; only the
+// "visible" verdict needs the whole support set: when the working set is separated from the origin in direction d, one
+// box-culled global scan looks for points with d.p' >= d.p'_i - tol (next to a hull vertex that is one or two chunks).  If it
+// finds none the verdict is certified exactly as in the general kernel, otherwise the point joins the working set.
+#define HPR_LOCAL 4
+__global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+                                                        const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
+                                                        const int* __restrict__ sidx_all, const int* __restrict__ scount,
+                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of, int q_lo, int q_hi,
+                                                        const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
+                                                        int* __restrict__ unc_list, int* __restrict__ unc_seed) {
+    __shared__ int s_cand[4][256];
+    const int v = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nq = count[v];
+    const int qi = blockIdx.x * 4 + wave;
+    if (qi >= nq || nq < q_lo || nq >= q_hi) return;
+    const double* qf = flipped + (size_t)v * 3 * N;
+    const double* fx = ss + (size_t)v * 3 * N;
+    const double* fy = fx + N;
+    const double* fz = fy + N;
+    const int* sidx = sidx_all + (size_t)v * N;
+    const int NS = scount[v];
+    const float4* boxes = boxes_all + (size_t)v * ((N + 63) >> 6) * (HPR_BOX_FLOATS / 4);
+    const int q = list[(size_t)v * N + qi];
+    const d3 pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]};
+    const double ma = __longlong_as_double((long long)maxabs[v]);
+    const double rb = ma * (8.0 * 1.1102230246251565e-16);
+    // working set (the query itself and the tail past NS are left out: index -2 never wins)
+    const int pq = pos_of[(size_t)v * N + q];
+    const int base = max(0, min((pq & ~63) - 64, ((NS + 63) & ~63) - 64 * HPR_LOCAL));
+    double lx[HPR_LOCAL + 1], ly[HPR_LOCAL + 1], lz[HPR_LOCAL + 1];
+    int li[HPR_LOCAL + 1];
+#pragma unroll
+    for (int u = 0; u < HPR_LOCAL; ++u) {
+        const int j = base + u * 64 + lane;
+        const int jc = min(j, NS - 1);
+        lx[u] = fx[jc]; ly[u] = fy[jc]; lz[u] = fz[jc];
+        const int id = sidx[jc];
+        li[u] = (j < NS && id != q) ? id : -2;
+    }
+    lx[HPR_LOCAL] = ly[HPR_LOCAL] = lz[HPR_LOCAL] = 0.0; li[HPR_LOCAL] = -2;       // the slot for what the global scans return
+    int n_extra = 0;
+    Gjk<double> g;                                                // (identical in every lane)
+    g.sa = g.sb = g.sc = g.sd = d3{0, 0, 0}; g.dir = pi;          // start looking straight out along the point's own ray
+    g.ia = g.ib = g.ic = g.id = -1;
+    g.dim = 0;
+    g.state = 0;
+#ifdef PD_HPR_STATS
+    int my_rounds = 0;
+    unsigned long long cand_chunks = 0, scans = 0;
+#endif
+    for (int round = 0; round < GJK_MAX_ROUNDS && g.state == 0; ++round) {
+#ifdef PD_HPR_STATS
+        ++my_rounds;
+#endif
+        const double dx = g.dir.x, dy = g.dir.y, dz = g.dir.z;
+        double best = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u <= HPR_LOCAL; ++u) {
+            const double val = fma(dz, lz[u], fma(dy, ly[u], dx * lx[u]));
+            if (li[u] != -2 && (val > best || (val == best && li[u] < bidx))) { best = val; bidx = li[u]; bx = lx[u]; by = ly[u]; bz = lz[u]; }
+        }
+        double myv = wave_max_f64(best);
+        int si = wave_min_i32(best == myv ? bidx : 0x7fffffff);
+        const unsigned long long who = __ballot(best == myv && bidx == si && bidx != 0x7fffffff);
+        bool have = who != 0ull;
+        d3 sp = {0, 0, 0};
+        if (have) {
+            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(who));
+            sp = d3{lane_f64(bx, src), lane_f64(by, src), lane_f64(bz, src)};
+        }
+        const double di = fma(dz, pi.z, fma(dy, pi.y, dx * pi.x));
+        const double l1 = fabs(dx) + fabs(dy) + fabs(dz);
+        if (di - ((have && myv > 0.0) ? myv : 0.0) > 0.0) {
+            // the working set does not pass the origin in this direction: does any point of the support set?
+            const double th = di - (2.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+#ifdef PD_HPR_STATS
+            ++scans;
+            unsigned long long* ncp = &cand_chunks;
+#else
+            unsigned long long* ncp = nullptr;
+#endif
+            const Support r = support_scan<false>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp);
+            if (r.pos >= 0 && (!have || r.val > myv || (r.val == myv && r.idx < si))) {
+                myv = r.val; si = r.idx; sp = d3{r.x, r.y, r.z}; have = true;
+                if (lane == n_extra) { lx[HPR_LOCAL] = r.x; ly[HPR_LOCAL] = r.y; lz[HPR_LOCAL] = r.z; li[HPR_LOCAL] = r.idx; }
+                n_extra = min(n_extra + 1, 64);
+            }
+        }
+        gjk_round(g, pi, myv, have, sp, si, rb);
+    }
+#ifdef PD_HPR_STATS
+    if (lane == 0) { atomicAdd(&g_hpr_stats[1][0], 1ull); atomicAdd(&g_hpr_stats[1][1], (unsigned long long)my_rounds); atomicAdd(&g_hpr_stats[1][5], cand_chunks);
+                     atomicAdd(&g_hpr_stats[1][6], scans);
+                     atomicAdd(&g_hpr_stats[1][2], 1ull); atomicAdd(&g_hpr_stats[1][3], (unsigned long long)my_rounds);
+                     if (g.state == 0) atomicAdd(&g_hpr_stats[1][4], 1ull);
+                     atomicAdd(&g_hpr_stats[1][8 + min(my_rounds, 63) / 8], 1ull); }
+#endif
+    if (lane == 0) {
+        vis[(size_t)v * N + q] = (g.state == 1) ? 1 : 0;
+        if (g.state == 0 || g.state == 3) {                           // round cap reached / not certifiable: the fallback passes
+            const int pos = atomicAdd(&unc_count[v], 1);
+            unc_list[(size_t)v * N + pos] = q;
+            int* sd = unc_seed + ((size_t)v * N + pos) * 4;           // the simplex it stopped at seeds the fallback
+            sd[0] = g.dim >= 1 ? g.ic : -2; sd[1] = g.dim >= 2 ? g.ib : -2; sd[2] = g.dim >= 3 ? g.id : -2; sd[3] = -2;
+        }
     }
 }
 
@@ -466,17 +762,50 @@ template <typename T> __device__ bool closest_simplex(Simplex<T>& S, v3<T>& v) {
     return true;
 }
 
-// ---- exact fallback: one 512-lane block per query the f64 pass could not certify.  Same iteration, double-double state and
-// double-double support values over the same support set (any superset of the hull vertices), duplicates of the query with a
-// larger cloud index excluded from S_i (of coinciding points the smallest index is the hull vertex), up to 512 rounds.
+// ---- fallback: one 512-lane block per query the boolean iteration could not certify (almost always: it cycled until the round
+// cap).  The distance iteration above over the same support set (any superset of the hull vertices), first in f64 with the f64
+// certificates (T = double), and for what that cannot certify in double-double (T = dd: exact differences, 2^-104 arithmetic,
+// 2^-96 bounds, up to 512 rounds).  Duplicates of the query with a larger cloud index are excluded from S_i (of coinciding
+// points the smallest index is the hull vertex).
+template <typename T> struct Num;
+template <> struct Num<double> {
+    static __device__ __forceinline__ double from(double a) { return a; }
+    static __device__ __forceinline__ double diff(double a, double b) { return a - b; }
+    static __device__ __forceinline__ bool gt(double a, double b) { return a > b; }
+    static __device__ __forceinline__ bool eq(double a, double b) { return a == b; }
+    static __device__ __forceinline__ double shfl(double a, int off) { return __shfl_xor(a, off); }
+    static __device__ __forceinline__ double lowest() { return -1.0e300; }
+    static constexpr double RB = 8.0 * 1.1102230246251565e-16;          // support value: <= 3.01 u |d|_1 max|coordinate| per side
+    static constexpr double STALL = 1.0e-11;
+    static constexpr int ROUNDS = 96;
+};
+template <> struct Num<dd> {
+    static __device__ __forceinline__ dd from(double a) { return dd_from(a); }
+    static __device__ __forceinline__ dd diff(double a, double b) { return dd_diff(a, b); }
+    static __device__ __forceinline__ bool gt(dd a, dd b) { return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo); }
+    static __device__ __forceinline__ bool eq(dd a, dd b) { return a.hi == b.hi && a.lo == b.lo; }
+    static __device__ __forceinline__ dd shfl(dd a, int off) { return dd{__shfl_xor(a.hi, off), __shfl_xor(a.lo, off)}; }
+    static __device__ __forceinline__ dd lowest() { return dd{-1.0e300, 0.0}; }
+    static constexpr double RB = 1.2621774483536189e-29;                 // 2^-96
+    static constexpr double STALL = 8.0e-25;
+    static constexpr int ROUNDS = 512;
+};
+template <typename T>
 __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ flipped, int N, const int* __restrict__ unc_count,
                                                    const int* __restrict__ unc_list, const int* __restrict__ unc_seed, uint8_t* __restrict__ vis,
                                                    const double* __restrict__ ss, const int* __restrict__ sidx_all, int scap,
-                                                   const int* __restrict__ scount, const unsigned long long* __restrict__ maxabs,
-                                                   int* __restrict__ counters /*[V][4]: exact queries, unresolved, rounds, -*/) {
+                                                   const int* __restrict__ scount, const float4* __restrict__ boxes_all,
+                                                   const int* __restrict__ pos_of, const unsigned long long* __restrict__ maxabs,
+                                                   int* __restrict__ next_count, int* __restrict__ next_list, int* __restrict__ next_seed,
+                                                   int* __restrict__ counters /*[V][4]: dd queries, unresolved, dd rounds, f64-distance queries*/) {
+    typedef Num<T> NT;
+    constexpr bool WAVE = sizeof(T) == sizeof(double);      // f64 stage: one wavefront per query, box-culled scans (support_scan)
+    __shared__ int s_cand[256];
+    const float4* boxes = boxes_all + (size_t)blockIdx.y * ((scap + 63) >> 6) * (HPR_BOX_FLOATS / 4);
+    const double ma = __longlong_as_double((long long)maxabs[blockIdx.y]);
     const int v = blockIdx.y;
     const int nq = unc_count[v];
-    __shared__ double s_hi[8], s_lo[8];
+    __shared__ T s_b[8];
     __shared__ int s_i[8];
     const double* fx = ss + (size_t)v * 3 * scap;
     const double* fy = fx + scap;
@@ -484,17 +813,32 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
     const int* sidx = sidx_all + (size_t)v * scap;
     const int NS = scount[v];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double rb = __longlong_as_double((long long)maxabs[v]) * 1.2621774483536189e-29;          // 2^-96 max|coordinate|
+    const double rb = __longlong_as_double((long long)maxabs[v]) * NT::RB;
     for (int u = blockIdx.x; u < nq; u += gridDim.x) {
         const int q = unc_list[(size_t)v * N + u];
         const double px = flipped[(size_t)v * 3 * N + q], py = flipped[(size_t)v * 3 * N + N + q], pz = flipped[(size_t)v * 3 * N + 2 * (size_t)N + q];
-        Simplex<dd> S;
+        double lx[HPR_LOCAL + 1], ly[HPR_LOCAL + 1], lz[HPR_LOCAL + 1];
+        int li[HPR_LOCAL + 1], n_extra = 0;
+        if constexpr (WAVE) {          // working set: the 256 support points around the query in the sorted order + what the global scans return
+            const int pq = pos_of[(size_t)v * N + q];
+            const int base = max(0, min((pq & ~63) - 64, ((NS + 63) & ~63) - 64 * HPR_LOCAL));
+#pragma unroll
+            for (int u = 0; u < HPR_LOCAL; ++u) {
+                const int j = base + u * 64 + lane;
+                const int jc = min(j, NS - 1);
+                lx[u] = fx[jc]; ly[u] = fy[jc]; lz[u] = fz[jc];
+                const int id = sidx[jc];
+                li[u] = (j < NS && id != q && !(id > q && lx[u] == px && ly[u] == py && lz[u] == pz)) ? id : -2;
+            }
+            lx[HPR_LOCAL] = ly[HPR_LOCAL] = lz[HPR_LOCAL] = 0.0; li[HPR_LOCAL] = -2;
+        }
+        Simplex<T> S;
         S.n = 0;
-        v3<dd> dir = {dd_from(px), dd_from(py), dd_from(pz)};         // first direction: straight out along the point's own ray
-        v3<dd> vclose = dir;
+        v3<T> dir = {NT::from(px), NT::from(py), NT::from(pz)};         // first direction: straight out along the point's own ray
+        v3<T> vclose = dir;
         int state = 0;                  // 0 running, 1 visible (certified), 2 hidden (certified), 3 not certifiable
         int rounds = 0;
-        {   // seed: the vertices the f64 iteration stopped at (cloud indices, -1 = the eye) -- its closest point is the start
+        {   // seed: the vertices the previous pass stopped at (cloud indices, -1 = the eye) -- its closest point is the start
             const int* sd = unc_seed + ((size_t)v * N + u) * 4;
             const double* cx = flipped + (size_t)v * 3 * N;
             for (int k = 0; k < 3; ++k) {
@@ -503,8 +847,8 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
                 bool dup = false;
                 for (int m = 0; m < S.n; ++m) dup = dup || S.idx[m] == id;
                 if (dup) continue;
-                v3<dd> a = id >= 0 ? v3<dd>{dd_diff(cx[id], px), dd_diff(cx[N + id], py), dd_diff(cx[2 * (size_t)N + id], pz)}
-                                   : v3<dd>{dd_from(-px), dd_from(-py), dd_from(-pz)};
+                v3<T> a = id >= 0 ? v3<T>{NT::diff(cx[id], px), NT::diff(cx[N + id], py), NT::diff(cx[2 * (size_t)N + id], pz)}
+                                  : v3<T>{NT::from(-px), NT::from(-py), NT::from(-pz)};
                 if (zero3(a)) continue;
                 for (int m = S.n; m > 0; --m) { S.w[m] = S.w[m - 1]; S.idx[m] = S.idx[m - 1]; }
                 S.w[0] = a; S.idx[0] = id; ++S.n;
@@ -512,119 +856,280 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
             if (S.n > 0 && closest_simplex(S, vclose) && !zero3(vclose)) dir = neg(vclose);
             else { S.n = 0; vclose = dir; }
         }
-        for (; rounds < 512 && state == 0; ++rounds) {
-            // support scan in double-double: (dx x + dy y) + dz z with exact inputs x, y, z
-            dd best = {-1.0e300, 0.0};
-            int bi = 0x7fffffff;
-            for (int j = threadIdx.x; j < NS; j += 512) {
-                const double x = fx[j], y = fy[j], zz = fz[j];
-                const int jo = sidx[j];
-                if (jo == q || (jo > q && x == px && y == py && zz == pz)) continue;
-                const dd val = (dir.x * dd_from(x) + dir.y * dd_from(y)) + dir.z * dd_from(zz);
-                if (val.hi > best.hi || (val.hi == best.hi && val.lo > best.lo)) { best = val; bi = j; }
-            }
+        for (; rounds < NT::ROUNDS && state == 0; ++rounds) {
+            T best = NT::lowest();
+            double spx = 0.0, spy = 0.0, spz = 0.0;           // the support point and its cloud index
+            int spi = -1;
+            bool have = false;
+            if constexpr (WAVE) {
+                // the working set first (see k_hpr_fine_local); the whole support set only when its answer is not enough
+                const double dxx = sgn_of(dir.x), dyy = sgn_of(dir.y), dzz = sgn_of(dir.z);
+                const double dpi = fma(dzz, pz, fma(dyy, py, dxx * px));
+                const double l1 = fabs(dxx) + fabs(dyy) + fabs(dzz);
+                double lb = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0;
+                int bidx = 0x7fffffff;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double oh = __shfl_xor(best.hi, off), ol = __shfl_xor(best.lo, off);
-                const int oi = __shfl_xor(bi, off);
-                if (oh > best.hi || (oh == best.hi && (ol > best.lo || (ol == best.lo && oi < bi)))) { best = dd{oh, ol}; bi = oi; }
-            }
-            __syncthreads();
-            if (lane == 0) { s_hi[wave] = best.hi; s_lo[wave] = best.lo; s_i[wave] = bi; }
-            __syncthreads();
-            best = dd{s_hi[0], s_lo[0]}; bi = s_i[0];
+                for (int u = 0; u <= HPR_LOCAL; ++u) {
+                    const double val = fma(dzz, lz[u], fma(dyy, ly[u], dxx * lx[u]));
+                    if (li[u] != -2 && (val > lb || (val == lb && li[u] < bidx))) { lb = val; bidx = li[u]; bx = lx[u]; by = ly[u]; bz = lz[u]; }
+                }
+                double m = wave_max_f64(lb);
+                int mi = wave_min_i32(lb == m ? bidx : 0x7fffffff);
+                const unsigned long long who = __ballot(lb == m && bidx == mi && bidx != 0x7fffffff);
+                have = who != 0ull;
+                if (have) {
+                    const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(who));
+                    spx = lane_f64(bx, src); spy = lane_f64(by, src); spz = lane_f64(bz, src); spi = mi;
+                }
+                bool weak = true;                                 // separated / repeated vertex / no progress: ask the whole set
+                if (have && m > 0.0 && dpi - m <= 0.0) {
+                    weak = false;
+                    for (int k = 0; k < S.n; ++k) weak = weak || S.idx[k] == spi;
+                    if (S.n > 0 && !weak) {
+                        const v3<T> al = {NT::diff(spx, px), NT::diff(spy, py), NT::diff(spz, pz)};
+                        const T vv = dot(vclose, vclose), va = dot(vclose, al);
+                        weak = sgn_of(vv - va) <= 0.0 || mag_of(vv - va) <= NT::STALL * mag_of(vv);
+                    }
+                } else if (!(have && m > 0.0) && dpi <= 0.0) weak = false;       // the eye passes the origin: it is the support
+                if (weak) {
+                    // nothing below the working set's best, a simplex vertex's value or the eye's can be the support
+                    double thr = have ? fmax(m, 0.0) : 0.0;
+                    for (int k = 0; k < S.n; ++k) thr = fmax(thr, sgn_of(dot(dir, S.w[k])) + dpi);
+                    thr -= (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+#ifdef PD_HPR_STATS
+                    unsigned long long ncand = 0;
+                    const Support r = support_scan<true>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, &ncand);
+                    if (lane == 0) { atomicAdd(&g_hpr_stats[0][5], ncand); atomicAdd(&g_hpr_stats[0][6], 1ull); }
+#else
+                    const Support r = support_scan<true>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, nullptr);
+#endif
+                    if (r.pos >= 0 && (!have || r.val > m || (r.val == m && r.idx < mi))) {
+                        have = true; m = r.val; spx = r.x; spy = r.y; spz = r.z; spi = r.idx;
+                        if (lane == n_extra) { lx[HPR_LOCAL] = r.x; ly[HPR_LOCAL] = r.y; lz[HPR_LOCAL] = r.z; li[HPR_LOCAL] = r.idx; }
+                        n_extra = min(n_extra + 1, 64);
+                    }
+                }
+                if (have) best = NT::from(m);
+            } else {
+                // support scan: (dx x + dy y) + dz z with exact inputs x, y, z
+                int bi = 0x7fffffff;
+                for (int j = threadIdx.x; j < NS; j += 512) {
+                    const double x = fx[j], y = fy[j], zz = fz[j];
+                    const int jo = sidx[j];
+                    if (jo == q || (jo > q && x == px && y == py && zz == pz)) continue;
+                    const T val = (dir.x * NT::from(x) + dir.y * NT::from(y)) + dir.z * NT::from(zz);
+                    if (NT::gt(val, best)) { best = val; bi = j; }
+                }
 #pragma unroll
-            for (int w = 1; w < 8; ++w) {
-                const double oh = s_hi[w], ol = s_lo[w];
-                const int oi = s_i[w];
-                if (oh > best.hi || (oh == best.hi && (ol > best.lo || (ol == best.lo && oi < bi)))) { best = dd{oh, ol}; bi = oi; }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const T ob = NT::shfl(best, off);
+                    const int oi = __shfl_xor(bi, off);
+                    if (NT::gt(ob, best) || (NT::eq(ob, best) && oi < bi)) { best = ob; bi = oi; }
+                }
+                __syncthreads();
+                if (lane == 0) { s_b[wave] = best; s_i[wave] = bi; }
+                __syncthreads();
+                best = s_b[0]; bi = s_i[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    const T ob = s_b[w];
+                    const int oi = s_i[w];
+                    if (NT::gt(ob, best) || (NT::eq(ob, best) && oi < bi)) { best = ob; bi = oi; }
+                }
+                have = bi < NS;
+                if (have) { spx = fx[bi]; spy = fy[bi]; spz = fz[bi]; spi = sidx[bi]; }
             }
             // every lane runs the identical state machine on the merged result
-            const bool real = sgn_of(best) > 0.0 && bi < NS;
-            const dd di = (dir.x * dd_from(px) + dir.y * dd_from(py)) + dir.z * dd_from(pz);
-            const dd gap = real ? di - best : di;
+            const bool real = have && sgn_of(best) > 0.0;
+            const T di = (dir.x * NT::from(px) + dir.y * NT::from(py)) + dir.z * NT::from(pz);
+            const T gap = real ? di - best : di;
             const double tol = rb * (mag_of(dir.x) + mag_of(dir.y) + mag_of(dir.z));
             if (sgn_of(gap) > 0.0 && mag_of(gap) > tol) { state = 1; break; }          // separating direction, certified
-            v3<dd> a;
+            v3<T> a;
             int ai = -1;
-            if (real) { a = v3<dd>{dd_diff(fx[bi], px), dd_diff(fy[bi], py), dd_diff(fz[bi], pz)}; ai = sidx[bi]; }
-            else a = v3<dd>{dd_from(-px), dd_from(-py), dd_from(-pz)};
+            if (real) { a = v3<T>{NT::diff(spx, px), NT::diff(spy, py), NT::diff(spz, pz)}; ai = spi; }
+            else a = v3<T>{NT::from(-px), NT::from(-py), NT::from(-pz)};
             if (zero3(a)) { state = real ? 2 : 3; break; }     // coincides with a point of smaller index (larger ones are excluded): that one is the vertex
             bool seen = false;
             for (int k = 0; k < S.n; ++k) seen = seen || S.idx[k] == ai;
             if (S.n > 0) {
                 // no progress: the support does not get closer to the origin than the closest point already found =>
                 // vclose IS the closest point of conv(S_i): the origin is outside, but by less than the certificate can show
-                const dd vv = dot(vclose, vclose), va = dot(vclose, a);
-                if (seen || sgn_of(vv - va) <= 0.0 || mag_of(vv - va) <= 8.0e-25 * mag_of(vv)) { state = 3; break; }
+                const T vv = dot(vclose, vclose), va = dot(vclose, a);
+                if (seen || sgn_of(vv - va) <= 0.0 || mag_of(vv - va) <= NT::STALL * mag_of(vv)) { state = 3; break; }
             }
             // newest vertex first (Ericson's region tests are written around vertex a)
             for (int k = S.n; k > 0; --k) { S.w[k] = S.w[k - 1]; S.idx[k] = S.idx[k - 1]; }
             S.w[0] = a; S.idx[0] = ai; ++S.n;
             if (!closest_simplex(S, vclose)) {
-                // origin inside the tetrahedron (in double-double): certify p'_i strictly inside with the four determinants
+                // origin inside the tetrahedron (in this arithmetic): certify p'_i strictly inside with the four determinants
                 const int s0 = -det_sign(S.w[1], S.w[2], S.w[3]), s1 = det_sign(S.w[0], S.w[2], S.w[3]),
                           s2 = -det_sign(S.w[0], S.w[1], S.w[3]), s3 = det_sign(S.w[0], S.w[1], S.w[2]);
                 state = (s0 != 0 && s0 == s1 && s1 == s2 && s2 == s3) ? 2 : 3;
                 break;
             }
-            if (zero3(vclose)) { state = 3; break; }          // the origin lies ON a face / edge of the simplex: exactly degenerate input
+            if (zero3(vclose)) { state = 3; break; }          // the origin lies ON a face / edge of the simplex within this arithmetic
             dir = neg(vclose);
         }
-        struct { int state; } g = {state};
+#ifdef PD_HPR_STATS
+        if (threadIdx.x == 0 && next_count != nullptr) atomicAdd(&g_hpr_stats[1][7], (unsigned long long)rounds);
+#endif
         if (threadIdx.x == 0) {
-            vis[(size_t)v * N + q] = g.state == 1 ? 1 : 0;
-            atomicAdd(&counters[4 * v], 1);
-            if (g.state != 1 && g.state != 2) atomicAdd(&counters[4 * v + 1], 1);      // not certifiable even in double-double
-            atomicAdd(&counters[4 * v + 2], rounds);
+            const bool settled = state == 1 || state == 2;
+            if (next_count != nullptr) {                         // f64 stage: what it cannot certify goes on to double-double
+                atomicAdd(&counters[4 * v + 3], 1);
+                if (settled) vis[(size_t)v * N + q] = state == 1 ? 1 : 0;
+                else {
+                    const int pos = atomicAdd(&next_count[v], 1);
+                    next_list[(size_t)v * N + pos] = q;
+                    int* sd = next_seed + ((size_t)v * N + pos) * 4;
+                    for (int k = 0; k < 4; ++k) sd[k] = k < 3 && k < S.n ? S.idx[k] : -2;
+                }
+            } else {
+                vis[(size_t)v * N + q] = state == 1 ? 1 : 0;
+                atomicAdd(&counters[4 * v], 1);
+                if (!settled) atomicAdd(&counters[4 * v + 1], 1);      // not certifiable even in double-double
+                atomicAdd(&counters[4 * v + 2], rounds);
+            }
         }
         __syncthreads();
     }
 }
 
-// second-level inputs: the support set = all points outside the coarse hull (coordinates + original index), and the query list =
-// those of them that no cheaper test accepted.  One workgroup per view walks the cloud in order (ballot ranks + a running
-// offset): both lists come out in ascending cloud order, which is what lets the support scan drop its index tie-break.
-// Members of the coarse set (outside == 2) are certain hull vertices: marked visible here, supports but never queries.
-__global__ __launch_bounds__(1024) void k_hpr_build(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside,
-                                                    const uint8_t* __restrict__ skip, double* __restrict__ ss, int* __restrict__ sidx,
-                                                    int* __restrict__ scount, int* __restrict__ count2, int* __restrict__ list2,
-                                                    uint8_t* __restrict__ vis) {
-    __shared__ int s_o[16], s_q[16];
-    const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ---- level-2 inputs.  Support set = every point the coarse hull does not certainly enclose (coarse-set members, points the
+// cheaper test accepted, queries level 1 could not settle); query list = those of them without a verdict yet.  The support set is
+// counting-sorted by the Morton code of its cell in a 32^3 grid over the view's bounding box (order inside a cell is whatever the
+// atomics give: the scans break ties by cloud index, so the results do not depend on it), then boxed per 64 points.
+#define HPR_CELL_BITS 5
+#define HPR_NCELL (1 << (3 * HPR_CELL_BITS))
+__device__ __forceinline__ int spread3(int x) {                               // 5 bits -> every third bit
+    x = (x | (x << 8)) & 0x0300f; x = (x | (x << 4)) & 0x030c3; x = (x | (x << 2)) & 0x09249;
+    return x;
+}
+// outside == nullptr: one-level mode, every point is a support point and every not-skipped point a query
+__global__ void k_hpr_bin(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside, const uint8_t* __restrict__ skip,
+                          const unsigned long long* __restrict__ bbox /*[V][6] keys of max(-x,-y,-z), max(x,y,z)*/, int* __restrict__ cellkey,
+                          int* __restrict__ hist, int* __restrict__ count2, int* __restrict__ list2, uint8_t* __restrict__ vis) {
+    __shared__ int s_wcnt[4], s_base;
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* f = flipped + (size_t)v * 3 * N;
-    double* so = ss + (size_t)v * 3 * N;
-    int base_o = 0, base_q = 0;
-    for (int i0 = 0; i0 < N; i0 += 1024) {
-        const int i = i0 + threadIdx.x;
-        const uint8_t o = i < N ? outside[(size_t)v * N + i] : 0;
-        const bool sk = i < N && skip != nullptr && skip[(size_t)v * N + i];
-        const bool out = o != 0, qry = o == 1 && !sk;
-        if (o == 2 && !sk) vis[(size_t)v * N + i] = 1;
-        const unsigned long long bo = __ballot(out), bq = __ballot(qry);
-        if (lane == 0) { s_o[wave] = __popcll(bo); s_q[wave] = __popcll(bq); }
-        __syncthreads();
-        int po = base_o, pq = base_q, to = 0, tq = 0;
+    double lo[3], sc[3];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            po += w < wave ? s_o[w] : 0; pq += w < wave ? s_q[w] : 0;
-            to += s_o[w]; tq += s_q[w];
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = -key_f64(bbox[6 * v + k]);
+        const double ext = key_f64(bbox[6 * v + 3 + k]) - lo[k];
+        sc[k] = ext > 0.0 ? (double)(1 << HPR_CELL_BITS) / ext : 0.0;
+    }
+    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < N;
+        const uint8_t o = in ? (outside ? outside[(size_t)v * N + i] : 1) : 0;
+        const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
+        const bool out = in && (o != 0 || sk), qry = o == 1 && !sk;
+        if (o == 2 && !sk) vis[(size_t)v * N + i] = 1;             // coarse-set member: a certain hull vertex
+        if (in) {
+            int key = -1;
+            if (out) {
+                int cxyz[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cxyz[k] = min((1 << HPR_CELL_BITS) - 1, max(0, (int)((f[(size_t)k * N + i] - lo[k]) * sc[k])));
+                key = spread3(cxyz[0]) | (spread3(cxyz[1]) << 1) | (spread3(cxyz[2]) << 2);
+                atomicAdd(&hist[(size_t)v * HPR_NCELL + key], 1);
+            }
+            cellkey[(size_t)v * N + i] = key;
         }
-        if (out) {
-            const int pos = po + __popcll(bo & ((1ull << lane) - 1ull));
-            so[pos] = f[i]; so[N + pos] = f[N + i]; so[2 * (size_t)N + pos] = f[2 * (size_t)N + i];
-            sidx[(size_t)v * N + pos] = i;
-        }
-        if (qry) list2[(size_t)v * N + pq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
-        base_o += to; base_q += tq;
+        const unsigned long long bal = __ballot(qry);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = atomicAdd(&count2[v], s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        if (qry) list2[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { scount[v] = base_o; count2[v] = base_q; }
+}
+// exclusive prefix sum of a view's cell histogram, in place; scount = the number of support points
+__global__ __launch_bounds__(1024) void k_hpr_cellscan(int* __restrict__ hist, int* __restrict__ scount) {
+    __shared__ int s_w[16];
+    const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PER = HPR_NCELL / 1024;
+    int* h = hist + (size_t)v * HPR_NCELL + threadIdx.x * PER;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { loc[k] = h[k]; sum += loc[k]; }
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = inc - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { base += w < wave ? s_w[w] : 0; total += s_w[w]; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { h[k] = base; base += loc[k]; }
+    if (threadIdx.x == 0) scount[v] = total;
+}
+__global__ void k_hpr_scatter(const double* __restrict__ flipped, int N, const int* __restrict__ cellkey, int* __restrict__ cellpos,
+                              double* __restrict__ ss, int* __restrict__ sidx, int* __restrict__ pos_of) {
+    const int v = blockIdx.y;
+    const double* f = flipped + (size_t)v * 3 * N;
+    double* so = ss + (size_t)v * 3 * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int key = cellkey[(size_t)v * N + i];
+        if (key < 0) continue;
+        const int pos = atomicAdd(&cellpos[(size_t)v * HPR_NCELL + key], 1);
+        so[pos] = f[i]; so[N + pos] = f[N + i]; so[2 * (size_t)N + pos] = f[2 * (size_t)N + i];
+        sidx[(size_t)v * N + pos] = i;
+        pos_of[(size_t)v * N + i] = pos;
+    }
+}
+// oriented bounding box of every 64 consecutive support points: one wavefront per chunk.  Axes (f32): e0 = the chunk's mean
+// direction from the eye, e1, e2 = tangents; extents = min / max of the f64 projections on the axes AS STORED, rounded outwards.
+__device__ __forceinline__ float f32_below(double a) {                      // largest f32 <= a
+    float f = (float)a;
+    if ((double)f > a) f = f > 0.0f ? __uint_as_float(__float_as_uint(f) - 1u) : (f < 0.0f ? __uint_as_float(__float_as_uint(f) + 1u) : -1.0e-45f);
+    return f;
+}
+__global__ __launch_bounds__(256) void k_hpr_boxes(const double* __restrict__ ss, int N, const int* __restrict__ scount, float4* __restrict__ boxes) {
+    const int v = blockIdx.y, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int NS = scount[v];
+    if ((c << 6) >= NS) return;
+    const int j = min((c << 6) + lane, NS - 1);                   // (a clamped duplicate cannot change a min / max)
+    const double* f = ss + (size_t)v * 3 * N;
+    const double x = f[j], y = f[N + j], z = f[2 * (size_t)N + j];
+    float sx = (float)x, sy = (float)y, sz = (float)z;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off); }
+    float e[3][3];
+    const float n0 = sqrtf(sx * sx + sy * sy + sz * sz);
+    if (n0 > 0.0f && n0 < 3.0e38f) { e[0][0] = sx / n0; e[0][1] = sy / n0; e[0][2] = sz / n0; }
+    else { e[0][0] = 0.0f; e[0][1] = 0.0f; e[0][2] = 1.0f; }
+    const float ax = fabsf(e[0][0]), ay = fabsf(e[0][1]), az = fabsf(e[0][2]);
+    float hx = 0.0f, hy = 0.0f, hz = 0.0f;                        // the world axis least aligned with e0
+    if (ax <= ay && ax <= az) hx = 1.0f; else if (ay <= az) hy = 1.0f; else hz = 1.0f;
+    float tx = e[0][1] * hz - e[0][2] * hy, ty = e[0][2] * hx - e[0][0] * hz, tz = e[0][0] * hy - e[0][1] * hx;
+    const float n1 = sqrtf(tx * tx + ty * ty + tz * tz);
+    e[1][0] = tx / n1; e[1][1] = ty / n1; e[1][2] = tz / n1;
+    e[2][0] = e[0][1] * e[1][2] - e[0][2] * e[1][1]; e[2][1] = e[0][2] * e[1][0] - e[0][0] * e[1][2]; e[2][2] = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = ((double)e[k][0] * x + (double)e[k][1] * y) + (double)e[k][2] * z;
+        hi[k] = -f32_below(-wave_max_f64(a)); lo[k] = f32_below(-wave_max_f64(-a));
+    }
+    if (lane == 0) {
+        float4* b = boxes + ((size_t)v * ((N + 63) >> 6) + c) * (HPR_BOX_FLOATS / 4);
+        b[0] = make_float4(e[0][0], e[0][1], e[0][2], e[1][0]); b[1] = make_float4(e[1][1], e[1][2], e[2][0], e[2][1]);
+        b[2] = make_float4(e[2][2], lo[0], lo[1], lo[2]); b[3] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
 }
 
 // coarse support set: the extreme point of the flipped cloud in each of KC Fibonacci-sphere directions (ties: smallest index)
-__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, int KC, double* __restrict__ cs,
-                                                      int* __restrict__ cidx, uint8_t* __restrict__ mark) {
+__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, int KC, float4* __restrict__ csf,
+                                                      double* __restrict__ csd /*[V][KC][4]: the same points in f64*/, int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/,
+                                                      uint8_t* __restrict__ mark) {
     const int v = blockIdx.y;
     const double* fx = flipped + (size_t)v * 3 * N;
     const double* fy = fx + N;
@@ -698,14 +1203,17 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
         }
         if (lane == 0 && k0 + k < KC) {
             // The hull is that of the cloud AND the eye (the origin of the flipped space): in a direction where every point
-            // has a negative projection the origin is the extreme element, not a cloud point -- the slot then holds the origin
-            // (support value 0, which the GJK step already treats as "the origin").  Otherwise the point is a certain hull
-            // vertex: member of the coarse set, marked 2, never queried.
-            double* c = cs + (size_t)v * 3 * KC;
-            const bool real = b > 0.0;
-            c[k0 + k] = real ? fx[id] : 0.0; c[KC + k0 + k] = real ? fy[id] : 0.0; c[2 * (size_t)KC + k0 + k] = real ? fz[id] : 0.0;
-            cidx[(size_t)v * KC + k0 + k] = real ? id : -1;
-            if (real) mark[(size_t)v * N + id] = 2;
+            // has a negative projection the origin is the extreme element, not a cloud point (the GJK step supplies the eye
+            // itself, support value 0).  Otherwise the point is a certain hull vertex: it joins the coarse set the first time a
+            // direction finds it (many directions share their extreme point), is marked 2 and never queried.
+            if (b > 0.0 && atomicExch(&claim[(size_t)v * N + id], 1) == 0) {
+                const int pos = atomicAdd(&kcount[v], 1);
+                csf[(size_t)v * KC + pos] = make_float4((float)fx[id], (float)fy[id], (float)fz[id], 0.0f);
+                double* cd = csd + ((size_t)v * KC + pos) * 4;
+                cd[0] = fx[id]; cd[1] = fy[id]; cd[2] = fz[id]; cd[3] = 0.0;
+                cidx[(size_t)v * KC + pos] = id;
+                mark[(size_t)v * N + id] = 2;
+            }
         }
     }
 }
@@ -713,15 +1221,14 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t flipped_bytes(int V, int N) { return a256((size_t)V * 3 * (size_t)(N > 0 ? N : 1) * sizeof(double)); }
 static size_t lists_bytes(int V, int N) { return a256((size_t)V * ((size_t)N + 64) * sizeof(int)); }
-#define HPR_HEAD_BYTES 2048      // workspace head: counters int[64][4] (exact-fallback queries, unresolved, rounds, -) + maxabs u64[64]
+static size_t boxes_bytes(int V, int N) { return a256((size_t)V * (size_t)((N + 63) / 64 + 1) * HPR_BOX_FLOATS * sizeof(float)); }
+static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int)); }
+// workspace head: counters int[64][4] (double-double queries, unresolved, double-double rounds, f64 distance-iteration queries),
+// maxabs u64[64] at 1024, bounding-box keys u64[64][6] at 2048
+#define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
-    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 8 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * 3 * HPR_KC * sizeof(double)) +
-           a256((size_t)V * HPR_KC * sizeof(int));
-}
-
-__global__ void k_hpr_fill_count(int* __restrict__ c, int V, int N) { if ((int)threadIdx.x < V) c[threadIdx.x] = N; }
-__global__ void k_hpr_iota(int* __restrict__ idx, int N) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) idx[(size_t)blockIdx.y * N + i] = i;
+    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) +
+           a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V);
 }
 
 extern "C" int pdhip_hidden_point_removal(const float* points, int N, const double* eyes_dev, int V, double radius,
@@ -733,43 +1240,58 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     hipStream_t s = as_stream(stream);
     char* p = reinterpret_cast<char*>(ws);
     int* counters = reinterpret_cast<int*>(p);
-    unsigned long long* maxabs = reinterpret_cast<unsigned long long*>(p + 1024); p += HPR_HEAD_BYTES;
+    unsigned long long* maxabs = reinterpret_cast<unsigned long long*>(p + 1024);
+    unsigned long long* bbox = reinterpret_cast<unsigned long long*>(p + 2048); p += HPR_HEAD_BYTES;
     double* flipped = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
-    double* ss = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);          // second-level support set (outside points)
+    double* ss = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);          // level-2 support set, cell-sorted
     int* count = reinterpret_cast<int*>(p); int* list = count + 64; p += lists_bytes(V, N);
     int* count2 = reinterpret_cast<int*>(p); int* list2 = count2 + 64; p += lists_bytes(V, N);
     int* scount = reinterpret_cast<int*>(p); int* sidx = scount + 64; p += lists_bytes(V, N);
-    int* ucount = reinterpret_cast<int*>(p); int* ulist = ucount + 64; p += lists_bytes(V, N);      // queries for the exact fallback
+    int* ucount = reinterpret_cast<int*>(p); int* ulist = ucount + 64; p += lists_bytes(V, N);      // queries for the f64 distance iteration
     int* useed = reinterpret_cast<int*>(p); p += 4 * lists_bytes(V, N);                               // ... and the simplex each stopped at
+    int* u2count = reinterpret_cast<int*>(p); int* u2list = u2count + 64; p += lists_bytes(V, N);   // queries for the double-double iteration
+    int* u2seed = reinterpret_cast<int*>(p); p += 4 * lists_bytes(V, N);
+    int* kcount = reinterpret_cast<int*>(p); int* cellkey = kcount + 64; p += lists_bytes(V, N);
+    int* pos_of = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
     uint8_t* outside = reinterpret_cast<uint8_t*>(p); p += a256((size_t)V * N);
-    double* cs = reinterpret_cast<double*>(p); p += a256((size_t)V * 3 * HPR_KC * sizeof(double));
-    int* cidx = reinterpret_cast<int*>(p);
+    float4* csf = reinterpret_cast<float4*>(p); p += a256((size_t)V * HPR_KC * sizeof(float4));
+    double* csd = reinterpret_cast<double*>(p); p += a256((size_t)V * HPR_KC * 4 * sizeof(double));
+    int* cidx = reinterpret_cast<int*>(p); p += a256((size_t)V * HPR_KC * sizeof(int));
+    float4* boxes = reinterpret_cast<float4*>(p); p += boxes_bytes(V, N);
+    int* hist = reinterpret_cast<int*>(p);
     dim3 gf(min(cdiv(N, 256), 256), V);
     PD_HIP(hipMemsetAsync(ws, 0, HPR_HEAD_BYTES, s));
-    k_hpr_flip<<<gf, 256, 0, s>>>(points, N, eyes_dev, radius, flipped, maxabs);
+    k_hpr_flip<<<dim3(min(cdiv(N, 256), 32), V), 256, 0, s>>>       // (few waves: each ends with seven atomics on the view's extrema)
+       (points, N, eyes_dev, radius, flipped, maxabs, bbox);
     PD_HIP(hipMemsetAsync(count, 0, 64 * sizeof(int), s));
     PD_HIP(hipMemsetAsync(count2, 0, 64 * sizeof(int), s));
-    PD_HIP(hipMemsetAsync(scount, 0, 64 * sizeof(int), s));
     PD_HIP(hipMemsetAsync(ucount, 0, 64 * sizeof(int), s));
+    PD_HIP(hipMemsetAsync(u2count, 0, 64 * sizeof(int), s));
+    PD_HIP(hipMemsetAsync(hist, 0, (size_t)V * HPR_NCELL * sizeof(int), s));
     k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);      // marks the skipped points visible; `list` = the queries
-    dim3 gg(cdiv(N, 4 * QPW), V), gg4(cdiv(min(N, HPR_NARROW_BELOW), 4), V), gx(32, V);
     constexpr int KC = HPR_KC;
-    if (N > 4 * HPR_KC) {            // the coarse level pays off only when the cloud is much larger than the coarse set
+    const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
+    if (two_level) {
         dim3 ge(cdiv(KC, QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
-        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, cs, cidx, outside);
-        k_hpr_gjk<true, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, nullptr, nullptr, nullptr, cs, cidx, KC, nullptr, outside, 0, 0x7fffffff, skip, maxabs, nullptr, nullptr, nullptr);
-        k_hpr_build<<<V, 1024, 0, s>>>(flipped, N, outside, skip, ss, sidx, scount, count2, list2, visibility);
-        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist, useed);
-        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist, useed);
-        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, maxabs, counters);
-    } else {                         // one level: support set = the whole cloud
-        k_hpr_iota<<<gf, 256, 0, s>>>(sidx, N);
-        k_hpr_fill_count<<<1, 64, 0, s>>>(scount, V, N);
-        k_hpr_gjk<false, QPW, false, 4><<<gg, 256, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, HPR_NARROW_BELOW, 0x7fffffff, nullptr, maxabs, ucount, ulist, useed);
-        k_hpr_gjk<false, 4, true, HPR_COOP_WAVES><<<gg4, HPR_COOP_WAVES * 64, 0, s>>>(flipped, N, count, list, visibility, flipped, sidx, N, scount, nullptr, 0, HPR_NARROW_BELOW, nullptr, maxabs, ucount, ulist, useed);
-        k_hpr_exact<<<gx, 512, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, flipped, sidx, N, scount, maxabs, counters);
+        PD_HIP(hipMemsetAsync(kcount, 0, 64 * sizeof(int), s));
+        PD_HIP(hipMemsetAsync(csf, 0, (size_t)V * HPR_KC * sizeof(float4), s));       // entries past the set's end: the eye
+        PD_HIP(hipMemsetAsync(pos_of, 0, (size_t)V * N * sizeof(int), s));       // (the extremes' claim flags until the scatter fills it)
+        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, csf, csd, cidx, kcount, pos_of, outside);
+        k_hpr_coarse<<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs);
     }
+    k_hpr_bin<<<gf, 256, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
+    k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
+    k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
+    k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
+    // level 2: 16 queries per wavefront when there are enough of them to fill the chip, one otherwise
+    const int narrow = max(1, 32768 / V);
+    k_hpr_fine<16><<<dim3(cdiv(N, 64), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, narrow, 0x7fffffff,
+                                                        maxabs, ucount, ulist, useed);
+    k_hpr_fine_local<<<dim3(cdiv(min(N, narrow), 4), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, 0, narrow,
+                                                                      maxabs, ucount, ulist, useed);
+    k_hpr_exact<double><<<dim3(64, V), 64, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, u2count, u2list, u2seed, counters);
+    k_hpr_exact<dd><<<dim3(32, V), 512, 0, s>>>(flipped, N, u2count, u2list, u2seed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, nullptr, nullptr, nullptr, counters);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -33,7 +33,8 @@ try:
     fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_hpr_stats
     buf = (C.c_ulonglong * 32)()
     fn(buf, 1); got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=vis0); torch.cuda.synchronize(); fn(buf, 1)
+    print('f64 distance iteration: scans', buf[6], 'candidate chunks', buf[5])
     for name, b in (('coarse', buf[0:16]), ('fine', buf[16:32])):
-        print(f'{name}: waves {b[0]} mean wave rounds {b[1] / max(b[0], 1):.1f}; queries {b[2]} mean query rounds {b[3] / max(b[2], 1):.1f}; unfinished {b[4]}; rounds histogram (x8) {list(b[8:16])}')
+        print(f'{name}: waves {b[0]} mean wave rounds {b[1] / max(b[0], 1):.1f}; queries {b[2]} mean query rounds {b[3] / max(b[2], 1):.1f}; unfinished {b[4]}; rounds histogram (x8) {list(b[8:16])}; candidate chunks per query round {b[5] / max(b[3], 1):.1f}; global scans per query {b[6] / max(b[2], 1):.2f}; f64 distance-iteration rounds {b[7]}')
 except AttributeError:
     pass
