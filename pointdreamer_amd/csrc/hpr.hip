@@ -28,12 +28,13 @@
 #include "common.h"
 using namespace pdhip;
 
-#define QPW 16                 // query points per wavefront
 #define GJK_MAX_ROUNDS 64
 #ifndef GJK_COARSE_ROUNDS
-#define GJK_COARSE_ROUNDS 16
+#define GJK_COARSE_ROUNDS 10     // level 1 gives up early: a wave pays every round for all 64 lanes, level 2 costs one wave per leftover (8: 0.69, 10: 0.60, 16: 0.66 ms)
 #endif
-#define HPR_KC 1024            // coarse support set size
+#ifndef HPR_KC
+#define HPR_KC 1024            // coarse support set size (directions tried; a multiple of 256)
+#endif
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
 __device__ unsigned long long g_hpr_stats[2][16];             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
@@ -465,105 +466,6 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
     return r;
 }
 
-// Q queries per wavefront live in lanes 0..Q-1; their scans run one after the other on all 64 lanes (direction, threshold and
-// query index wave-uniform in SGPRs), the GJK step then runs on the Q lanes at once.  Q = 1 for short query lists (the pipeline's
-// case: only depth-rejected points are queried), where the kernel time is the longest query's chain of dependent rounds.
-template <int Q>
-__global__ __launch_bounds__(256) void k_hpr_fine(const double* __restrict__ flipped, int N, const int* __restrict__ count,
-                                                  const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
-                                                  const int* __restrict__ sidx_all, const int* __restrict__ scount,
-                                                  const float4* __restrict__ boxes_all, const int* __restrict__ pos_of, int q_lo, int q_hi,
-                                                  const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
-                                                  int* __restrict__ unc_list, int* __restrict__ unc_seed) {
-    __shared__ int s_cand[4][256];
-    const int v = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nq = count[v];
-    const int q0 = (blockIdx.x * 4 + wave) * Q;
-    if (q0 >= nq || nq < q_lo || nq >= q_hi) return;
-    const double* qf = flipped + (size_t)v * 3 * N;
-    const double* fx = ss + (size_t)v * 3 * N;
-    const double* fy = fx + N;
-    const double* fz = fy + N;
-    const int* sidx = sidx_all + (size_t)v * N;
-    const int NS = scount[v];
-    const float4* boxes = boxes_all + (size_t)v * ((N + 63) >> 6) * (HPR_BOX_FLOATS / 4);
-    const bool owner = lane < Q && q0 + lane < nq;
-    const int q = owner ? list[(size_t)v * N + q0 + lane] : -1;
-    d3 pi = {0, 0, 0};
-    Gjk<double> g;
-    g.sa = g.sb = g.sc = g.sd = d3{0, 0, 0}; g.dir = d3{0, 0, 1};
-    g.ia = g.ib = g.ic = g.id = -1;
-    g.dim = 0;
-    g.state = owner ? 0 : 2;
-    const double ma = __longlong_as_double((long long)maxabs[v]);
-    const double rb = ma * (8.0 * 1.1102230246251565e-16);
-    double nbx = 0.0, nby = 0.0, nbz = 0.0;                       // the neighbour in the sorted order: seeds the first round's bound
-    bool have_nb = false;
-    if (owner) {
-        pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]};
-        g.dir = pi;                                               // start looking straight out along the point's own ray
-        const int pq = pos_of[(size_t)v * N + q];
-        int nb = pq ^ 1;
-        if (nb >= NS) nb = pq - 1;
-        if (nb >= 0 && nb != pq) { nbx = fx[nb]; nby = fy[nb]; nbz = fz[nb]; have_nb = true; }
-    }
-#ifdef PD_HPR_STATS
-    int my_rounds = 0, wave_rounds = 0;
-    unsigned long long cand_chunks = 0;
-#endif
-    for (int round = 0; round < GJK_MAX_ROUNDS; ++round) {
-        const unsigned long long run = __ballot(g.state == 0);
-        if (run == 0ull) break;
-#ifdef PD_HPR_STATS
-        ++wave_rounds; if (g.state == 0) ++my_rounds;
-#endif
-        // a value some point of S_i certainly attains in this direction (0: the eye), less the rounding of that estimate and of the bound
-        double thr = 0.0;
-        {
-            const double dpi = fma(g.dir.z, pi.z, fma(g.dir.y, pi.y, g.dir.x * pi.x));
-            if (g.dim == 0) { if (have_nb) thr = fmax(thr, fma(g.dir.z, nbz, fma(g.dir.y, nby, g.dir.x * nbx))); }
-            else {
-                thr = fmax(thr, dot(g.dir, g.sc) + dpi);
-                if (g.dim >= 2) thr = fmax(thr, dot(g.dir, g.sb) + dpi);
-                if (g.dim >= 3) thr = fmax(thr, dot(g.dir, g.sd) + dpi);
-            }
-            thr -= (4.0 * rb + HPR_BOUND_SLACK * ma) * (fabs(g.dir.x) + fabs(g.dir.y) + fabs(g.dir.z));
-        }
-        double myv = -1.0e300;
-        d3 sp = {0, 0, 0};
-        int si = -1;
-        bool have = false;
-        for (unsigned long long rm = run; rm != 0ull; rm &= rm - 1ull) {
-            const int k = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rm));
-#ifdef PD_HPR_STATS
-            unsigned long long* ncp = &cand_chunks;
-#else
-            unsigned long long* ncp = nullptr;
-#endif
-            const Support r = support_scan<false>(fx, fy, fz, sidx, NS, boxes, lane_f64(g.dir.x, k), lane_f64(g.dir.y, k), lane_f64(g.dir.z, k),
-                                                  lane_f64(thr, k), __builtin_amdgcn_readlane(q, k), 0.0, 0.0, 0.0, s_cand[wave], lane, ncp);
-            if (lane == k) { myv = r.val; sp = d3{r.x, r.y, r.z}; si = r.idx; have = r.pos >= 0; }
-        }
-        if (g.state == 0) gjk_round(g, pi, myv, have, sp, si, rb);
-    }
-#ifdef PD_HPR_STATS
-    if (lane == 0) { atomicAdd(&g_hpr_stats[1][0], 1ull); atomicAdd(&g_hpr_stats[1][1], (unsigned long long)wave_rounds); atomicAdd(&g_hpr_stats[1][5], cand_chunks); }
-    if (owner) { atomicAdd(&g_hpr_stats[1][2], 1ull); atomicAdd(&g_hpr_stats[1][3], (unsigned long long)my_rounds);
-                 if (g.state == 0) atomicAdd(&g_hpr_stats[1][4], 1ull);
-                 atomicAdd(&g_hpr_stats[1][8 + min(my_rounds, 63) / 8], 1ull); }
-#endif
-    if (owner) {
-        vis[(size_t)v * N + q] = (g.state == 1) ? 1 : 0;
-        if (g.state == 0 || g.state == 3) {                           // round cap reached / not certifiable: the fallback passes
-            const int pos = atomicAdd(&unc_count[v], 1);
-            unc_list[(size_t)v * N + pos] = q;
-            int* sd = unc_seed + ((size_t)v * N + pos) * 4;           // the simplex it stopped at seeds the fallback
-            sd[0] = g.dim >= 1 ? g.ic : -2; sd[1] = g.dim >= 2 ? g.ib : -2; sd[2] = g.dim >= 3 ? g.id : -2; sd[3] = -2;
-        }
-    }
-}
-
 // ---- level 2 for SHORT query lists (the pipeline's case: only depth-rejected points are queried; a few hundred per view).
 // There the kernel time is the longest query's chain of dependent rounds, so a round must not wait on memory: one wavefront
 // per query keeps a WORKING SET in registers -- the 256 support points around the query in the sorted order, four per lane,
@@ -576,7 +478,7 @@ __global__ __launch_bounds__(256) void k_hpr_fine(const double* __restrict__ fli
 __global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                         const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
                                                         const int* __restrict__ sidx_all, const int* __restrict__ scount,
-                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of, int q_lo, int q_hi,
+                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of,
                                                         const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
                                                         int* __restrict__ unc_list, int* __restrict__ unc_seed) {
     __shared__ int s_cand[4][256];
@@ -584,7 +486,7 @@ __global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nq = count[v];
     const int qi = blockIdx.x * 4 + wave;
-    if (qi >= nq || nq < q_lo || nq >= q_hi) return;
+    if (qi >= nq) return;
     const double* qf = flipped + (size_t)v * 3 * N;
     const double* fx = ss + (size_t)v * 3 * N;
     const double* fy = fx + N;
@@ -1025,8 +927,7 @@ __global__ void k_hpr_bin(const double* __restrict__ flipped, int N, const uint8
         const bool in = i < N;
         const uint8_t o = in ? (outside ? outside[(size_t)v * N + i] : 1) : 0;
         const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
-        const bool out = in && (o != 0 || sk), qry = o == 1 && !sk;
-        if (o == 2 && !sk) vis[(size_t)v * N + i] = 1;             // coarse-set member: a certain hull vertex
+        const bool out = in && (o != 0 || sk), qry = o != 0 && !sk;
         if (in) {
             int key = -1;
             if (out) {
@@ -1126,96 +1027,94 @@ __global__ __launch_bounds__(256) void k_hpr_boxes(const double* __restrict__ ss
     }
 }
 
-// coarse support set: the extreme point of the flipped cloud in each of KC Fibonacci-sphere directions (ties: smallest index)
-__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, int KC, float4* __restrict__ csf,
-                                                      double* __restrict__ csd /*[V][KC][4]: the same points in f64*/, int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/,
-                                                      uint8_t* __restrict__ mark) {
-    const int v = blockIdx.y;
+// ---- coarse set: the extreme point of the flipped cloud in each of KC Fibonacci-sphere directions, without repeats.  Any set of
+// cloud points serves level 1 (its only verdict is certified on the points themselves, and its members are queried like every
+// other point), so this is the same approximate f32 GEMM + column maximum as the level-1 scan: A = 32 points, B = 64 of the
+// directions, a wave keeps the best tile per lane and locates the row afterwards.  The cloud is cut into HPR_EXT_POINTS-point
+// slabs (one wave per slab and 64 directions); the slabs meet in an atomicMax on (value, index) keys.
+#define HPR_EXT_POINTS 2048
+__device__ __forceinline__ unsigned int f32_key(float x) { const unsigned int b = __float_as_uint(x); return (b >> 31) ? ~b : (b | 0x80000000u); }
+__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, unsigned long long* __restrict__ keys /*[V][KC], zeroed*/) {
+    const int v = blockIdx.z, lane = threadIdx.x & 63, l31 = lane & 31;
+    const bool hi = lane >= 32;
+    const int grp = blockIdx.y * 4 + (threadIdx.x >> 6);                  // 64 directions
+    const int p_lo = blockIdx.x * HPR_EXT_POINTS, p_hi = min(N, p_lo + HPR_EXT_POINTS);
+    if (grp * 64 >= HPR_KC || p_lo >= N) return;
     const double* fx = flipped + (size_t)v * 3 * N;
     const double* fy = fx + N;
     const double* fz = fy + N;
-    // a block owns QPW directions; its four waves scan a quarter of the cloud each and merge through LDS (KC / QPW blocks of
-    // 4 waves per view fill the chip, one wave per QPW directions did not: 300 -> 100 us)
-    __shared__ double s_b[4][QPW];
-    __shared__ int s_i[4][QPW];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k0 = blockIdx.x * QPW;
-    if (k0 >= KC) return;
-    double dx[QPW], dy[QPW], dz[QPW], best[QPW];
-    int bi[QPW];
-    // the block's QPW Fibonacci directions: one lane each (f64 sin / cos of a large argument are hundreds of instructions; every
-    // lane computing all of them was most of this kernel's time), shared through LDS
-    __shared__ double s_d[QPW][3];
-    if (threadIdx.x < QPW) {
-        const int kk = min(k0 + (int)threadIdx.x, KC - 1);
-        const double z = 1.0 - (2.0 * kk + 1.0) / KC, r = sqrt(fmax(0.0, 1.0 - z * z)), phi = kk * 2.399963229728653;
-        s_d[threadIdx.x][0] = r * cos(phi); s_d[threadIdx.x][1] = r * sin(phi); s_d[threadIdx.x][2] = z;
+    float x0, y0, z0, x1, y1, z1;                                          // the lane's two directions (query columns l31 and 32 + l31)
+    {
+        const int k0 = grp * 64 + l31, k1 = k0 + 32;
+        const double za = 1.0 - (2.0 * k0 + 1.0) / HPR_KC, ra = sqrt(fmax(0.0, 1.0 - za * za)), pa = k0 * 2.399963229728653;
+        const double zb = 1.0 - (2.0 * k1 + 1.0) / HPR_KC, rb = sqrt(fmax(0.0, 1.0 - zb * zb)), pb = k1 * 2.399963229728653;
+        x0 = (float)(ra * cos(pa)); y0 = (float)(ra * sin(pa)); z0 = (float)za;
+        x1 = (float)(rb * cos(pb)); y1 = (float)(rb * sin(pb)); z1 = (float)zb;
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < QPW; ++k) {
-        dx[k] = s_d[k][0]; dy[k] = s_d[k][1]; dz[k] = s_d[k][2];
-        best[k] = -1.0e300; bi[k] = 0x7fffffff;
+    const float b1_0 = hi ? y0 : x0, b2_0 = hi ? 0.0f : z0, b1_1 = hi ? y1 : x1, b2_1 = hi ? 0.0f : z1;
+    const f32x16 zero = {0};
+    float best0 = -3.0e38f, best1 = -3.0e38f;
+    int t0 = 0, t1 = 0;
+    const double* fa = hi ? fy : fx;                                       // lane l: A[point l & 31][k = l >> 5]: x | y, then z | 0
+    double na, nz, nc, nw;                                                 // the next trip's operands are requested a trip ahead
+    {
+        const int ja = min(p_lo + l31, N - 1), jb = min(p_lo + 32 + l31, N - 1);      // (a repeated point cannot change a maximum)
+        na = fa[ja]; nz = fz[ja]; nc = fa[jb]; nw = fz[jb];
     }
-    // four points per lane in flight: with two waves per SIMD a single dependent load per iteration leaves the L2 latency exposed
-    for (int j = wave * 64 + lane; j < N; j += 1024) {
-        double x[4], y[4], z[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ju = min(j + u * 256, N - 1);                   // (a clamped duplicate cannot change an argmax)
-            x[u] = fx[ju]; y[u] = fy[ju]; z[u] = fz[ju];
+    for (int j0 = p_lo; j0 < p_hi; j0 += 64) {                            // two tiles per trip
+        const float a1 = (float)na, a2 = hi ? 0.0f : (float)nz, c1 = (float)nc, c2 = hi ? 0.0f : (float)nw;
+        {
+            const int ja = min(j0 + 64 + l31, N - 1), jb = min(j0 + 96 + l31, N - 1);
+            na = fa[ja]; nz = fz[ja]; nc = fa[jb]; nw = fz[jb];
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ju = j + u * 256;
-            if (ju < N) {
-#pragma unroll
-                for (int k = 0; k < QPW; ++k) {
-                    const double val = dx[k] * x[u] + dy[k] * y[u] + dz[k] * z[u];
-                    if (val > best[k]) { best[k] = val; bi[k] = ju; }
-                }
-            }
-        }
+        f32x16 A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0), A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);
+        f32x16 B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_0, zero, 0, 0, 0), B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_1, zero, 0, 0, 0);
+        A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, A1, 0, 0, 0);
+        B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_0, B0, 0, 0, 0); B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_1, B1, 0, 0, 0);
+        const float ma0 = tile_max(A0), ma1 = tile_max(A1), mb0 = tile_max(B0), mb1 = tile_max(B1);
+        if (ma0 > best0) { best0 = ma0; t0 = j0; }
+        if (ma1 > best1) { best1 = ma1; t1 = j0; }
+        if (mb0 > best0) { best0 = mb0; t0 = j0 + 32; }
+        if (mb1 > best1) { best1 = mb1; t1 = j0 + 32; }
     }
+    // the row inside the best tile: the lane's 16 rows, the same fmaf chain (bitwise the matrix core's values)
+    int i0 = -1, i1 = -1;
+    {
+        float r0 = -3.0e38f, r1 = -3.0e38f;
 #pragma unroll
-    for (int k = 0; k < QPW; ++k) {
-        double b = best[k];
-        int id = bi[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(b, off);
-            const int oi = __shfl_xor(id, off);
-            if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
-        }
-        if (lane == 0) { s_b[wave][k] = b; s_i[wave][k] = id; }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int k = 0; k < QPW; ++k) {
-        double b = s_b[0][k];
-        int id = s_i[0][k];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const double ob = s_b[w][k];
-            const int oi = s_i[w][k];
-            if (ob > b || (ob == b && oi < id)) { b = ob; id = oi; }
-        }
-        if (lane == 0 && k0 + k < KC) {
-            // The hull is that of the cloud AND the eye (the origin of the flipped space): in a direction where every point
-            // has a negative projection the origin is the extreme element, not a cloud point (the GJK step supplies the eye
-            // itself, support value 0).  Otherwise the point is a certain hull vertex: it joins the coarse set the first time a
-            // direction finds it (many directions share their extreme point), is marked 2 and never queried.
-            if (b > 0.0 && atomicExch(&claim[(size_t)v * N + id], 1) == 0) {
-                const int pos = atomicAdd(&kcount[v], 1);
-                csf[(size_t)v * KC + pos] = make_float4((float)fx[id], (float)fy[id], (float)fz[id], 0.0f);
-                double* cd = csd + ((size_t)v * KC + pos) * 4;
-                cd[0] = fx[id]; cd[1] = fy[id]; cd[2] = fz[id]; cd[3] = 0.0;
-                cidx[(size_t)v * KC + pos] = id;
-                mark[(size_t)v * N + id] = 2;
-            }
+        for (int i = 0; i < 16; ++i) {
+            const int row = 8 * (i / 4) + (i % 4) + (hi ? 4 : 0);
+            const int ja = min(t0 + row, N - 1), jb = min(t1 + row, N - 1);
+            const float w0 = fmaf((float)fz[ja], z0, fmaf((float)fy[ja], y0, (float)fx[ja] * x0));
+            const float w1 = fmaf((float)fz[jb], z1, fmaf((float)fy[jb], y1, (float)fx[jb] * x1));
+            if (w0 > r0) { r0 = w0; i0 = ja; }
+            if (w1 > r1) { r1 = w1; i1 = jb; }
         }
     }
+    // both half-waves hold a candidate for the same two directions: let the atomics join them (ties: the smaller index)
+    unsigned long long* kv = keys + (size_t)v * HPR_KC + grp * 64;
+    if (i0 >= 0) atomicMax(&kv[l31], ((unsigned long long)f32_key(best0) << 32) | (unsigned int)(0x7fffffff - i0));
+    if (i1 >= 0) atomicMax(&kv[32 + l31], ((unsigned long long)f32_key(best1) << 32) | (unsigned int)(0x7fffffff - i1));
+}
+// The hull is that of the cloud AND the eye (the origin of the flipped space): in a direction where every point has a negative
+// projection the eye is the extreme element and no point is taken (the GJK step supplies the eye itself, support value 0).
+// A point joins the coarse set the first time a direction finds it (many directions share their extreme point).
+__global__ void k_hpr_extremes_fin(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ keys,
+                                   float4* __restrict__ csf, double* __restrict__ csd /*[V][KC][4]: the same points in f64*/,
+                                   int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/) {
+    const int v = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= HPR_KC) return;
+    const unsigned long long key = keys[(size_t)v * HPR_KC + k];
+    const unsigned int vb = (unsigned int)(key >> 32);
+    const int id = 0x7fffffff - (int)(unsigned int)(key & 0xffffffffu);
+    if (vb <= 0x80000000u || id < 0 || id >= N) return;                   // no point with a positive projection
+    if (atomicExch(&claim[(size_t)v * N + id], 1) != 0) return;
+    const double* f = flipped + (size_t)v * 3 * N;
+    const int pos = atomicAdd(&kcount[v], 1);
+    csf[(size_t)v * HPR_KC + pos] = make_float4((float)f[id], (float)f[N + id], (float)f[2 * (size_t)N + id], 0.0f);
+    double* cd = csd + ((size_t)v * HPR_KC + pos) * 4;
+    cd[0] = f[id]; cd[1] = f[N + id]; cd[2] = f[2 * (size_t)N + id]; cd[3] = 0.0;
+    cidx[(size_t)v * HPR_KC + pos] = id;
 }
 
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1227,7 +1126,7 @@ static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int
 // maxabs u64[64] at 1024, bounding-box keys u64[64][6] at 2048
 #define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
-    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) +
+    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
            a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V);
 }
 
@@ -1256,6 +1155,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     uint8_t* outside = reinterpret_cast<uint8_t*>(p); p += a256((size_t)V * N);
     float4* csf = reinterpret_cast<float4*>(p); p += a256((size_t)V * HPR_KC * sizeof(float4));
     double* csd = reinterpret_cast<double*>(p); p += a256((size_t)V * HPR_KC * 4 * sizeof(double));
+    unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_KC * sizeof(unsigned long long));
     int* cidx = reinterpret_cast<int*>(p); p += a256((size_t)V * HPR_KC * sizeof(int));
     float4* boxes = reinterpret_cast<float4*>(p); p += boxes_bytes(V, N);
     int* hist = reinterpret_cast<int*>(p);
@@ -1272,24 +1172,20 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     constexpr int KC = HPR_KC;
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     if (two_level) {
-        dim3 ge(cdiv(KC, QPW), V);
         PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
         PD_HIP(hipMemsetAsync(kcount, 0, 64 * sizeof(int), s));
         PD_HIP(hipMemsetAsync(csf, 0, (size_t)V * HPR_KC * sizeof(float4), s));       // entries past the set's end: the eye
+        PD_HIP(hipMemsetAsync(ekeys, 0, (size_t)V * HPR_KC * sizeof(unsigned long long), s));
         PD_HIP(hipMemsetAsync(pos_of, 0, (size_t)V * N * sizeof(int), s));       // (the extremes' claim flags until the scatter fills it)
-        k_hpr_extremes<<<ge, 256, 0, s>>>(flipped, N, KC, csf, csd, cidx, kcount, pos_of, outside);
+        k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, ekeys);
+        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of);
         k_hpr_coarse<<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs);
     }
     k_hpr_bin<<<gf, 256, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
     k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
     k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
-    // level 2: 16 queries per wavefront when there are enough of them to fill the chip, one otherwise
-    const int narrow = max(1, 32768 / V);
-    k_hpr_fine<16><<<dim3(cdiv(N, 64), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, narrow, 0x7fffffff,
-                                                        maxabs, ucount, ulist, useed);
-    k_hpr_fine_local<<<dim3(cdiv(min(N, narrow), 4), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, 0, narrow,
-                                                                      maxabs, ucount, ulist, useed);
+    k_hpr_fine_local<<<dim3(cdiv(N, 4), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, maxabs, ucount, ulist, useed);
     k_hpr_exact<double><<<dim3(64, V), 64, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, u2count, u2list, u2seed, counters);
     k_hpr_exact<dd><<<dim3(32, V), 512, 0, s>>>(flipped, N, u2count, u2list, u2seed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, nullptr, nullptr, nullptr, counters);
     PD_LAUNCH_CHECK();
