@@ -96,14 +96,15 @@ int pdhip_point_visibility(int cam_res, const float* point_uvs /*[V,N,2]*/, cons
  *      skip (may be NULL): [V,N] u8; points already accepted by another test (demo.py:110 ORs the depth test with
  *      this one) are not queried and come back as 1, so the result is directly the OR-ed validation.
  *      Every verdict carries a floating-point certificate (separating direction / enclosing tetrahedron with error
- *      bounds); what f64 cannot certify is re-run in double-double arithmetic, so the result is the vertex set of the
- *      exact hull of the flipped points.  pdhip_hpr_read_counters (synchronises) reports, for the last call on `ws`:
- *      out[0] queries sent to the double-double fallback, out[1] queries not certifiable even there (exactly
- *      degenerate input; reported hidden), out[2] fallback rounds. */
+ *      bounds) on the f64 coordinates; what the f64 certificates cannot decide is re-run as a distance iteration, first in
+ *      f64, then in double-double arithmetic, so the result is the vertex set of the exact hull of the flipped points.
+ *      pdhip_hpr_read_counters (synchronises) reports, for the last call on `ws`, summed over the views: out[0] queries
+ *      sent to the double-double iteration, out[1] queries not certifiable even there (exactly degenerate input; reported
+ *      hidden), out[2] double-double rounds, out[3] queries sent to the f64 distance iteration. */
 size_t pdhip_hpr_ws_bytes(int V, int N);
 int pdhip_hidden_point_removal(const float* points /*[N,3]*/, int N, const double* eyes /*[V,3]*/, int V, double radius,
                                const uint8_t* skip, uint8_t* visibility, void* ws, void* stream);
-int pdhip_hpr_read_counters(const void* ws, int V, long long* out /*[3]*/, void* stream);
+int pdhip_hpr_read_counters(const void* ws, int V, long long* out /*[4]*/, void* stream);
 
 /* ---- demo.py:121-125: point_pixels = clip(long(uv*res)) as (row,col). */
 int pdhip_point_pixels(const float* point_uvs /*[V,N,2]*/, int V, int N, int res,

@@ -4,27 +4,30 @@
 //   flip:   q = p - eye,  p' = q + 2 (radius - |q|) q / |q|                       (float64, like open3d)
 //   visible(i)  <=>  p'_i is a vertex of conv({p'_j} U {0})  <=>  0 is NOT in conv(S_i),
 //                    S_i = {p'_j - p'_i : j != i} U {-p'_i}
-// Instead of building the hull (qhull: serial, incremental), every point answers its own containment question with a
-// boolean GJK iteration whose only heavy step is the support function  argmax_j  d . p'_j  -- an O(N) streaming
-// reduction.  One wavefront owns 16 query points: all 64 lanes stream the flipped cloud once per round (coalesced f64
-// SoA, L2-resident: 24 N bytes per view) and evaluate the 16 search directions against every point (48 f64 FMAs per
-// 24 bytes), the 16 GJK states live in lanes 0-15.  Work: ~10 rounds x N^2 x 3 FMA per view (f64 vector rate bound).
-// Two levels: ALL points are first tested against a COARSE support set -- the KC extreme points of the flipped cloud in KC
-// Fibonacci-sphere directions (one streaming pass; its members are certain hull vertices and are never queried).  conv(subset)
-// is inside conv(cloud), so "origin enclosed" there is already the final answer (hidden).  A point strictly inside conv(subset)
-// is also never a support point of the full cloud, so the second level -- only for the queries the coarse hull cannot enclose --
-// scans just the OUTSIDE set (~40 % of the cloud), compacted in cloud order so that the scan needs no index tie-break.  Short
-// query lists (the pipeline's case: only depth-rejected points are queried) run 4 queries per 256-lane block with the scan split
-// over the four waves.  30 k points x 8 views: 88 -> 15 ms for all points, 48 -> 2.4 ms behind the depth-test skip mask
-// (KC = 1024 measured best of 512..8192).
-// Every verdict is CERTIFIED: "visible" by a separating direction d with  d.p'_i - max(max_j d.p'_j, 0) > rounding bound,
-// "hidden" by a tetrahedron of cloud points (or the eye) whose four orientation determinants around p'_i pass Shewchuk's
-// static filter.  A verdict the f64 filter cannot certify, a degenerate simplex and a query still running at the round cap
-// go to k_hpr_exact: the same iteration in double-double arithmetic (2^-104) over the same support set, certified with
-// double-double bounds; what even that cannot certify (exact coplanarity / duplicate points) is counted in the workspace
-// counters (pdhip_hpr_read_counters) and reported hidden.  The result is therefore the vertex set of the exact hull of the
-// f64 flipped points; qhull (open3d, scipy) differs from it only for points within its own merge tolerance (~1e-13 * radius)
-// of a facet.  open3d itself is absent (PARITY UNPINNED); the oracle drives the same qhull through scipy.
+// Instead of building the hull (qhull: serial, incremental), every point answers its own containment question with a GJK
+// iteration.  Every verdict is CERTIFIED on the f64 coordinates: "visible" by a separating direction d with
+// d.p'_i - max(max_j d.p'_j, 0) > rounding bound, "hidden" by a tetrahedron of cloud points (or the eye) whose four
+// orientation determinants around p'_i pass Shewchuk's static filter.  How a candidate direction / tetrahedron is FOUND is free,
+// which is what the three levels exploit:
+//   level 1  k_hpr_extremes + k_hpr_coarse: all queries against a coarse set of <= 1024 cloud points (the extreme points in
+//            Fibonacci directions).  conv(subset) is inside conv(cloud): "enclosed" there is final.  Lane = query; the support
+//            scans are an f32 GEMM on the matrix cores (points x directions, v_mfma_f32_32x32x2_f32) followed by a column
+//            maximum -- approximate, but the verdict is certified on the true coordinates.  ~2/3 of a cloud ends here.
+//   level 2  k_hpr_fine_local: what level 1 could not enclose, against the points outside the coarse hull (a point strictly
+//            inside it is never a support point).  That set is Morton-sorted and cut into 64-point chunks with oriented boxes
+//            (the flipped cloud is a thin shell around the eye); one wavefront per query iterates on a register-resident
+//            working set of the 256 points around it and consults the whole set -- box-culled to a chunk or two -- only to
+//            certify "visible".
+//   level 3  k_hpr_exact<double>, k_hpr_exact<dd>: the few queries whose boolean iteration cycles or whose f64 certificate
+//            fails: the distance form of GJK (monotone, terminates), first in f64 with the same certificates, then in
+//            double-double arithmetic (2^-104) with 2^-96 bounds; what even that cannot certify (exact coplanarity /
+//            duplicate points) is counted in the workspace counters (pdhip_hpr_read_counters) and reported hidden.
+// The result is therefore the vertex set of the exact hull of the f64 flipped points; qhull (open3d, scipy) differs from it only
+// for points within its own merge tolerance (~1e-13 * radius) of a facet.  open3d itself is absent (PARITY UNPINNED); the oracle
+// drives the same qhull through scipy.  8 views x 30 k points behind the depth-test skip mask: 2.66 ms (round 2's first form:
+// wave-cooperative f64 scans) -> 0.56 ms; all points queried: 17 -> 1.5 ms.
+// The order of the sorted support set inside a Morton cell comes from atomics; the scans break ties by cloud index and every
+// verdict is certified, so the visibility does not depend on it (the fallback counters may differ by a query between runs).
 #include "common.h"
 using namespace pdhip;
 
@@ -1192,14 +1195,15 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     return PDHIP_OK;
 }
 
-// counters of the last pdhip_hidden_point_removal call that used `ws` (synchronises `stream`): out[0] = queries resolved by the
-// double-double fallback, out[1] = queries not certifiable even there (reported hidden), out[2] = fallback rounds, summed over views
-extern "C" int pdhip_hpr_read_counters(const void* ws, int V, long long* out /*[3]*/, void* stream) {
+// counters of the last pdhip_hidden_point_removal call that used `ws` (synchronises `stream`), summed over views: out[0] = queries
+// sent to the double-double iteration, out[1] = queries not certifiable even there (reported hidden), out[2] = double-double
+// rounds, out[3] = queries sent to the f64 distance iteration (level 3's first stage)
+extern "C" int pdhip_hpr_read_counters(const void* ws, int V, long long* out /*[4]*/, void* stream) {
     PD_REQUIRE(ws && out && V > 0 && V <= 64, "pdhip_hpr_read_counters: bad arguments");
     int h[64 * 4];
     PD_HIP(hipMemcpyAsync(h, ws, sizeof(int) * 4 * V, hipMemcpyDeviceToHost, as_stream(stream)));
     PD_HIP(hipStreamSynchronize(as_stream(stream)));
-    out[0] = out[1] = out[2] = 0;
-    for (int v = 0; v < V; ++v) { out[0] += h[4 * v]; out[1] += h[4 * v + 1]; out[2] += h[4 * v + 2]; }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int v = 0; v < V; ++v) { out[0] += h[4 * v]; out[1] += h[4 * v + 1]; out[2] += h[4 * v + 2]; out[3] += h[4 * v + 3]; }
     return PDHIP_OK;
 }

@@ -1,8 +1,8 @@
 """Row P3b: hidden-point removal (Katz et al.), the reference's Open3D call at ours_utils.py:204-225.
 
 The reference copies the cloud to the host and runs qhull once per view; here all views are answered on the device by
-`pdhip_hidden_point_removal` (csrc/hpr.hip): spherical flip in float64, then one boolean-GJK containment query per
-point whose support function is a streaming argmax over the flipped cloud."""
+`pdhip_hidden_point_removal` (csrc/hpr.hip): spherical flip in float64, then one certified GJK containment query per
+point -- against a coarse hull on the matrix cores first, then against the Morton-sorted points outside it."""
 import numpy as np
 import torch
 
@@ -13,7 +13,7 @@ from ._lib import ptr, as_u8, stream, check
 def hidden_point_removal(points, eye_positions, radius, already_valid=None, return_stats=False):
     """points [N,3] (GPU), eye_positions [V,3] (numpy / list, as create_cameras returns them) -> [V,N] bool.
     already_valid [V,N] bool (optional): points another test accepted; they are not queried and the result is the OR.
-    return_stats: also return dict(exact_fallback=, unresolved=, fallback_rounds=) of the certified-verdict machinery
+    return_stats: also return dict(exact_fallback=, unresolved=, fallback_rounds=, distance_f64=) of the certified-verdict machinery
     (synchronises; `unresolved` > 0 means exactly degenerate input whose verdict -- hidden -- is a convention)."""
     L = _lib.lib()
     pts = points.detach().float().contiguous()
@@ -29,7 +29,7 @@ def hidden_point_removal(points, eye_positions, radius, already_valid=None, retu
           'pdhip_hidden_point_removal')
     if return_stats:
         import ctypes as C
-        out = (C.c_longlong * 3)()
+        out = (C.c_longlong * 4)()
         check(L.pdhip_hpr_read_counters(ptr(ws), V, out, stream()), 'pdhip_hpr_read_counters')
-        return vis, dict(exact_fallback=int(out[0]), unresolved=int(out[1]), fallback_rounds=int(out[2]))
+        return vis, dict(exact_fallback=int(out[0]), unresolved=int(out[1]), fallback_rounds=int(out[2]), distance_f64=int(out[3]))
     return vis

@@ -314,6 +314,26 @@ def test_p3b_hidden_point_removal_vs_qhull(pd, n, shape):
     assert np.array_equal(N_(got2), got)
 
 
+def test_p3b_large_support_set(pd):
+    """100k points on a sphere, no skip mask: the level-2 support set (the points outside the coarse hull) spans more than 256
+    chunks, so the box-culled scans walk several chunk groups, and every point is a query of the working-set kernel."""
+    from pointdreamer_amd import hpr
+    n = 100000
+    pts, _ = pd['syn'].sphere_points(n, seed=11)
+    _, _, eyes, _ = pd['cu'].create_cameras(8, 1.6, 512, device=DEV)
+    eyes = eyes[:2]
+    got, st = hpr.hidden_point_removal(T(pts), eyes, 100, return_stats=True)
+    got = N_(got)
+    want = oproj.point_validation_by_hpr(pts, eyes, 100)
+    assert st['unresolved'] == 0, st
+    bad = np.argwhere(got != want)
+    for v, i in bad[:20]:
+        m = oproj.hpr_margin(oproj.hpr_flip(pts, eyes[v], 100), i)
+        assert abs(m) < 1e-9 and bool(got[v, i]) == (m > 0), (v, i, m)
+    assert len(bad) <= 2, (len(bad), st)
+    assert (want.sum(1) > 16384).all()                       # more hull vertices per view than 256 chunks hold
+
+
 def test_p3b_duplicates_and_tiny_clouds(pd):
     """Coinciding points: the smallest index is the hull vertex, the copies are hidden (qhull keeps one of them, which one is
     its processing order); clouds below the two-level threshold and of a handful of points take the one-level path."""
