@@ -13,13 +13,13 @@
 //            Fibonacci directions).  conv(subset) is inside conv(cloud): "enclosed" there is final.  Lane = query; the support
 //            scans are an f32 GEMM on the matrix cores (points x directions, v_mfma_f32_32x32x2_f32) followed by a column
 //            maximum -- approximate, but the verdict is certified on the true coordinates.  ~2/3 of a cloud ends here.
-//   level 2  k_hpr_fine_local: what level 1 could not enclose, against the points outside the coarse hull (a point strictly
+//   level 2  k_hpr_fine_dist: what level 1 could not enclose, against the points outside the coarse hull (a point strictly
 //            inside it is never a support point).  That set is Morton-sorted and cut into 64-point chunks with oriented boxes
-//            (the flipped cloud is a thin shell around the eye); one wavefront per query iterates on a register-resident
-//            working set of the 256 points around it and consults the whole set -- box-culled to a chunk or two -- only to
-//            certify "visible".
-//   level 3  k_hpr_exact<double>, k_hpr_exact<dd>: the few queries whose boolean iteration cycles or whose f64 certificate
-//            fails: the distance form of GJK (monotone, terminates), first in f64 with the same certificates, then in
+//            (the flipped cloud is a thin shell around the eye); one wavefront per query runs the distance form of GJK on a
+//            register-resident working set of the 256 points around it (closest-point sub-problem solved across the lanes)
+//            and consults the whole set -- box-culled to a chunk or two -- only to certify "visible".
+//   level 3  k_hpr_exact<double>, k_hpr_exact<dd>: the few queries whose f64 certificate fails or that stall: the distance
+//            iteration with Ericson's full region tests and the duplicate-point rule, first in f64, then in
 //            double-double arithmetic (2^-104) with 2^-96 bounds; what even that cannot certify (exact coplanarity /
 //            duplicate points) is counted in the workspace counters (pdhip_hpr_read_counters) and reported hidden.
 // The result is therefore the vertex set of the exact hull of the f64 flipped points; qhull (open3d, scipy) differs from it only
@@ -469,27 +469,62 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
     return r;
 }
 
-// ---- level 2 for SHORT query lists (the pipeline's case: only depth-rejected points are queried; a few hundred per view).
-// There the kernel time is the longest query's chain of dependent rounds, so a round must not wait on memory: one wavefront
-// per query keeps a WORKING SET in registers -- the 256 support points around the query in the sorted order, four per lane,
-// plus every point a global scan has returned -- and the GJK iteration takes its support points from that set.  Any point of
-// S_i that passes the origin is a legitimate next vertex, and "enclosed" is certified on real points as always; only the
-// "visible" verdict needs the whole support set: when the working set is separated from the origin in direction d, one
-// box-culled global scan looks for points with d.p' >= d.p'_i - tol (next to a hull vertex that is one or two chunks).  If it
-// finds none the verdict is certified exactly as in the general kernel, otherwise the point joins the working set.
+// ---- level 2: one wavefront per query.  The kernel time is the longest query's chain of dependent rounds, so a round must not
+// wait on memory: the wave keeps a WORKING SET in registers -- the 256 support points around the query in the sorted order, four
+// per lane, plus every point a global scan has returned -- and the GJK iteration takes its support points from that set.  Any
+// point of S_i that passes the origin is a legitimate next vertex, and "enclosed" is certified on real points as always; only
+// "visible" and "no progress" need the whole support set: then one box-culled global scan looks for points with
+// d.p' >= the working set's best (next to a hull vertex that is one or two chunks); what it returns joins the working set.
 #define HPR_LOCAL 4
-__global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict__ flipped, int N, const int* __restrict__ count,
-                                                        const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
-                                                        const int* __restrict__ sidx_all, const int* __restrict__ scount,
-                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of,
-                                                        const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
-                                                        int* __restrict__ unc_list, int* __restrict__ unc_seed) {
+// The iteration is GJK proper, the DISTANCE form (the search direction is minus the closest point of the simplex to the
+// origin; the distance decreases every round, so it cannot cycle the way the boolean form does on nearly degenerate input).  The
+// closest-point sub-problem is solved across the lanes: the closest point of conv{a, w0, w1, w2} lies on a face that contains
+// the newest vertex a, so the eight candidate faces {a} U X, X a subset of the kept vertices, are one lane each -- project the
+// origin on the face's affine hull through its 3x3 (padded) Gram system by Cramer's rule, keep the candidates whose barycentric
+// coordinates are all positive (they are points of the simplex, and the true closest point is one of them), take the nearest.
+// No branches on the simplex size.
+__device__ __forceinline__ d3 sel3(bool c, d3 a, d3 b) { return d3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }      // (by component: a struct select goes through memory)
+__device__ __forceinline__ bool closest_with_newest(const d3 a, d3& W0, d3& W1, d3& W2, int& I0, int& I1, int& I2, int& n, const int ai,
+                                                    d3& v, const int lane) {
+    const d3 e0 = W0 - a, e1 = W1 - a, e2 = W2 - a;
+    const int mask = lane & 7;
+    const bool a0 = (mask & 1) && n >= 1, a1 = (mask & 2) && n >= 2, a2 = (mask & 4) && n >= 3;
+    const bool mine = lane < 8 && (!(mask & 1) || n >= 1) && (!(mask & 2) || n >= 2) && (!(mask & 4) || n >= 3);
+    const double G00 = a0 ? dot(e0, e0) : 1.0, G11 = a1 ? dot(e1, e1) : 1.0, G22 = a2 ? dot(e2, e2) : 1.0;
+    const double G01 = (a0 && a1) ? dot(e0, e1) : 0.0, G02 = (a0 && a2) ? dot(e0, e2) : 0.0, G12 = (a1 && a2) ? dot(e1, e2) : 0.0;
+    const double r0 = a0 ? -dot(a, e0) : 0.0, r1 = a1 ? -dot(a, e1) : 0.0, r2 = a2 ? -dot(a, e2) : 0.0;
+    const double c00 = G11 * G22 - G12 * G12, c01 = G01 * G22 - G12 * G02, c02 = G01 * G12 - G11 * G02;
+    const double det = (G00 * c00 - G01 * c01) + G02 * c02;
+    const double n0 = (r0 * c00 - G01 * (r1 * G22 - G12 * r2)) + G02 * (r1 * G12 - G11 * r2);
+    const double n1 = (G00 * (r1 * G22 - r2 * G12) - r0 * c01) + G02 * (G01 * r2 - r1 * G02);
+    const double n2 = (G00 * (G11 * r2 - G12 * r1) - G01 * (G01 * r2 - r1 * G02)) + r0 * c02;
+    const bool ok = mine && det > 0.0 && (!a0 || n0 > 0.0) && (!a1 || n1 > 0.0) && (!a2 || n2 > 0.0) && (n0 + n1) + n2 < det;
+    const double l0 = n0 / det, l1 = n1 / det, l2 = n2 / det;
+    const d3 c = {(a.x + l0 * e0.x) + (l1 * e1.x + l2 * e2.x), (a.y + l0 * e0.y) + (l1 * e1.y + l2 * e2.y), (a.z + l0 * e0.z) + (l1 * e1.z + l2 * e2.z)};
+    const double d2 = ok ? dot(c, c) : 1.0e300;
+    const double best = -wave_max_f64(-d2);
+    const int win = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(d2 == best)));      // lane 0 ({a} alone) is always a candidate
+    v = d3{lane_f64(c.x, win), lane_f64(c.y, win), lane_f64(c.z, win)};
+    const int wm = win & 7;
+    if (wm == 7) return false;                                   // the origin is inside the tetrahedron (simplex left whole)
+    // new simplex: the newest vertex first, then the kept vertices the winning face uses
+    const bool b0 = wm & 1, b1 = wm & 2, b2 = wm & 4;
+    const d3 first = sel3(b0, W0, sel3(b1, W1, W2)), second = sel3(b0 && b1, W1, W2);       // (second is read only when two are kept)
+    const int ifirst = b0 ? I0 : (b1 ? I1 : I2), isecond = (b0 && b1) ? I1 : I2;
+    W0 = a; I0 = ai; W1 = first; I1 = ifirst; W2 = second; I2 = isecond;
+    n = 1 + (b0 ? 1 : 0) + (b1 ? 1 : 0) + (b2 ? 1 : 0);
+    return true;
+}
+__global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+                                                       const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
+                                                       const int* __restrict__ sidx_all, const int* __restrict__ scount,
+                                                       const float4* __restrict__ boxes_all, const int* __restrict__ pos_of,
+                                                       const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
+                                                       int* __restrict__ unc_list, int* __restrict__ unc_seed) {
     __shared__ int s_cand[4][256];
     const int v = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nq = count[v];
-    const int qi = blockIdx.x * 4 + wave;
-    if (qi >= nq) return;
     const double* qf = flipped + (size_t)v * 3 * N;
     const double* fx = ss + (size_t)v * 3 * N;
     const double* fy = fx + N;
@@ -497,10 +532,13 @@ __global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict
     const int* sidx = sidx_all + (size_t)v * N;
     const int NS = scount[v];
     const float4* boxes = boxes_all + (size_t)v * ((N + 63) >> 6) * (HPR_BOX_FLOATS / 4);
-    const int q = list[(size_t)v * N + qi];
-    const d3 pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]};
     const double ma = __longlong_as_double((long long)maxabs[v]);
     const double rb = ma * (8.0 * 1.1102230246251565e-16);
+    // (a fixed grid that strides over the list: a grid sized for N queries would be mostly empty blocks, and dispatching those costs
+    // more than the work -- 58 k of 60 k in the pipeline's case)
+    for (int qi = blockIdx.x * 4 + wave; qi < nq; qi += gridDim.x * 4) {
+    const int q = list[(size_t)v * N + qi];
+    const d3 pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]};
     // working set (the query itself and the tail past NS are left out: index -2 never wins)
     const int pq = pos_of[(size_t)v * N + q];
     const int base = max(0, min((pq & ~63) - 64, ((NS + 63) & ~63) - 64 * HPR_LOCAL));
@@ -516,20 +554,18 @@ __global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict
     }
     lx[HPR_LOCAL] = ly[HPR_LOCAL] = lz[HPR_LOCAL] = 0.0; li[HPR_LOCAL] = -2;       // the slot for what the global scans return
     int n_extra = 0;
-    Gjk<double> g;                                                // (identical in every lane)
-    g.sa = g.sb = g.sc = g.sd = d3{0, 0, 0}; g.dir = pi;          // start looking straight out along the point's own ray
-    g.ia = g.ib = g.ic = g.id = -1;
-    g.dim = 0;
-    g.state = 0;
+    // (everything below is identical in every lane, except inside closest_with_newest)
+    d3 W0 = {0, 0, 0}, W1 = {0, 0, 0}, W2 = {0, 0, 0}, vclose = pi, dir = pi;     // first direction: straight out along the point's own ray
+    int I0 = -2, I1 = -2, I2 = -2, n = 0, state = 0;
 #ifdef PD_HPR_STATS
     int my_rounds = 0;
     unsigned long long cand_chunks = 0, scans = 0;
 #endif
-    for (int round = 0; round < GJK_MAX_ROUNDS && g.state == 0; ++round) {
+    for (int round = 0; round < GJK_MAX_ROUNDS && state == 0; ++round) {
 #ifdef PD_HPR_STATS
         ++my_rounds;
 #endif
-        const double dx = g.dir.x, dy = g.dir.y, dz = g.dir.z;
+        const double dx = dir.x, dy = dir.y, dz = dir.z;
         double best = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0;
         int bidx = 0x7fffffff;
 #pragma unroll
@@ -548,9 +584,21 @@ __global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict
         }
         const double di = fma(dz, pi.z, fma(dy, pi.y, dx * pi.x));
         const double l1 = fabs(dx) + fabs(dy) + fabs(dz);
-        if (di - ((have && myv > 0.0) ? myv : 0.0) > 0.0) {
-            // the working set does not pass the origin in this direction: does any point of the support set?
-            const double th = di - (2.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+        const double vv = dot(vclose, vclose);
+        // is the working set's answer enough?  Not if it does not pass the origin (only the whole set can certify "visible"), nor
+        // if it is already a vertex of the simplex or brings the simplex no closer (only the whole set can say "no progress")
+        bool weak = true;
+        if (have && myv > 0.0 && di - myv <= 0.0) {
+            weak = (n >= 1 && si == I0) || (n >= 2 && si == I1) || (n >= 3 && si == I2);
+            if (n > 0 && !weak) { const double va = dot(vclose, sp - pi); weak = vv - va <= 1.0e-11 * vv; }
+        } else if (!(have && myv > 0.0) && di <= 0.0) weak = false;              // the eye passes the origin: it is the support
+        if (weak) {
+            // nothing below the working set's best, the eye's value or a simplex vertex's can be the support
+            double th = have ? fmax(myv, 0.0) : 0.0;
+            if (n >= 1) th = fmax(th, dot(dir, W0) + di);
+            if (n >= 2) th = fmax(th, dot(dir, W1) + di);
+            if (n >= 3) th = fmax(th, dot(dir, W2) + di);
+            th -= (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
 #ifdef PD_HPR_STATS
             ++scans;
             unsigned long long* ncp = &cand_chunks;
@@ -564,23 +612,42 @@ __global__ __launch_bounds__(256) void k_hpr_fine_local(const double* __restrict
                 n_extra = min(n_extra + 1, 64);
             }
         }
-        gjk_round(g, pi, myv, have, sp, si, rb);
+        // the support point of S_i in this direction is now exact: that point, or the eye (value 0)
+        const bool real = have && myv > 0.0;
+        const double gap = di - (real ? myv : 0.0);
+        if (gap > rb * l1) { state = 1; break; }                                 // certified visible
+        if (gap > 0.0 && n >= 1) { state = 3; break; }                           // visible in f64, but inside the rounding bound
+        const d3 a = sel3(real, sp - pi, neg(pi));
+        const int ai = real ? si : -1;
+        if (zero3(a)) { state = 3; break; }                                       // coincides with another point: the double-double stage has the rule
+        if ((n >= 1 && ai == I0) || (n >= 2 && ai == I1) || (n >= 3 && ai == I2)) { state = 3; break; }
+        if (n > 0 && vv - dot(vclose, a) <= 1.0e-11 * vv) { state = 3; break; }   // no progress: the origin is outside by less than f64 can show
+        if (!closest_with_newest(a, W0, W1, W2, I0, I1, I2, n, ai, vclose, lane)) {
+            // origin inside the tetrahedron (a, W0, W1, W2) in f64: certify p'_i strictly inside with the four determinants
+            const int s0 = -det_sign(W0, W1, W2), s1 = det_sign(a, W1, W2), s2 = -det_sign(a, W0, W2), s3 = det_sign(a, W0, W1);
+            state = (s0 != 0 && s0 == s1 && s1 == s2 && s2 == s3) ? 2 : 3;
+            if (state == 3) { I2 = I1; I1 = I0; I0 = ai; n = 3; }               // (seed for the next stage: three of the four)
+            break;
+        }
+        if (zero3(vclose)) { state = 3; break; }
+        dir = neg(vclose);
     }
 #ifdef PD_HPR_STATS
     if (lane == 0) { atomicAdd(&g_hpr_stats[1][0], 1ull); atomicAdd(&g_hpr_stats[1][1], (unsigned long long)my_rounds); atomicAdd(&g_hpr_stats[1][5], cand_chunks);
                      atomicAdd(&g_hpr_stats[1][6], scans);
                      atomicAdd(&g_hpr_stats[1][2], 1ull); atomicAdd(&g_hpr_stats[1][3], (unsigned long long)my_rounds);
-                     if (g.state == 0) atomicAdd(&g_hpr_stats[1][4], 1ull);
+                     if (state == 0) atomicAdd(&g_hpr_stats[1][4], 1ull);
                      atomicAdd(&g_hpr_stats[1][8 + min(my_rounds, 63) / 8], 1ull); }
 #endif
     if (lane == 0) {
-        vis[(size_t)v * N + q] = (g.state == 1) ? 1 : 0;
-        if (g.state == 0 || g.state == 3) {                           // round cap reached / not certifiable: the fallback passes
+        vis[(size_t)v * N + q] = (state == 1) ? 1 : 0;
+        if (state == 0 || state == 3) {                               // round cap reached / not certifiable in f64: the double-double stage
             const int pos = atomicAdd(&unc_count[v], 1);
             unc_list[(size_t)v * N + pos] = q;
-            int* sd = unc_seed + ((size_t)v * N + pos) * 4;           // the simplex it stopped at seeds the fallback
-            sd[0] = g.dim >= 1 ? g.ic : -2; sd[1] = g.dim >= 2 ? g.ib : -2; sd[2] = g.dim >= 3 ? g.id : -2; sd[3] = -2;
+            int* sd = unc_seed + ((size_t)v * N + pos) * 4;           // the simplex it stopped at seeds that stage
+            sd[0] = n >= 1 ? I0 : -2; sd[1] = n >= 2 ? I1 : -2; sd[2] = n >= 3 ? I2 : -2; sd[3] = -2;
         }
+    }
     }
 }
 
@@ -1188,7 +1255,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
     k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
     k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
-    k_hpr_fine_local<<<dim3(cdiv(N, 4), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, maxabs, ucount, ulist, useed);
+    k_hpr_fine_dist<<<dim3(min(cdiv(N, 4), 512), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, maxabs, ucount, ulist, useed);
     k_hpr_exact<double><<<dim3(64, V), 64, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, u2count, u2list, u2seed, counters);
     k_hpr_exact<dd><<<dim3(32, V), 512, 0, s>>>(flipped, N, u2count, u2list, u2seed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, nullptr, nullptr, nullptr, counters);
     PD_LAUNCH_CHECK();
