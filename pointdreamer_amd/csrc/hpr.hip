@@ -266,6 +266,7 @@ __device__ __forceinline__ float tile_max(const f32x16 a) {          // (v_max3_
                 m3 = fmaxf(fmaxf(a[9], a[10]), a[11]), m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
     return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), a[15]));
 }
+template <int COLS>          // query columns of 32 per wavefront: 2 = a query in every lane; 1 = queries in lanes 0-31 only, twice the waves (measured: 186 vs 158 us)
 __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                     const int* __restrict__ list, const float4* __restrict__ csf /*[V][KC]*/,
                                                     const double* __restrict__ csd /*[V][KC][4]*/, const int* __restrict__ cidx /*[V][KC]*/,
@@ -273,15 +274,15 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
                                                     const unsigned long long* __restrict__ maxabs) {
     const int v = blockIdx.y;
     const int nq = count[v];
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if ((qi & ~63) >= nq) return;
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    const bool hi = lane >= 32;
+    const int qi = COLS == 2 ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + l31;
+    if ((COLS == 2 ? (qi & ~63) : (qi & ~31)) >= nq) return;
     const float4* c = csf + (size_t)v * HPR_KC;
     const int KS = min(kcount[v], HPR_KC), KT = (KS + 31) >> 5;       // (the set is padded with the eye (0, 0, 0) to whole tiles)
     const double* qf = flipped + (size_t)v * 3 * N;
     const double rb = __longlong_as_double((long long)maxabs[v]) * (8.0 * 1.1102230246251565e-16);
-    const int lane = threadIdx.x & 63, l31 = lane & 31;
-    const bool hi = lane >= 32;
-    const bool owner = qi < nq;
+    const bool owner = qi < nq && (COLS == 2 || !hi);
     const int q = owner ? list[(size_t)v * N + qi] : 0;
     d3 pi = {0, 0, 0};
     Gjk<double> g;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         const float dx = (float)(g.dir.x * sc), dy = (float)(g.dir.y * sc), dz = (float)(g.dir.z * sc);
         // B operands (lane l: B[k = l >> 5][query column l & 31]) for the wave's two columns of 32 queries
         const float x0 = __shfl(dx, l31), y0 = __shfl(dy, l31), z0 = __shfl(dz, l31);
-        const float x1 = __shfl(dx, 32 + l31), y1 = __shfl(dy, 32 + l31), z1 = __shfl(dz, 32 + l31);
+        const float x1 = COLS == 2 ? __shfl(dx, 32 + l31) : 0.0f, y1 = COLS == 2 ? __shfl(dy, 32 + l31) : 0.0f, z1 = COLS == 2 ? __shfl(dz, 32 + l31) : 0.0f;
         const float b1_0 = hi ? y0 : x0, b2_0 = hi ? 0.0f : z0, b1_1 = hi ? y1 : x1, b2_1 = hi ? 0.0f : z1;
         float best0 = -3.0e38f, best1 = -3.0e38f;
         int code0 = -1, code1 = -1;                               // tile * 16 + accumulator entry
@@ -314,18 +315,18 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         {                                                                                                          \
             const float a1 = hi ? (PT).y : (PT).x, a2 = hi ? 0.0f : (PT).z;      /* lane l: A[point l & 31][k = l >> 5] */ \
             ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0);                                  \
-            ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);                                  \
+            if (COLS == 2) ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);                   \
             ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, ACC0, 0, 0, 0);                                  \
-            ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, ACC1, 0, 0, 0);                                  \
+            if (COLS == 2) ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, ACC1, 0, 0, 0);                   \
         }
 #define HPR_TILE_REDUCE(ACC0, ACC1, T)                                                                             \
         {   /* per tile only WHICH tile holds the lane's maximum; the position inside it is found once, after the scan */ \
-            const float m0 = tile_max(ACC0), m1 = tile_max(ACC1);                                                  \
+            const float m0 = tile_max(ACC0);                                                                       \
             if (m0 > best0) { best0 = m0; code0 = (T); }                                                           \
-            if (m1 > best1) { best1 = m1; code1 = (T); }                                                           \
+            if (COLS == 2) { const float m1 = tile_max(ACC1); if (m1 > best1) { best1 = m1; code1 = (T); } }       \
         }
         const int KT2 = (KT + 1) & ~1, TMAX = HPR_KC / 32 - 1;
-        f32x16 A0, A1, B0, B1;
+        f32x16 A0, A1 = zero, B0, B1 = zero;
         float4 pa = c[l31], pb = c[32 + l31];
         HPR_TILE_MFMA(A0, A1, pa)
         for (int t = 0; t < KT2; t += 2) {
@@ -347,18 +348,26 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = 8 * (i / 4) + (i % 4);
-                const float4 u0 = c[base0 + row], u1 = c[base1 + row];
-                const float w0 = fmaf(u0.z, z0, fmaf(u0.y, y0, u0.x * x0)), w1 = fmaf(u1.z, z1, fmaf(u1.y, y1, u1.x * x1));
+                const float4 u0 = c[base0 + row];
+                const float w0 = fmaf(u0.z, z0, fmaf(u0.y, y0, u0.x * x0));
                 if (w0 > r0) { r0 = w0; j0 = base0 + row; }
-                if (w1 > r1) { r1 = w1; j1 = base1 + row; }
+                if (COLS == 2) {
+                    const float4 u1 = c[base1 + row];
+                    const float w1 = fmaf(u1.z, z1, fmaf(u1.y, y1, u1.x * x1));
+                    if (w1 > r1) { r1 = w1; j1 = base1 + row; }
+                }
             }
         }
         // join the two half-waves
-        const float ob0 = __shfl_xor(best0, 32), ob1 = __shfl_xor(best1, 32);
-        const int oj0 = __shfl_xor(j0, 32), oj1 = __shfl_xor(j1, 32);
+        const float ob0 = __shfl_xor(best0, 32);
+        const int oj0 = __shfl_xor(j0, 32);
         if (ob0 > best0) j0 = oj0;
-        if (ob1 > best1) j1 = oj1;
-        int bi = hi ? j1 : j0;                                    // query lane l is column l & 31 of query tile l >> 5
+        if (COLS == 2) {
+            const float ob1 = __shfl_xor(best1, 32);
+            const int oj1 = __shfl_xor(j1, 32);
+            if (ob1 > best1) j1 = oj1;
+        }
+        int bi = (COLS == 2 && hi) ? j1 : j0;                                    // query lane l is column l & 31 of query tile l >> 5
         if (bi >= KS) bi = -1;                                    // a pad entry: the eye
         if (g.state == 0) {
             d3 sp = {0, 0, 0};
@@ -1193,7 +1202,7 @@ static size_t lists_bytes(int V, int N) { return a256((size_t)V * ((size_t)N + 6
 static size_t boxes_bytes(int V, int N) { return a256((size_t)V * (size_t)((N + 63) / 64 + 1) * HPR_BOX_FLOATS * sizeof(float)); }
 static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int)); }
 // workspace head: counters int[64][4] (double-double queries, unresolved, double-double rounds, f64 distance-iteration queries),
-// maxabs u64[64] at 1024, bounding-box keys u64[64][6] at 2048
+// maxabs u64[64] at 1024, bounding-box keys u64[64][6] at 2048, six per-view counters int[64] at 5120
 #define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
     return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
@@ -1207,49 +1216,44 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     PD_REQUIRE(points && eyes_dev && visibility && ws, "pdhip_hidden_point_removal: null pointer");
     PD_REQUIRE(V <= 64, "pdhip_hidden_point_removal: at most 64 views");
     hipStream_t s = as_stream(stream);
+    // everything that must start at zero sits at the front of the workspace: one fill
     char* p = reinterpret_cast<char*>(ws);
     int* counters = reinterpret_cast<int*>(p);
     unsigned long long* maxabs = reinterpret_cast<unsigned long long*>(p + 1024);
-    unsigned long long* bbox = reinterpret_cast<unsigned long long*>(p + 2048); p += HPR_HEAD_BYTES;
+    unsigned long long* bbox = reinterpret_cast<unsigned long long*>(p + 2048);
+    int* count = reinterpret_cast<int*>(p + 5120);                 // six per-view counters of 64 ints each
+    int* count2 = count + 64; int* scount = count + 128; int* ucount = count + 192; int* u2count = count + 256; int* kcount = count + 320;
+    p += HPR_HEAD_BYTES;
+    int* hist = reinterpret_cast<int*>(p); p += hist_bytes(V);
+    uint8_t* outside = reinterpret_cast<uint8_t*>(p); p += a256((size_t)V * N);
+    float4* csf = reinterpret_cast<float4*>(p); p += a256((size_t)V * HPR_KC * sizeof(float4));      // (entries past the set's end: the eye)
+    unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_KC * sizeof(unsigned long long));
+    int* pos_of = reinterpret_cast<int*>(p); p += lists_bytes(V, N);   // (the extremes' claim flags until the scatter fills it)
+    const size_t zero_bytes = (size_t)(p - reinterpret_cast<char*>(ws));
     double* flipped = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     double* ss = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);          // level-2 support set, cell-sorted
-    int* count = reinterpret_cast<int*>(p); int* list = count + 64; p += lists_bytes(V, N);
-    int* count2 = reinterpret_cast<int*>(p); int* list2 = count2 + 64; p += lists_bytes(V, N);
-    int* scount = reinterpret_cast<int*>(p); int* sidx = scount + 64; p += lists_bytes(V, N);
-    int* ucount = reinterpret_cast<int*>(p); int* ulist = ucount + 64; p += lists_bytes(V, N);      // queries for the f64 distance iteration
-    int* useed = reinterpret_cast<int*>(p); p += 4 * lists_bytes(V, N);                               // ... and the simplex each stopped at
-    int* u2count = reinterpret_cast<int*>(p); int* u2list = u2count + 64; p += lists_bytes(V, N);   // queries for the double-double iteration
+    int* list = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
+    int* list2 = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
+    int* sidx = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
+    int* ulist = reinterpret_cast<int*>(p); p += lists_bytes(V, N);               // queries for the f64 distance iteration of level 3
+    int* useed = reinterpret_cast<int*>(p); p += 4 * lists_bytes(V, N);           // ... and the simplex each stopped at
+    int* u2list = reinterpret_cast<int*>(p); p += lists_bytes(V, N);              // queries for the double-double iteration
     int* u2seed = reinterpret_cast<int*>(p); p += 4 * lists_bytes(V, N);
-    int* kcount = reinterpret_cast<int*>(p); int* cellkey = kcount + 64; p += lists_bytes(V, N);
-    int* pos_of = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
-    uint8_t* outside = reinterpret_cast<uint8_t*>(p); p += a256((size_t)V * N);
-    float4* csf = reinterpret_cast<float4*>(p); p += a256((size_t)V * HPR_KC * sizeof(float4));
+    int* cellkey = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
     double* csd = reinterpret_cast<double*>(p); p += a256((size_t)V * HPR_KC * 4 * sizeof(double));
-    unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_KC * sizeof(unsigned long long));
     int* cidx = reinterpret_cast<int*>(p); p += a256((size_t)V * HPR_KC * sizeof(int));
     float4* boxes = reinterpret_cast<float4*>(p); p += boxes_bytes(V, N);
-    int* hist = reinterpret_cast<int*>(p);
     dim3 gf(min(cdiv(N, 256), 256), V);
-    PD_HIP(hipMemsetAsync(ws, 0, HPR_HEAD_BYTES, s));
+    PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
     k_hpr_flip<<<dim3(min(cdiv(N, 256), 32), V), 256, 0, s>>>       // (few waves: each ends with seven atomics on the view's extrema)
        (points, N, eyes_dev, radius, flipped, maxabs, bbox);
-    PD_HIP(hipMemsetAsync(count, 0, 64 * sizeof(int), s));
-    PD_HIP(hipMemsetAsync(count2, 0, 64 * sizeof(int), s));
-    PD_HIP(hipMemsetAsync(ucount, 0, 64 * sizeof(int), s));
-    PD_HIP(hipMemsetAsync(u2count, 0, 64 * sizeof(int), s));
-    PD_HIP(hipMemsetAsync(hist, 0, (size_t)V * HPR_NCELL * sizeof(int), s));
     k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);      // marks the skipped points visible; `list` = the queries
     constexpr int KC = HPR_KC;
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     if (two_level) {
-        PD_HIP(hipMemsetAsync(outside, 0, (size_t)V * N, s));
-        PD_HIP(hipMemsetAsync(kcount, 0, 64 * sizeof(int), s));
-        PD_HIP(hipMemsetAsync(csf, 0, (size_t)V * HPR_KC * sizeof(float4), s));       // entries past the set's end: the eye
-        PD_HIP(hipMemsetAsync(ekeys, 0, (size_t)V * HPR_KC * sizeof(unsigned long long), s));
-        PD_HIP(hipMemsetAsync(pos_of, 0, (size_t)V * N * sizeof(int), s));       // (the extremes' claim flags until the scatter fills it)
         k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, ekeys);
         k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of);
-        k_hpr_coarse<<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs);
+        k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs);
     }
     k_hpr_bin<<<gf, 256, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
