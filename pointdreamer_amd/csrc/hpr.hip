@@ -528,6 +528,7 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
                                                        const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
                                                        const int* __restrict__ sidx_all, const int* __restrict__ scount,
                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of,
+                                                       const int* __restrict__ mdir /*may be null*/, const double* __restrict__ fdir,
                                                        const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
                                                        int* __restrict__ unc_list, int* __restrict__ unc_seed) {
     __shared__ int s_cand[4][256];
@@ -565,6 +566,10 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
     int n_extra = 0;
     // (everything below is identical in every lane, except inside closest_with_newest)
     d3 W0 = {0, 0, 0}, W1 = {0, 0, 0}, W2 = {0, 0, 0}, vclose = pi, dir = pi;     // first direction: straight out along the point's own ray
+    // ... except for a member of the coarse set (most of this level's queries): it was found as the extreme point of a known
+    // direction, in which it is most likely separated from everything else -- one certified scan instead of an iteration
+    const int mk = mdir != nullptr ? mdir[(size_t)v * N + q] : 0;
+    if (mk > 0) dir = d3{fdir[4 * (mk - 1)], fdir[4 * (mk - 1) + 1], fdir[4 * (mk - 1) + 2]};
     int I0 = -2, I1 = -2, I2 = -2, n = 0, state = 0;
 #ifdef PD_HPR_STATS
     int my_rounds = 0;
@@ -1180,14 +1185,21 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
 // A point joins the coarse set the first time a direction finds it (many directions share their extreme point).
 __global__ void k_hpr_extremes_fin(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ keys,
                                    float4* __restrict__ csf, double* __restrict__ csd /*[V][KC][4]: the same points in f64*/,
-                                   int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/) {
+                                   int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/,
+                                   int* __restrict__ mdir /*[V][N], zeroed: 1 + the direction that found the point*/,
+                                   double* __restrict__ fdir /*[KC][4]: the directions in f64*/) {
     const int v = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= HPR_KC) return;
+    if (v == 0) {
+        const double zk = 1.0 - (2.0 * k + 1.0) / HPR_KC, rk = sqrt(fmax(0.0, 1.0 - zk * zk)), pk = k * 2.399963229728653;
+        fdir[4 * k] = rk * cos(pk); fdir[4 * k + 1] = rk * sin(pk); fdir[4 * k + 2] = zk; fdir[4 * k + 3] = 0.0;
+    }
     const unsigned long long key = keys[(size_t)v * HPR_KC + k];
     const unsigned int vb = (unsigned int)(key >> 32);
     const int id = 0x7fffffff - (int)(unsigned int)(key & 0xffffffffu);
     if (vb <= 0x80000000u || id < 0 || id >= N) return;                   // no point with a positive projection
     if (atomicExch(&claim[(size_t)v * N + id], 1) != 0) return;
+    mdir[(size_t)v * N + id] = k + 1;
     const double* f = flipped + (size_t)v * 3 * N;
     const int pos = atomicAdd(&kcount[v], 1);
     csf[(size_t)v * HPR_KC + pos] = make_float4((float)f[id], (float)f[N + id], (float)f[2 * (size_t)N + id], 0.0f);
@@ -1206,7 +1218,7 @@ static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int
 #define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
     return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
-           a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V);
+           a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V) + a256((size_t)HPR_KC * 4 * sizeof(double));
 }
 
 extern "C" int pdhip_hidden_point_removal(const float* points, int N, const double* eyes_dev, int V, double radius,
@@ -1229,6 +1241,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     float4* csf = reinterpret_cast<float4*>(p); p += a256((size_t)V * HPR_KC * sizeof(float4));      // (entries past the set's end: the eye)
     unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_KC * sizeof(unsigned long long));
     int* pos_of = reinterpret_cast<int*>(p); p += lists_bytes(V, N);   // (the extremes' claim flags until the scatter fills it)
+    int* mdir = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
     const size_t zero_bytes = (size_t)(p - reinterpret_cast<char*>(ws));
     double* flipped = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     double* ss = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);          // level-2 support set, cell-sorted
@@ -1243,6 +1256,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     double* csd = reinterpret_cast<double*>(p); p += a256((size_t)V * HPR_KC * 4 * sizeof(double));
     int* cidx = reinterpret_cast<int*>(p); p += a256((size_t)V * HPR_KC * sizeof(int));
     float4* boxes = reinterpret_cast<float4*>(p); p += boxes_bytes(V, N);
+    double* fdir = reinterpret_cast<double*>(p); p += a256((size_t)HPR_KC * 4 * sizeof(double));
     dim3 gf(min(cdiv(N, 256), 256), V);
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
     k_hpr_flip<<<dim3(min(cdiv(N, 256), 32), V), 256, 0, s>>>       // (few waves: each ends with seven atomics on the view's extrema)
@@ -1252,14 +1266,14 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     if (two_level) {
         k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, ekeys);
-        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of);
+        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir, fdir);
         k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs);
     }
     k_hpr_bin<<<gf, 256, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
     k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
     k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
-    k_hpr_fine_dist<<<dim3(min(cdiv(N, 4), 512), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, maxabs, ucount, ulist, useed);
+    k_hpr_fine_dist<<<dim3(min(cdiv(N, 4), 512), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, two_level ? mdir : nullptr, fdir, maxabs, ucount, ulist, useed);
     k_hpr_exact<double><<<dim3(64, V), 64, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, u2count, u2list, u2seed, counters);
     k_hpr_exact<dd><<<dim3(32, V), 512, 0, s>>>(flipped, N, u2count, u2list, u2seed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, nullptr, nullptr, nullptr, counters);
     PD_LAUNCH_CHECK();

@@ -161,14 +161,19 @@ __global__ __launch_bounds__(256) void k_nbf_bits(const unsigned long long* __re
         h[i] = acc;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < NBF_RB * W64; i += 4) {
-        const int yy = i / W64, w = i - yy * W64, y = y0 + yy;
+    // output: 16 texels (a quarter word) per thread and step -> one 16-byte store each, 1 KB per wavefront instruction (a byte per
+    // lane made this kernel store-issue bound: 76 us for 8 MB)
+    const int Q16 = A >> 4;                                       // 16-texel pieces per row
+    for (int i = threadIdx.x; i < NBF_RB * Q16; i += blockDim.x) {
+        const int yy = i / Q16, c = i - yy * Q16, w = c >> 2, y = y0 + yy;
         if (y >= A) break;
         unsigned long long border = 0ull;
         for (int k = 0; k <= 2 * r; ++k) border |= h[(size_t)(yy + k) * W64 + w];
-        const unsigned long long keep = vb[(size_t)y * W64 + w] & ~border;
-        out[((size_t)v * A + y) * A + (size_t)w * 64 + lane] = (uint8_t)((keep >> lane) & 1ull);
+        const unsigned int keep = (unsigned int)((vb[(size_t)y * W64 + w] & ~border) >> ((c & 3) * 16)) & 0xffffu;
+        uint4 o;                                                  // bit j -> byte j: four bits at a time, (b * 0x00204081) & 0x01010101
+        o.x = ((keep & 15u) * 0x00204081u) & 0x01010101u; o.y = (((keep >> 4) & 15u) * 0x00204081u) & 0x01010101u;
+        o.z = (((keep >> 8) & 15u) * 0x00204081u) & 0x01010101u; o.w = (((keep >> 12) & 15u) * 0x00204081u) & 0x01010101u;
+        *reinterpret_cast<uint4*>(out + ((size_t)v * A + y) * A + (size_t)c * 16) = o;
     }
 }
 
