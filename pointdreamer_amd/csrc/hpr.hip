@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
 #define HPR_BOUND_SLACK 1.0e-5   // x |d|_1 max|coordinate|: f32 evaluation of the bound (<= 3e-6) with margin
 struct Support { double val, x, y, z; int pos, idx; };      // wave-uniform; pos < 0: no point of S_i reaches the threshold
 // DUPX: also exclude the points that coincide with the query and have a larger cloud index (the distance iteration's rule)
-template <bool DUPX>
+template <bool DUPX, int BATCH>        // BATCH candidate chunks per trip (their loads are in flight together)
 __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
                                                 const int* __restrict__ sidx, const int NS, const float4* __restrict__ boxes,
                                                 const double dx, const double dy, const double dz, const double th, const int qk,
@@ -444,19 +444,19 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (n_cand) *n_cand += nc;
-        for (int b0 = 0; b0 < nc; b0 += 8) {                      // eight candidate chunks per trip: their loads are in flight together
-            int jj[8];
+        for (int b0 = 0; b0 < nc; b0 += BATCH) {
+            int jj[BATCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) jj[u] = (s_cand[min(b0 + u, nc - 1)] << 6) + lane;   // (a repeated chunk cannot change the result)
-            double x[8], y[8], z[8];
-            int jo[8];
+            for (int u = 0; u < BATCH; ++u) jj[u] = b0 + u < nc ? (s_cand[b0 + u] << 6) + lane : NS;
+            double x[BATCH], y[BATCH], z[BATCH];
+            int jo[BATCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < BATCH; ++u) {
                 const int j = min(jj[u], NS - 1);
                 x[u] = fx[j]; y[u] = fy[j]; z[u] = fz[j]; jo[u] = sidx[j];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < BATCH; ++u) {
                 const double val = fma(dz, z[u], fma(dy, y[u], dx * x[u]));
                 bool ok = jj[u] < NS && jo[u] != qk;
                 if (DUPX) ok = ok && !(jo[u] > qk && x[u] == px && y[u] == py && z[u] == pz);
@@ -508,7 +508,7 @@ __device__ __forceinline__ bool closest_with_newest(const d3 a, d3& W0, d3& W1, 
     const double n1 = (G00 * (r1 * G22 - r2 * G12) - r0 * c01) + G02 * (G01 * r2 - r1 * G02);
     const double n2 = (G00 * (G11 * r2 - G12 * r1) - G01 * (G01 * r2 - r1 * G02)) + r0 * c02;
     const bool ok = mine && det > 0.0 && (!a0 || n0 > 0.0) && (!a1 || n1 > 0.0) && (!a2 || n2 > 0.0) && (n0 + n1) + n2 < det;
-    const double l0 = n0 / det, l1 = n1 / det, l2 = n2 / det;
+    const double rdet = 1.0 / det, l0 = n0 * rdet, l1 = n1 * rdet, l2 = n2 * rdet;       // (the search may be a rounding off; the verdicts are certified elsewhere)
     const d3 c = {(a.x + l0 * e0.x) + (l1 * e1.x + l2 * e2.x), (a.y + l0 * e0.y) + (l1 * e1.y + l2 * e2.y), (a.z + l0 * e0.z) + (l1 * e1.z + l2 * e2.z)};
     const double d2 = ok ? dot(c, c) : 1.0e300;
     const double best = -wave_max_f64(-d2);
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
 #else
             unsigned long long* ncp = nullptr;
 #endif
-            const Support r = support_scan<false>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp);
+            const Support r = support_scan<false, 2>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp);
             if (r.pos >= 0 && (!have || r.val > myv || (r.val == myv && r.idx < si))) {
                 myv = r.val; si = r.idx; sp = d3{r.x, r.y, r.z}; have = true;
                 if (lane == n_extra) { lx[HPR_LOCAL] = r.x; ly[HPR_LOCAL] = r.y; lz[HPR_LOCAL] = r.z; li[HPR_LOCAL] = r.idx; }
@@ -884,10 +884,10 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
                     thr -= (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
 #ifdef PD_HPR_STATS
                     unsigned long long ncand = 0;
-                    const Support r = support_scan<true>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, &ncand);
+                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, &ncand);
                     if (lane == 0) { atomicAdd(&g_hpr_stats[0][5], ncand); atomicAdd(&g_hpr_stats[0][6], 1ull); }
 #else
-                    const Support r = support_scan<true>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, nullptr);
+                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, nullptr);
 #endif
                     if (r.pos >= 0 && (!have || r.val > m || (r.val == m && r.idx < mi))) {
                         have = true; m = r.val; spx = r.x; spy = r.y; spz = r.z; spi = r.idx;
