@@ -277,9 +277,25 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
     const int lane = threadIdx.x & 63, l31 = lane & 31;
     const bool hi = lane >= 32;
     const int qi = COLS == 2 ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + l31;
-    if ((COLS == 2 ? (qi & ~63) : (qi & ~31)) >= nq) return;
-    const float4* c = csf + (size_t)v * HPR_KC;
+    if (blockIdx.x * (COLS == 2 ? 256 : 128) >= nq) return;           // (the whole block: before the barrier below)
     const int KS = min(kcount[v], HPR_KC), KT = (KS + 31) >> 5;       // (the set is padded with the eye (0, 0, 0) to whole tiles)
+    // the view's coarse set lives in LDS for the block's lifetime (f32 records for the scans, f64 records + cloud indices for the
+    // GJK step): every round ends with two dependent look-ups into it, which from L2 were a third of the round's latency
+    __shared__ float4 s_csf[HPR_KC];
+    __shared__ double s_csd[HPR_KC][3];
+    __shared__ int s_cidx[HPR_KC];
+    {
+        const int KL = min(HPR_KC, ((KT + 2) & ~1) * 32);          // (whole tiles, an even number of them, one more for the prefetch)
+        for (int i = threadIdx.x; i < KL; i += 256) {
+            s_csf[i] = csf[(size_t)v * HPR_KC + i];
+            const double* cd = csd + ((size_t)v * HPR_KC + i) * 4;
+            s_csd[i][0] = cd[0]; s_csd[i][1] = cd[1]; s_csd[i][2] = cd[2];
+            s_cidx[i] = cidx[(size_t)v * HPR_KC + i];
+        }
+        __syncthreads();
+    }
+    if ((COLS == 2 ? (qi & ~63) : (qi & ~31)) >= nq) return;
+    const float4* c = s_csf;
     const double* qf = flipped + (size_t)v * 3 * N;
     const double rb = __longlong_as_double((long long)maxabs[v]) * (8.0 * 1.1102230246251565e-16);
     const bool owner = qi < nq && (COLS == 2 || !hi);
@@ -374,9 +390,8 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
             int si = -1;
             double myv = 0.0;
             if (bi >= 0) {
-                si = cidx[(size_t)v * HPR_KC + bi];
-                const double* cd = csd + ((size_t)v * HPR_KC + bi) * 4;
-                sp = {cd[0], cd[1], cd[2]};
+                si = s_cidx[bi];
+                sp = {s_csd[bi][0], s_csd[bi][1], s_csd[bi][2]};
                 myv = fma(g.dir.z, sp.z, fma(g.dir.y, sp.y, g.dir.x * sp.x));
             }
             if (si == q) g.state = 3;                             // the query is itself a member of the coarse set: level 2 decides
