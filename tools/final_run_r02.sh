@@ -17,6 +17,7 @@ cd $GRAFT_REPO_ROOT
 python tools/rocpd_stats.py gpurun_out/prof_r02/*/*.db $O/kernel_stats.md > /dev/null 2>&1
 rm -rf gpurun_out/prof_r02
 bash tools/prof_nearest.sh > /dev/null 2>&1; cp gpurun_out/kernel_stats_nearest.md $O/kernel_stats_nearest.md
+bash tools/prof_hpr.sh > /dev/null 2>&1; cp gpurun_out/kernel_stats_hpr.md $O/kernel_stats_hpr.md; grep -v amdgpu.ids gpurun_out/prof_hpr.log | grep 'ms\|mismatch\|identity' > $O/hpr_dbg.log
 rm -rf gpurun_out/pmc_bench
 bash tools/pmc_bench.sh > $O/pmc_bench.log 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_bench $O/pmc_conv.json 4 > /dev/null 2>&1
