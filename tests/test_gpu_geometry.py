@@ -334,6 +334,44 @@ def test_p3b_large_support_set(pd):
     assert (want.sum(1) > 16384).all()                       # more hull vertices per view than 256 chunks hold
 
 
+@pytest.mark.parametrize("kind", ['cube', 'gauss', 'plane', 'cylinder', 'clusters', 'shell_grid', 'two_level_plane'])
+def test_p3b_cloud_zoo_vs_qhull(pd, kind):
+    """Clouds of different character through all three levels: box (flat faces: many coplanar flipped neighbours), Gaussian blob,
+    a thin noisy plate and an exactly planar grid (the flip of a plane is a sphere through the eye: every point is a hull vertex,
+    neighbours nearly cospherical), a cylinder, tight clusters, a latitude / longitude grid on a sphere (exact symmetries)."""
+    from pointdreamer_amd import hpr
+    rng = np.random.default_rng(abs(hash(kind)) % (2 ** 31))
+    n = 6000
+    if kind == 'cube':
+        pts = rng.uniform(-0.5, 0.5, (n, 3)); ax = rng.integers(0, 3, n); pts[np.arange(n), ax] = np.sign(pts[np.arange(n), ax]) * 0.5
+    elif kind == 'gauss':
+        pts = rng.standard_normal((n, 3)) * 0.2
+    elif kind == 'plane':
+        pts = np.concatenate([rng.uniform(-0.6, 0.6, (n, 2)), 0.15 + 0.002 * rng.standard_normal((n, 1))], 1)
+    elif kind == 'cylinder':
+        th = rng.uniform(0, 2 * np.pi, n); pts = np.stack([0.4 * np.cos(th), 0.4 * np.sin(th), rng.uniform(-0.6, 0.6, n)], 1)
+    elif kind == 'clusters':
+        c = rng.uniform(-0.5, 0.5, (12, 3)); pts = c[rng.integers(0, 12, n)] + 0.01 * rng.standard_normal((n, 3))
+    elif kind == 'shell_grid':
+        a, b = np.meshgrid(np.linspace(0.05, np.pi - 0.05, 60), np.linspace(0, 2 * np.pi, 100, endpoint=False), indexing='ij')
+        pts = 0.5 * np.stack([np.sin(a) * np.cos(b), np.sin(a) * np.sin(b), np.cos(a)], -1).reshape(-1, 3)
+    else:                                                  # exactly planar grid, above the two-level threshold
+        a, b = np.meshgrid(np.linspace(-0.6, 0.6, 80), np.linspace(-0.6, 0.6, 80), indexing='ij')
+        pts = np.stack([a, b, 0.2 + 0.3 * a - 0.1 * b], -1).reshape(-1, 3)
+    pts = pts.astype(np.float32)
+    _, _, eyes, _ = pd['cu'].create_cameras(8, 1.6, 512, device=DEV)
+    eyes = eyes[::2]
+    got, st = hpr.hidden_point_removal(T(pts), eyes, 100, return_stats=True)
+    got = N_(got)
+    want = oproj.point_validation_by_hpr(pts, eyes, 100)
+    bad = np.argwhere(got != want)
+    for v, i in bad[:50]:                                  # only inside qhull's own merge tolerance, and then the device has the exact verdict
+        m = oproj.hpr_margin(oproj.hpr_flip(pts, eyes[v], 100), i)
+        assert abs(m) < 1e-9, (kind, v, i, m, bool(got[v, i]), bool(want[v, i]))
+        assert bool(got[v, i]) == (m > 0) or st['unresolved'] > 0, (kind, v, i, m)
+    assert len(bad) <= max(2, st['unresolved']), (kind, len(bad), st)
+
+
 def test_p3b_duplicates_and_tiny_clouds(pd):
     """Coinciding points: the smallest index is the hull vertex, the copies are hidden (qhull keeps one of them, which one is
     its processing order); clouds below the two-level threshold and of a handful of points take the one-level path."""
