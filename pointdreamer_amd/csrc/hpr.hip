@@ -31,7 +31,9 @@
 #include "common.h"
 using namespace pdhip;
 
+#ifndef GJK_MAX_ROUNDS
 #define GJK_MAX_ROUNDS 64
+#endif
 #ifndef GJK_COARSE_ROUNDS
 #define GJK_COARSE_ROUNDS 10     // level 1 gives up early: a wave pays every round for all 64 lanes, level 2 costs one wave per leftover (8: 0.69, 10: 0.60, 16: 0.66 ms)
 #endif
@@ -424,7 +426,7 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
                                                 const int* __restrict__ sidx, const int NS, const float4* __restrict__ boxes,
                                                 const double dx, const double dy, const double dz, const double th, const int qk,
                                                 const double px, const double py, const double pz, int* s_cand /*[256], this wave's*/,
-                                                const int lane, unsigned long long* n_cand) {
+                                                const int lane, unsigned long long* n_cand, const int skip_lo = 0, const int skip_hi = 0) {
     const int NCH = (NS + 63) >> 6;
     // the direction in f32, scaled into range by a power of two (the bound is homogeneous in d; th is scaled alike)
     const double mag = fmax(fabs(dx), fmax(fabs(dy), fabs(dz)));
@@ -445,7 +447,7 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
                 const float p0 = fmaf(dzf, b0.z, fmaf(dyf, b0.y, dxf * b0.x)), p1 = fmaf(dzf, b1.y, fmaf(dyf, b1.x, dxf * b0.w)),
                             p2 = fmaf(dzf, b2.x, fmaf(dyf, b1.w, dxf * b1.z));
                 const float bound = (fmaxf(p0 * b2.y, p0 * b3.x) + fmaxf(p1 * b2.z, p1 * b3.y)) + fmaxf(p2 * b2.w, p2 * b3.z);
-                cand[u] = (double)bound >= ths;
+                cand[u] = (double)bound >= ths && !(cc >= skip_lo && cc < skip_hi);      // (chunks the caller already holds)
             }
         }
         int nc = 0;
@@ -634,7 +636,8 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
 #else
             unsigned long long* ncp = nullptr;
 #endif
-            const Support r = support_scan<false, 2>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp);
+            const Support r = support_scan<false, 2>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp,
+                                                     base >> 6, (base >> 6) + HPR_LOCAL);      // (the working set's own chunks are in myv already)
             if (r.pos >= 0 && (!have || r.val > myv || (r.val == myv && r.idx < si))) {
                 myv = r.val; si = r.idx; sp = d3{r.x, r.y, r.z}; have = true;
                 if (lane == n_extra) { lx[HPR_LOCAL] = r.x; ly[HPR_LOCAL] = r.y; lz[HPR_LOCAL] = r.z; li[HPR_LOCAL] = r.idx; }
@@ -819,10 +822,11 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
         const int q = unc_list[(size_t)v * N + u];
         const double px = flipped[(size_t)v * 3 * N + q], py = flipped[(size_t)v * 3 * N + N + q], pz = flipped[(size_t)v * 3 * N + 2 * (size_t)N + q];
         double lx[HPR_LOCAL + 1], ly[HPR_LOCAL + 1], lz[HPR_LOCAL + 1];
-        int li[HPR_LOCAL + 1], n_extra = 0;
+        int li[HPR_LOCAL + 1], n_extra = 0, ws_chunk = 0;
         if constexpr (WAVE) {          // working set: the 256 support points around the query in the sorted order + what the global scans return
             const int pq = pos_of[(size_t)v * N + q];
             const int base = max(0, min((pq & ~63) - 64, ((NS + 63) & ~63) - 64 * HPR_LOCAL));
+            ws_chunk = base >> 6;
 #pragma unroll
             for (int u = 0; u < HPR_LOCAL; ++u) {
                 const int j = base + u * 64 + lane;
@@ -899,10 +903,10 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
                     thr -= (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
 #ifdef PD_HPR_STATS
                     unsigned long long ncand = 0;
-                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, &ncand);
+                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, &ncand, ws_chunk, ws_chunk + HPR_LOCAL);
                     if (lane == 0) { atomicAdd(&g_hpr_stats[0][5], ncand); atomicAdd(&g_hpr_stats[0][6], 1ull); }
 #else
-                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, nullptr);
+                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, nullptr, ws_chunk, ws_chunk + HPR_LOCAL);
 #endif
                     if (r.pos >= 0 && (!have || r.val > m || (r.val == m && r.idx < mi))) {
                         have = true; m = r.val; spx = r.x; spy = r.y; spz = r.z; spi = r.idx;
