@@ -42,10 +42,13 @@ using namespace pdhip;
 #endif
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
-__device__ unsigned long long g_hpr_stats[2][16];             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
+__device__ unsigned long long g_hpr_stats[2][16];
+__device__ unsigned long long g_hpr_t[4];                        // level 2: per-query wall time in 100 MHz ticks: sum, max, sum over coarse-set members, their count             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
 extern "C" int pdhip_lab_hpr_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hpr_stats), sizeof(g_hpr_stats)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_hpr_t), sizeof(g_hpr_t)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_stats), z, sizeof(z)) != hipSuccess) return -1;
+                 if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_t), z, sizeof(g_hpr_t)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -164,6 +167,12 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     v = fmax(v, dpp_f64<0xB1, 0xf>(v)); v = fmax(v, dpp_f64<0x4E, 0xf>(v)); v = fmax(v, dpp_f64<0x141, 0xf>(v)); v = fmax(v, dpp_f64<0x140, 0xf>(v));
     v = fmax(v, dpp_f64<0x142, 0xa>(v)); v = fmax(v, dpp_f64<0x143, 0xc>(v));
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, __int_as_float(dpp_i32<0xB1, 0xf>(__float_as_int(v)))); v = fmaxf(v, __int_as_float(dpp_i32<0x4E, 0xf>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x141, 0xf>(__float_as_int(v)))); v = fmaxf(v, __int_as_float(dpp_i32<0x140, 0xf>(__float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i32<0x142, 0xa>(__float_as_int(v)))); v = fmaxf(v, __int_as_float(dpp_i32<0x143, 0xc>(__float_as_int(v))));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
     v = min(v, dpp_i32<0xB1, 0xf>(v)); v = min(v, dpp_i32<0x4E, 0xf>(v)); v = min(v, dpp_i32<0x141, 0xf>(v)); v = min(v, dpp_i32<0x140, 0xf>(v));
@@ -424,63 +433,80 @@ struct Support { double val, x, y, z; int pos, idx; };      // wave-uniform; pos
 template <bool DUPX, int BATCH>        // BATCH candidate chunks per trip (their loads are in flight together)
 __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
                                                 const int* __restrict__ sidx, const int NS, const float4* __restrict__ boxes,
-                                                const double dx, const double dy, const double dz, const double th, const int qk,
-                                                const double px, const double py, const double pz, int* s_cand /*[256], this wave's*/,
-                                                const int lane, unsigned long long* n_cand, const int skip_lo = 0, const int skip_hi = 0) {
+                                                const double dx, const double dy, const double dz, const double th, const double slack,
+                                                const int qk, const double px, const double py, const double pz,
+                                                int* s_cand /*[256], this wave's*/, const int lane, unsigned long long* n_cand,
+                                                const int skip_lo = 0, const int skip_hi = 0) {
     const int NCH = (NS + 63) >> 6;
-    // the direction in f32, scaled into range by a power of two (the bound is homogeneous in d; th is scaled alike)
+    // the direction in f32, scaled into range by a power of two (the bound is homogeneous in d; th and slack are scaled alike)
     const double mag = fmax(fabs(dx), fmax(fabs(dy), fabs(dz)));
     const double sc = mag > 0.0 ? __longlong_as_double((long long)((0x3ffull + 0x3ffull - (((unsigned long long)__double_as_longlong(mag) >> 52) & 0x7ffull)) << 52)) : 1.0;
     const float dxf = (float)(dx * sc), dyf = (float)(dy * sc), dzf = (float)(dz * sc);
-    const double ths = th * sc;
+    double ths = th * sc;
+    const double slacks = slack * sc;
     double best = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0;
     int bidx = 0x7fffffff, bpos = -1;
     for (int g0 = 0; g0 < NCH; g0 += 256) {
-        bool cand[4];
+        float bound[4];
+        bool todo[4];
+        float bm = -3.0e38f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cc = g0 + u * 64 + lane;
-            cand[u] = false;
-            if (cc < NCH) {
+            todo[u] = false; bound[u] = -3.0e38f;
+            if (cc < NCH && !(cc >= skip_lo && cc < skip_hi)) {            // (skip: chunks the caller already holds)
                 const float4* b = boxes + (size_t)cc * (HPR_BOX_FLOATS / 4);
                 const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];          // e0.xyz e1.x | e1.yz e2.xy | e2.z lo.xyz | hi.xyz -
                 const float p0 = fmaf(dzf, b0.z, fmaf(dyf, b0.y, dxf * b0.x)), p1 = fmaf(dzf, b1.y, fmaf(dyf, b1.x, dxf * b0.w)),
                             p2 = fmaf(dzf, b2.x, fmaf(dyf, b1.w, dxf * b1.z));
-                const float bound = (fmaxf(p0 * b2.y, p0 * b3.x) + fmaxf(p1 * b2.z, p1 * b3.y)) + fmaxf(p2 * b2.w, p2 * b3.z);
-                cand[u] = (double)bound >= ths && !(cc >= skip_lo && cc < skip_hi);      // (chunks the caller already holds)
+                bound[u] = (fmaxf(p0 * b2.y, p0 * b3.x) + fmaxf(p1 * b2.z, p1 * b3.y)) + fmaxf(p2 * b2.w, p2 * b3.z);
+                todo[u] = (double)bound[u] >= ths;
+                bm = fmaxf(bm, bound[u]);
             }
         }
-        int nc = 0;
+        // two tiers: first only the chunks whose bound is within 0.4 % of the largest (the flipped cloud is a shell: the support
+        // point is almost always there), then whatever can still beat the value found -- a weak threshold (a direction far from the
+        // working set's side of the cloud) would otherwise let half the chunks through
+        bm = wave_max_f32(bm);
+        double tier = bm > 0.0f ? fmax(ths, (double)bm * 0.996) : ths;
+        for (int pass = 0; pass < 2; ++pass) {
+            int nc = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned long long bal = __ballot(cand[u]);
-            if (cand[u]) s_cand[nc + __popcll(bal & ((1ull << lane) - 1ull))] = g0 + u * 64 + lane;
-            nc += __popcll(bal);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (n_cand) *n_cand += nc;
-        for (int b0 = 0; b0 < nc; b0 += BATCH) {
-            int jj[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) jj[u] = b0 + u < nc ? (s_cand[b0 + u] << 6) + lane : NS;
-            double x[BATCH], y[BATCH], z[BATCH];
-            int jo[BATCH];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int j = min(jj[u], NS - 1);
-                x[u] = fx[j]; y[u] = fy[j]; z[u] = fz[j]; jo[u] = sidx[j];
+            for (int u = 0; u < 4; ++u) {
+                const bool c = todo[u] && (double)bound[u] >= tier;
+                const unsigned long long bal = __ballot(c);
+                if (c) { s_cand[nc + __popcll(bal & ((1ull << lane) - 1ull))] = g0 + u * 64 + lane; todo[u] = false; }
+                nc += __popcll(bal);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (n_cand) *n_cand += nc;
+            for (int b0 = 0; b0 < nc; b0 += BATCH) {
+                int jj[BATCH];
 #pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const double val = fma(dz, z[u], fma(dy, y[u], dx * x[u]));
-                bool ok = jj[u] < NS && jo[u] != qk;
-                if (DUPX) ok = ok && !(jo[u] > qk && x[u] == px && y[u] == py && z[u] == pz);
-                if (ok && (val > best || (val == best && jo[u] < bidx))) { best = val; bidx = jo[u]; bpos = jj[u]; bx = x[u]; by = y[u]; bz = z[u]; }
+                for (int u = 0; u < BATCH; ++u) jj[u] = b0 + u < nc ? (s_cand[b0 + u] << 6) + lane : NS;
+                double x[BATCH], y[BATCH], z[BATCH];
+                int jo[BATCH];
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const int j = min(jj[u], NS - 1);
+                    x[u] = fx[j]; y[u] = fy[j]; z[u] = fz[j]; jo[u] = sidx[j];
+                }
+#pragma unroll
+                for (int u = 0; u < BATCH; ++u) {
+                    const double val = fma(dz, z[u], fma(dy, y[u], dx * x[u]));
+                    bool ok = jj[u] < NS && jo[u] != qk;
+                    if (DUPX) ok = ok && !(jo[u] > qk && x[u] == px && y[u] == py && z[u] == pz);
+                    if (ok && (val > best || (val == best && jo[u] < bidx))) { best = val; bidx = jo[u]; bpos = jj[u]; bx = x[u]; by = y[u]; bz = z[u]; }
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            if (tier <= ths) break;                                // the first tier was everything
+            const double wb = wave_max_f64(best);                  // what is found bounds what is still worth a look (ties included)
+            if (wb > -1.0e299) ths = fmax(ths, wb * sc - slacks);
+            tier = ths;
         }
-        __builtin_amdgcn_wave_barrier();
     }
     Support r;
     r.val = wave_max_f64(best);
@@ -565,6 +591,9 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
     // more than the work -- 58 k of 60 k in the pipeline's case)
     for (int qi = blockIdx.x * 4 + wave; qi < nq; qi += gridDim.x * 4) {
     const int q = list[(size_t)v * N + qi];
+#ifdef PD_HPR_STATS
+    const unsigned long long t_begin = wall_clock64();
+#endif
     const d3 pi = {qf[q], qf[N + q], qf[2 * (size_t)N + q]};
     // working set (the query itself and the tail past NS are left out: index -2 never wins)
     const int pq = pos_of[(size_t)v * N + q];
@@ -629,14 +658,15 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
             if (n >= 1) th = fmax(th, dot(dir, W0) + di);
             if (n >= 2) th = fmax(th, dot(dir, W1) + di);
             if (n >= 3) th = fmax(th, dot(dir, W2) + di);
-            th -= (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+            const double slk = (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+            th -= slk;
 #ifdef PD_HPR_STATS
             ++scans;
             unsigned long long* ncp = &cand_chunks;
 #else
             unsigned long long* ncp = nullptr;
 #endif
-            const Support r = support_scan<false, 2>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp,
+            const Support r = support_scan<false, 2>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, slk, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp,
                                                      base >> 6, (base >> 6) + HPR_LOCAL);      // (the working set's own chunks are in myv already)
             if (r.pos >= 0 && (!have || r.val > myv || (r.val == myv && r.idx < si))) {
                 myv = r.val; si = r.idx; sp = d3{r.x, r.y, r.z}; have = true;
@@ -665,6 +695,8 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
         dir = neg(vclose);
     }
 #ifdef PD_HPR_STATS
+    if (lane == 0) { const unsigned long long dt = wall_clock64() - t_begin + (state == 77 ? 1 : 0);
+                     atomicAdd(&g_hpr_t[0], dt); atomicMax(&g_hpr_t[1], dt); if (mk > 0) { atomicAdd(&g_hpr_t[2], dt); atomicAdd(&g_hpr_t[3], 1ull); } }
     if (lane == 0) { atomicAdd(&g_hpr_stats[1][0], 1ull); atomicAdd(&g_hpr_stats[1][1], (unsigned long long)my_rounds); atomicAdd(&g_hpr_stats[1][5], cand_chunks);
                      atomicAdd(&g_hpr_stats[1][6], scans);
                      atomicAdd(&g_hpr_stats[1][2], 1ull); atomicAdd(&g_hpr_stats[1][3], (unsigned long long)my_rounds);
@@ -900,13 +932,14 @@ __global__ __launch_bounds__(512) void k_hpr_exact(const double* __restrict__ fl
                     // nothing below the working set's best, a simplex vertex's value or the eye's can be the support
                     double thr = have ? fmax(m, 0.0) : 0.0;
                     for (int k = 0; k < S.n; ++k) thr = fmax(thr, sgn_of(dot(dir, S.w[k])) + dpi);
-                    thr -= (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+                    const double slk = (4.0 * rb + HPR_BOUND_SLACK * ma) * l1;
+                    thr -= slk;
 #ifdef PD_HPR_STATS
                     unsigned long long ncand = 0;
-                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, &ncand, ws_chunk, ws_chunk + HPR_LOCAL);
+                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, slk, q, px, py, pz, s_cand, lane, &ncand, ws_chunk, ws_chunk + HPR_LOCAL);
                     if (lane == 0) { atomicAdd(&g_hpr_stats[0][5], ncand); atomicAdd(&g_hpr_stats[0][6], 1ull); }
 #else
-                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, q, px, py, pz, s_cand, lane, nullptr, ws_chunk, ws_chunk + HPR_LOCAL);
+                    const Support r = support_scan<true, 2>(fx, fy, fz, sidx, NS, boxes, dxx, dyy, dzz, thr, slk, q, px, py, pz, s_cand, lane, nullptr, ws_chunk, ws_chunk + HPR_LOCAL);
 #endif
                     if (r.pos >= 0 && (!have || r.val > m || (r.val == m && r.idx < mi))) {
                         have = true; m = r.val; spx = r.x; spy = r.y; spz = r.z; spi = r.idx;
