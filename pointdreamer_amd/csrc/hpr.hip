@@ -43,7 +43,7 @@ using namespace pdhip;
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
 __device__ unsigned long long g_hpr_stats[2][16];
-__device__ unsigned long long g_hpr_t[4];                        // level 2: per-query wall time in 100 MHz ticks: sum, max, sum over coarse-set members, their count             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
+__device__ unsigned long long g_hpr_t[8];                        // level 2: per-query wall time in 100 MHz ticks: sum, max, sum over coarse-set members, their count             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
 extern "C" int pdhip_lab_hpr_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hpr_stats), sizeof(g_hpr_stats)) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_hpr_t), sizeof(g_hpr_t)) != hipSuccess) return -1;
@@ -696,7 +696,8 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
     }
 #ifdef PD_HPR_STATS
     if (lane == 0) { const unsigned long long dt = wall_clock64() - t_begin + (state == 77 ? 1 : 0);
-                     atomicAdd(&g_hpr_t[0], dt); atomicMax(&g_hpr_t[1], dt); if (mk > 0) { atomicAdd(&g_hpr_t[2], dt); atomicAdd(&g_hpr_t[3], 1ull); } }
+                     atomicAdd(&g_hpr_t[0], dt); atomicMax(&g_hpr_t[1], dt); if (mk > 0) { atomicAdd(&g_hpr_t[2], dt); atomicAdd(&g_hpr_t[3], 1ull); }
+                     atomicMax(&g_hpr_t[4], scans); if (scans > 3) atomicAdd(&g_hpr_t[5], 1ull); atomicMax(&g_hpr_t[6], cand_chunks); if (dt > 20000) atomicAdd(&g_hpr_t[7], 1ull); }
     if (lane == 0) { atomicAdd(&g_hpr_stats[1][0], 1ull); atomicAdd(&g_hpr_stats[1][1], (unsigned long long)my_rounds); atomicAdd(&g_hpr_stats[1][5], cand_chunks);
                      atomicAdd(&g_hpr_stats[1][6], scans);
                      atomicAdd(&g_hpr_stats[1][2], 1ull); atomicAdd(&g_hpr_stats[1][3], (unsigned long long)my_rounds);

@@ -31,10 +31,11 @@ import ctypes as C
 from pointdreamer_amd import _lib
 try:
     fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_hpr_stats
-    buf = (C.c_ulonglong * 36)()
+    buf = (C.c_ulonglong * 40)()
     fn(buf, 1); got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=vis0); torch.cuda.synchronize(); fn(buf, 1)
     nm = max(buf[18] - buf[35], 1)
     print(f'level 2 per-query wall time (100 MHz ticks -> us): mean {buf[32] / max(buf[18], 1) / 100:.1f}, max {buf[33] / 100:.1f}; members {buf[35]}: mean {buf[34] / max(buf[35], 1) / 100:.1f}; others {nm}: mean {(buf[32] - buf[34]) / nm / 100:.1f}')
+    print('level 2: max scans per query', buf[36], '; queries with > 3 scans', buf[37], '; max candidate chunks of a query', buf[38], '; queries above 20000 ticks', buf[39])
     print('f64 distance iteration: scans', buf[6], 'candidate chunks', buf[5])
     for name, b in (('coarse', buf[0:16]), ('fine', buf[16:32])):
         print(f'{name}: waves {b[0]} mean wave rounds {b[1] / max(b[0], 1):.1f}; queries {b[2]} mean query rounds {b[3] / max(b[2], 1):.1f}; unfinished {b[4]}; rounds histogram (x8) {list(b[8:16])}; candidate chunks per query round {b[5] / max(b[3], 1):.1f}; global scans per query {b[6] / max(b[2], 1):.2f}; f64 distance-iteration rounds {b[7]}')
