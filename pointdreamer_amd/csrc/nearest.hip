@@ -9,7 +9,7 @@ using namespace pdhip;
 
 // Column pass, parallel over (column, 64-row segment).  Pass A records every segment's first / last site row; pass B
 // scans its own segment down and up with the carries taken from the other segments' summaries.
-#define SEG 64
+#define SEG 16                 // (64: a 256^2 x 8 job is 128 wavefronts of 64 dependent iterations -- 27 us of latency)
 template <bool F32MASK>
 __device__ __forceinline__ bool is_site(const void* mask, size_t base, size_t idx) {
     if (F32MASK) return reinterpret_cast<const float*>(mask)[base + idx] != 0.0f;
