@@ -1193,26 +1193,32 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
     float best0 = -3.0e38f, best1 = -3.0e38f;
     int t0 = 0, t1 = 0;
     const double* fa = hi ? fy : fx;                                       // lane l: A[point l & 31][k = l >> 5]: x | y, then z | 0
-    double na, nz, nc, nw;                                                 // the next trip's operands are requested a trip ahead
-    {
-        const int ja = min(p_lo + l31, N - 1), jb = min(p_lo + 32 + l31, N - 1);      // (a repeated point cannot change a maximum)
-        na = fa[ja]; nz = fz[ja]; nc = fa[jb]; nw = fz[jb];
+    // operands are requested four trips (256 points) ahead: a trip is 0.2 us of matrix work against an L2 round trip of 1-2 us
+    double ra[4], rz[4], rc[4], rw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ja = min(p_lo + 64 * u + l31, N - 1), jb = min(p_lo + 64 * u + 32 + l31, N - 1);      // (a repeated point cannot change a maximum)
+        ra[u] = fa[ja]; rz[u] = fz[ja]; rc[u] = fa[jb]; rw[u] = fz[jb];
     }
-    for (int j0 = p_lo; j0 < p_hi; j0 += 64) {                            // two tiles per trip
-        const float a1 = (float)na, a2 = hi ? 0.0f : (float)nz, c1 = (float)nc, c2 = hi ? 0.0f : (float)nw;
-        {
-            const int ja = min(j0 + 64 + l31, N - 1), jb = min(j0 + 96 + l31, N - 1);
-            na = fa[ja]; nz = fz[ja]; nc = fa[jb]; nw = fz[jb];
+    for (int jo = p_lo; jo < p_hi; jo += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                                     // two tiles per trip
+            const int j0 = jo + 64 * u;
+            const float a1 = (float)ra[u], a2 = hi ? 0.0f : (float)rz[u], c1 = (float)rc[u], c2 = hi ? 0.0f : (float)rw[u];
+            {
+                const int ja = min(j0 + 256 + l31, N - 1), jb = min(j0 + 288 + l31, N - 1);
+                ra[u] = fa[ja]; rz[u] = fz[ja]; rc[u] = fa[jb]; rw[u] = fz[jb];
+            }
+            f32x16 A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0), A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);
+            f32x16 B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_0, zero, 0, 0, 0), B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_1, zero, 0, 0, 0);
+            A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, A1, 0, 0, 0);
+            B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_0, B0, 0, 0, 0); B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_1, B1, 0, 0, 0);
+            const float ma0 = tile_max(A0), ma1 = tile_max(A1), mb0 = tile_max(B0), mb1 = tile_max(B1);
+            if (ma0 > best0) { best0 = ma0; t0 = j0; }
+            if (ma1 > best1) { best1 = ma1; t1 = j0; }
+            if (mb0 > best0) { best0 = mb0; t0 = j0 + 32; }
+            if (mb1 > best1) { best1 = mb1; t1 = j0 + 32; }
         }
-        f32x16 A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0), A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);
-        f32x16 B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_0, zero, 0, 0, 0), B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_1, zero, 0, 0, 0);
-        A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, A1, 0, 0, 0);
-        B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_0, B0, 0, 0, 0); B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_1, B1, 0, 0, 0);
-        const float ma0 = tile_max(A0), ma1 = tile_max(A1), mb0 = tile_max(B0), mb1 = tile_max(B1);
-        if (ma0 > best0) { best0 = ma0; t0 = j0; }
-        if (ma1 > best1) { best1 = ma1; t1 = j0; }
-        if (mb0 > best0) { best0 = mb0; t0 = j0 + 32; }
-        if (mb1 > best1) { best1 = mb1; t1 = j0 + 32; }
     }
     // the row inside the best tile: the lane's 16 rows, the same fmaf chain (bitwise the matrix core's values)
     int i0 = -1, i1 = -1;
