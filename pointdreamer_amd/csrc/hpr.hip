@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
                                                     const int* __restrict__ list, const float4* __restrict__ csf /*[V][KC]*/,
                                                     const double* __restrict__ csd /*[V][KC][4]*/, const int* __restrict__ cidx /*[V][KC]*/,
                                                     const int* __restrict__ kcount, uint8_t* __restrict__ outside,
-                                                    const unsigned long long* __restrict__ maxabs) {
+                                                    const unsigned long long* __restrict__ maxabs, double* __restrict__ qdir /*[V][N][3]*/) {
     const int v = blockIdx.y;
     const int nq = count[v];
     const int lane = threadIdx.x & 63, l31 = lane & 31;
@@ -416,6 +416,10 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
                  atomicAdd(&g_hpr_stats[0][8 + min(my_rounds, 63) / 8], 1ull); }
 #endif
     if (owner) outside[(size_t)v * N + q] = g.state != 2;        // 0: CERTIFIED enclosed by the coarse hull: hidden, and never a support point
+    if (owner && g.state != 2) {                                  // level 2 starts where this level stopped looking
+        double* qd = qdir + ((size_t)v * N + q) * 3;
+        qd[0] = g.dir.x; qd[1] = g.dir.y; qd[2] = g.dir.z;
+    }
 }
 
 // ---- level 2: the queries the coarse hull cannot enclose, against the points outside the coarse hull, which are sorted by a
@@ -572,6 +576,7 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
                                                        const int* __restrict__ sidx_all, const int* __restrict__ scount,
                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of,
                                                        const int* __restrict__ mdir /*may be null*/, const double* __restrict__ fdir,
+                                                       const double* __restrict__ qdir /*may be null*/,
                                                        const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
                                                        int* __restrict__ unc_list, int* __restrict__ unc_seed) {
     __shared__ int s_cand[4][256];
@@ -616,6 +621,11 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
     // direction, in which it is most likely separated from everything else -- one certified scan instead of an iteration
     const int mk = mdir != nullptr ? mdir[(size_t)v * N + q] : 0;
     if (mk > 0) dir = d3{fdir[4 * (mk - 1)], fdir[4 * (mk - 1) + 1], fdir[4 * (mk - 1) + 2]};
+    else if (qdir != nullptr) {
+        const double* qd = qdir + ((size_t)v * N + q) * 3;
+        const d3 dq = {qd[0], qd[1], qd[2]};
+        if (!zero3(dq)) dir = dq;
+    }
     int I0 = -2, I1 = -2, I2 = -2, n = 0, state = 0;
 #ifdef PD_HPR_STATS
     int my_rounds = 0;
@@ -1276,7 +1286,7 @@ static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int
 // maxabs u64[64] at 1024, bounding-box keys u64[64][6] at 2048, six per-view counters int[64] at 5120
 #define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
-    return HPR_HEAD_BYTES + 2 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
+    return HPR_HEAD_BYTES + 3 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
            a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V) + a256((size_t)HPR_KC * 4 * sizeof(double));
 }
 
@@ -1316,6 +1326,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     int* cidx = reinterpret_cast<int*>(p); p += a256((size_t)V * HPR_KC * sizeof(int));
     float4* boxes = reinterpret_cast<float4*>(p); p += boxes_bytes(V, N);
     double* fdir = reinterpret_cast<double*>(p); p += a256((size_t)HPR_KC * 4 * sizeof(double));
+    double* qdir = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     dim3 gf(min(cdiv(N, 256), 256), V);
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
     k_hpr_flip<<<dim3(min(cdiv(N, 256), 32), V), 256, 0, s>>>       // (few waves: each ends with seven atomics on the view's extrema)
@@ -1326,13 +1337,13 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     if (two_level) {
         k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, ekeys);
         k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir, fdir);
-        k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs);
+        k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs, qdir);
     }
     k_hpr_bin<<<gf, 256, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
     k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
     k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
-    k_hpr_fine_dist<<<dim3(min(cdiv(N, 4), 512), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, two_level ? mdir : nullptr, fdir, maxabs, ucount, ulist, useed);
+    k_hpr_fine_dist<<<dim3(min(cdiv(N, 4), 512), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, two_level ? mdir : nullptr, fdir, two_level ? qdir : nullptr, maxabs, ucount, ulist, useed);
     k_hpr_exact<double><<<dim3(64, V), 64, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, u2count, u2list, u2seed, counters);
     k_hpr_exact<dd><<<dim3(32, V), 512, 0, s>>>(flipped, N, u2count, u2list, u2seed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, nullptr, nullptr, nullptr, counters);
     PD_LAUNCH_CHECK();
