@@ -532,6 +532,9 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
 // "visible" and "no progress" need the whole support set: then one box-culled global scan looks for points with
 // d.p' >= the working set's best (next to a hull vertex that is one or two chunks); what it returns joins the working set.
 #define HPR_LOCAL 4
+#ifndef HPR_SCAN_BATCH
+#define HPR_SCAN_BATCH 2
+#endif
 // The iteration is GJK proper, the DISTANCE form (the search direction is minus the closest point of the simplex to the
 // origin; the distance decreases every round, so it cannot cycle the way the boolean form does on nearly degenerate input).  The
 // closest-point sub-problem is solved across the lanes: the closest point of conv{a, w0, w1, w2} lies on a face that contains
@@ -539,6 +542,9 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
 // origin on the face's affine hull through its 3x3 (padded) Gram system by Cramer's rule, keep the candidates whose barycentric
 // coordinates are all positive (they are points of the simplex, and the true closest point is one of them), take the nearest.
 // No branches on the simplex size.
+// (The kernel is bound by VALU issue -- every lane executes a round's ~900 instructions for the one query.  Variants with one query
+// per 16- or 32-lane group, i.e. 4x / 2x fewer instructions per query, ended at the same 105-110 us for the pipeline's 6 500
+// queries: with 1 600 waves the chip runs out of waves to hide a round's dependent chain behind.)
 __device__ __forceinline__ d3 sel3(bool c, d3 a, d3 b) { return d3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }      // (by component: a struct select goes through memory)
 __device__ __forceinline__ bool closest_with_newest(const d3 a, d3& W0, d3& W1, d3& W2, int& I0, int& I1, int& I2, int& n, const int ai,
                                                     d3& v, const int lane) {
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
 #else
             unsigned long long* ncp = nullptr;
 #endif
-            const Support r = support_scan<false, 2>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, slk, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp,
+            const Support r = support_scan<false, HPR_SCAN_BATCH>(fx, fy, fz, sidx, NS, boxes, dx, dy, dz, th, slk, q, 0.0, 0.0, 0.0, s_cand[wave], lane, ncp,
                                                      base >> 6, (base >> 6) + HPR_LOCAL);      // (the working set's own chunks are in myv already)
             if (r.pos >= 0 && (!have || r.val > myv || (r.val == myv && r.idx < si))) {
                 myv = r.val; si = r.idx; sp = d3{r.x, r.y, r.z}; have = true;
