@@ -192,41 +192,29 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 }
 __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* __restrict__ eyes, double radius,
                            double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/,
-                           unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/) {
+                           unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/,
+                           const uint8_t* __restrict__ skip, int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis) {
     // open3d PointCloud::HiddenPointRemoval: p' = q + 2 (radius - |q|) q / |q| evaluated as q + ((2 (radius - n)) q) / n
-    const int v = blockIdx.y;
-    const double ex = eyes[3 * v], ey = eyes[3 * v + 1], ez = eyes[3 * v + 2];
-    double m = 0.0, b[6] = {-1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
-        const double qx = (double)pts[3 * i] - ex, qy = (double)pts[3 * i + 1] - ey, qz = (double)pts[3 * i + 2] - ez;
-        double n = sqrt(qx * qx + qy * qy + qz * qz);
-        if (n == 0.0) n = 0.0001;
-        const double k = 2.0 * (radius - n);
-        double* f = flipped + (size_t)v * 3 * N;
-        const double x = qx + (k * qx) / n, y = qy + (k * qy) / n, z = qz + (k * qz) / n;
-        f[i] = x; f[N + i] = y; f[2 * (size_t)N + i] = z;
-        m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
-        b[0] = fmax(b[0], -x); b[1] = fmax(b[1], -y); b[2] = fmax(b[2], -z); b[3] = fmax(b[3], x); b[4] = fmax(b[4], y); b[5] = fmax(b[5], z);
-    }
-    m = wave_max_f64(m);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) b[k] = wave_max_f64(b[k]);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&maxabs[v], (unsigned long long)__double_as_longlong(m));   // non-negative f64: bit order = value order
-#pragma unroll
-        for (int k = 0; k < 6; ++k) atomicMax(&bbox[6 * v + k], f64_key(b[k]));
-    }
-}
-
-// queries that still need the hull test: all points, or only those a cheaper test (`skip`) has not already accepted
-__global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __restrict__ count, int* __restrict__ list,
-                              uint8_t* __restrict__ vis) {
-    // one returning atomic per 256-thread block (a returning atomic on one address costs ~100 ns; per wave it serialised to 45 us)
+    // Also here: the queries that still need the hull test -- all points, or only those a cheaper test (`skip`) has not already
+    // accepted (those are marked visible) -- compacted into `list` with one returning atomic per 256-thread block and step.
     __shared__ int s_wcnt[4], s_base;
     const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double ex = eyes[3 * v], ey = eyes[3 * v + 1], ez = eyes[3 * v + 2];
+    double m = 0.0, b[6] = {-1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300};
     for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
         const int i = i0 + threadIdx.x;
         const bool in = i < N;
+        if (in) {
+            const double qx = (double)pts[3 * i] - ex, qy = (double)pts[3 * i + 1] - ey, qz = (double)pts[3 * i + 2] - ez;
+            double n = sqrt(qx * qx + qy * qy + qz * qz);
+            if (n == 0.0) n = 0.0001;
+            const double k = 2.0 * (radius - n);
+            double* f = flipped + (size_t)v * 3 * N;
+            const double x = qx + (k * qx) / n, y = qy + (k * qy) / n, z = qz + (k * qz) / n;
+            f[i] = x; f[N + i] = y; f[2 * (size_t)N + i] = z;
+            m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
+            b[0] = fmax(b[0], -x); b[1] = fmax(b[1], -y); b[2] = fmax(b[2], -z); b[3] = fmax(b[3], x); b[4] = fmax(b[4], y); b[5] = fmax(b[5], z);
+        }
         const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
         const bool q = in && !sk;
         const unsigned long long bal = __ballot(q);
@@ -240,7 +228,24 @@ __global__ void k_hpr_collect(const uint8_t* __restrict__ skip, int N, int* __re
         else if (sk) vis[(size_t)v * N + i] = 1;
         __syncthreads();
     }
+    m = wave_max_f64(m);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) b[k] = wave_max_f64(b[k]);
+    // one set of atomics per block (they all land on the view's seven words: per wave they serialised to 45 us)
+    __shared__ double s_r[4][7];
+    if ((threadIdx.x & 63) == 0) {
+        s_r[wave][0] = m;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_r[wave][1 + k] = b[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const double r = fmax(fmax(s_r[0][threadIdx.x], s_r[1][threadIdx.x]), fmax(s_r[2][threadIdx.x], s_r[3][threadIdx.x]));
+        if (threadIdx.x == 0) atomicMax(&maxabs[v], (unsigned long long)__double_as_longlong(r));   // non-negative f64: bit order = value order
+        else atomicMax(&bbox[6 * v + threadIdx.x - 1], f64_key(r));
+    }
 }
+
 
 // what a query lane does with the support point of its round: myv = the largest support value over the real points (real_pt: one
 // was found; sp / sp_idx = that point and its cloud index).  The support of S_i is that point or the eye (value 0).
@@ -1335,9 +1340,8 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     double* qdir = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     dim3 gf(min(cdiv(N, 256), 256), V);
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
-    k_hpr_flip<<<dim3(min(cdiv(N, 256), 32), V), 256, 0, s>>>       // (few waves: each ends with seven atomics on the view's extrema)
-       (points, N, eyes_dev, radius, flipped, maxabs, bbox);
-    k_hpr_collect<<<gf, 256, 0, s>>>(skip, N, count, list, visibility);      // marks the skipped points visible; `list` = the queries
+    k_hpr_flip<<<dim3(min(cdiv(N, 256), 128), V), 256, 0, s>>>
+       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility);      // (+ marks the skipped points visible; `list` = the queries)
     constexpr int KC = HPR_KC;
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     if (two_level) {
