@@ -190,14 +190,14 @@ __device__ __forceinline__ unsigned long long f64_key(double x) {            // 
 __device__ __forceinline__ double key_f64(unsigned long long k) {
     return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
 }
-__global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* __restrict__ eyes, double radius,
+__global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts, int N, const double* __restrict__ eyes, double radius,
                            double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/,
                            unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/,
                            const uint8_t* __restrict__ skip, int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis) {
     // open3d PointCloud::HiddenPointRemoval: p' = q + 2 (radius - |q|) q / |q| evaluated as q + ((2 (radius - n)) q) / n
     // Also here: the queries that still need the hull test -- all points, or only those a cheaper test (`skip`) has not already
     // accepted (those are marked visible) -- compacted into `list` with one returning atomic per 256-thread block and step.
-    __shared__ int s_wcnt[4], s_base;
+    __shared__ int s_wcnt[16], s_base;
     const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double ex = eyes[3 * v], ey = eyes[3 * v + 1], ez = eyes[3 * v + 2];
     double m = 0.0, b[6] = {-1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300};
@@ -220,10 +220,12 @@ __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* _
         const unsigned long long bal = __ballot(q);
         if (lane == 0) s_wcnt[wave] = __popcll(bal);
         __syncthreads();
-        if (threadIdx.x == 0) s_base = atomicAdd(&count[v], s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        int mine = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = s_wcnt[w]; mine += w < wave ? c : 0; tot += c; }
+        if (threadIdx.x == 0) s_base = atomicAdd(&count[v], tot);
         __syncthreads();
-        int base = s_base;
-        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        const int base = s_base + mine;
         if (q) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         else if (sk) vis[(size_t)v * N + i] = 1;
         __syncthreads();
@@ -232,7 +234,7 @@ __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* _
 #pragma unroll
     for (int k = 0; k < 6; ++k) b[k] = wave_max_f64(b[k]);
     // one set of atomics per block (they all land on the view's seven words: per wave they serialised to 45 us)
-    __shared__ double s_r[4][7];
+    __shared__ double s_r[16][7];
     if ((threadIdx.x & 63) == 0) {
         s_r[wave][0] = m;
 #pragma unroll
@@ -240,7 +242,8 @@ __global__ void k_hpr_flip(const float* __restrict__ pts, int N, const double* _
     }
     __syncthreads();
     if (threadIdx.x < 7) {
-        const double r = fmax(fmax(s_r[0][threadIdx.x], s_r[1][threadIdx.x]), fmax(s_r[2][threadIdx.x], s_r[3][threadIdx.x]));
+        double r = s_r[0][threadIdx.x];
+        for (int w = 1; w < 16; ++w) r = fmax(r, s_r[w][threadIdx.x]);
         if (threadIdx.x == 0) atomicMax(&maxabs[v], (unsigned long long)__double_as_longlong(r));   // non-negative f64: bit order = value order
         else atomicMax(&bbox[6 * v + threadIdx.x - 1], f64_key(r));
     }
@@ -1067,10 +1070,10 @@ __device__ __forceinline__ int spread3(int x) {                               //
     return x;
 }
 // outside == nullptr: one-level mode, every point is a support point and every not-skipped point a query
-__global__ void k_hpr_bin(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside, const uint8_t* __restrict__ skip,
+__global__ __launch_bounds__(1024) void k_hpr_bin(const double* __restrict__ flipped, int N, const uint8_t* __restrict__ outside, const uint8_t* __restrict__ skip,
                           const unsigned long long* __restrict__ bbox /*[V][6] keys of max(-x,-y,-z), max(x,y,z)*/, int* __restrict__ cellkey,
                           int* __restrict__ hist, int* __restrict__ count2, int* __restrict__ list2, uint8_t* __restrict__ vis) {
-    __shared__ int s_wcnt[4], s_base;
+    __shared__ int s_wcnt[16], s_base;                            // (1024-lane blocks: the returning atomic below is ~0.2 us per block)
     const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* f = flipped + (size_t)v * 3 * N;
     double lo[3], sc[3];
@@ -1100,10 +1103,12 @@ __global__ void k_hpr_bin(const double* __restrict__ flipped, int N, const uint8
         const unsigned long long bal = __ballot(qry);
         if (lane == 0) s_wcnt[wave] = __popcll(bal);
         __syncthreads();
-        if (threadIdx.x == 0) s_base = atomicAdd(&count2[v], s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3]);
+        int mine = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = s_wcnt[w]; mine += w < wave ? c : 0; tot += c; }
+        if (threadIdx.x == 0) s_base = atomicAdd(&count2[v], tot);
         __syncthreads();
-        int base = s_base;
-        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        const int base = s_base + mine;
         if (qry) list2[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
         __syncthreads();
     }
@@ -1340,7 +1345,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     double* qdir = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     dim3 gf(min(cdiv(N, 256), 256), V);
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
-    k_hpr_flip<<<dim3(min(cdiv(N, 256), 128), V), 256, 0, s>>>
+    k_hpr_flip<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>
        (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility);      // (+ marks the skipped points visible; `list` = the queries)
     constexpr int KC = HPR_KC;
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
@@ -1349,7 +1354,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
         k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir, fdir);
         k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs, qdir);
     }
-    k_hpr_bin<<<gf, 256, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
+    k_hpr_bin<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
     k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
     k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
