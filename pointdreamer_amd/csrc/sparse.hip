@@ -25,6 +25,8 @@ struct SparseWs {
     int32_t* nn_idx;      // [V][r*r]
     int32_t* pp;          // [V][N] packed (row<<16|col) or -1
     uint32_t* minidx;     // [V][r*r] smallest valid point index landing on the pixel (0xffffffff: none)
+    uint32_t* edge_cnt;   // [V] number of edge pixels
+    int32_t* edge_list;   // [V][r*r] edge pixels (row * res + col), any order
 };
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -42,6 +44,8 @@ static SparseWs carve(void* ws, int V, int N, int res, size_t* total) {
     w.nn_idx = (int32_t*)(base + off); off += align256(4 * px);
     w.pp = (int32_t*)(base + off); off += align256(4 * (size_t)V * (N > 0 ? N : 1));
     w.minidx = (uint32_t*)(base + off); off += align256(4 * px);
+    w.edge_cnt = (uint32_t*)(base + off); off += align256(4 * (size_t)V);
+    w.edge_list = (int32_t*)(base + off); off += align256(4 * px);
     if (total) *total = off;
     return w;
 }
@@ -116,8 +120,9 @@ __device__ __forceinline__ void bilinear_taps_s(int n_in, int n_out, int d, int&
 // new foreground mask (Resize+Pad when the view is rescaled) and winner-buffer init
 __global__ void k_sparse_mask(const uint8_t* __restrict__ hard, int res, const ViewParams* __restrict__ params,
                               uint8_t* __restrict__ mask_new, uint32_t* __restrict__ winA, uint32_t* __restrict__ winB,
-                              uint32_t* __restrict__ minidx) {
+                              uint32_t* __restrict__ minidx, uint32_t* __restrict__ edge_cnt) {
     const int v = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) edge_cnt[v] = 0;
     const ViewParams p = params[v];
     const uint8_t* src = hard + (size_t)v * res * res;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < res * res; idx += gridDim.x * blockDim.x) {
@@ -183,40 +188,73 @@ __global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* _
 // P6 + edge colouring: one block per (view,row).  Every inner-edge pixel takes the colour of its nearest valid point
 // (exact integer distance, ties -> smallest point index): one wave per edge pixel searches the per-pixel min-index image
 // in a growing square window -- the window is exhaustive once its radius covers the best distance found.
-__global__ void k_sparse_edges(const uint8_t* __restrict__ mask_new, int N, int res, int edge_point_size,
-                               const ViewParams* __restrict__ params, const uint32_t* __restrict__ minidx,
-                               uint32_t* __restrict__ winB, int32_t* __restrict__ nn_idx) {
-    const int v = blockIdx.y, row = blockIdx.x;
+// P6a: the edge pixels (foreground with a background 8-neighbour) of every view, compacted into one list per view (one returning
+// atomic per image row).  P6b then gives every edge pixel a wavefront of its own: with one workgroup per row the rows tangent to
+// the silhouette (up to ~100 edge pixels) were the whole kernel time (38 us).
+#define EDGE_BAND 8             // image rows per workgroup: ONE returning atomic per band (same-address atomics cost ~0.1-0.2 us each)
+__global__ __launch_bounds__(1024) void k_sparse_edge_list(const uint8_t* __restrict__ mask_new, int res, const ViewParams* __restrict__ params,
+                                                           uint32_t* __restrict__ edge_cnt, int32_t* __restrict__ edge_list) {
+    const int v = blockIdx.y, row0 = blockIdx.x * EDGE_BAND;
     const ViewParams p = params[v];
     if (p.degenerate) return;
-    extern __shared__ int s_edge[];            // [res] edge columns of this row
-    __shared__ int s_n;
+    __shared__ int s_wcnt[16], s_base;
     const uint8_t* m = mask_new + (size_t)v * res * res;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    for (int col = threadIdx.x; col < res; col += blockDim.x) {
-        bool fg = m[row * res + col];
-        bool bgn = false;
-        if (fg) {
-            for (int dy = -1; dy <= 1; ++dy) {
-                int y = row + dy;
-                if (y < 0 || y >= res) continue;
-                for (int dx = -1; dx <= 1; ++dx) {
-                    int x = col + dx;
-                    if (x < 0 || x >= res) continue;
-                    bgn |= !m[y * res + x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npix = min(EDGE_BAND, res - row0) * res;
+    int running = 0;                                              // edge pixels of the earlier steps of this band (block-uniform)
+    // two sweeps over the band: count, reserve the band's slice of the list, write
+    for (int pass = 0; pass < 2; ++pass) {
+        int total = 0;
+        for (int i0 = 0; i0 < npix; i0 += 1024) {
+            const int i = i0 + (int)threadIdx.x;
+            bool edge = false;
+            int lin = 0;
+            if (i < npix) {
+                const int row = row0 + i / res, col = i - (i / res) * res;
+                lin = row * res + col;
+                if (m[lin]) {
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const int y = row + dy;
+                        if (y < 0 || y >= res) continue;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int x = col + dx;
+                            if (x < 0 || x >= res) continue;
+                            edge |= !m[y * res + x];
+                        }
+                    }
                 }
             }
+            const unsigned long long bal = __ballot(edge);
+            if (lane == 0) s_wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int mine = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { const int c = s_wcnt[w]; mine += w < wave ? c : 0; tot += c; }
+            if (pass == 1 && edge) edge_list[(size_t)v * res * res + s_base + running + mine + __popcll(bal & ((1ull << lane) - 1ull))] = lin;
+            if (pass == 1) running += tot;
+            total += tot;
+            __syncthreads();
         }
-        if (fg && bgn) s_edge[atomicAdd(&s_n, 1)] = col;
+        if (pass == 0) {
+            if (threadIdx.x == 0) s_base = total > 0 ? (int)atomicAdd(&edge_cnt[v], (uint32_t)total) : 0;
+            __syncthreads();
+        }
     }
-    __syncthreads();
-    const int ne = s_n;
+}
+
+__global__ void k_sparse_edges(const int32_t* __restrict__ edge_list, const uint32_t* __restrict__ edge_cnt, int res, int edge_point_size,
+                               const ViewParams* __restrict__ params, const uint32_t* __restrict__ minidx,
+                               uint32_t* __restrict__ winB, int32_t* __restrict__ nn_idx) {
+    const int v = blockIdx.y;
+    const ViewParams p = params[v];
+    if (p.degenerate) return;
+    const int ne = (int)edge_cnt[v];
     const int ge = 2 * edge_point_size - 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const uint32_t* mi = minidx + (size_t)v * res * res;
-    for (int e = wave; e < ne; e += nw) {
-        const int col = s_edge[e];
+    for (int e = blockIdx.x * nw + wave; e < ne; e += gridDim.x * nw) {
+        const int lin0 = edge_list[(size_t)v * res * res + e];
+        const int row = lin0 / res, col = lin0 - row * res;
         unsigned long long best = ~0ull;
         int rho = 8;
         while (true) {
@@ -312,13 +350,12 @@ extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colo
     const float omt = (float)(1.0 - mask_ratio_thresh);
     k_sparse_counts<<<V, 1024, 0, s>>>(hard_masks, validation, N, res, thr, omt, w.params, w.counts);
     dim3 gm(min(cdiv((long long)res * res, 256), 256), V);
-    k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB, w.minidx);
+    k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB, w.minidx, w.edge_cnt);
     if (N > 0) {
         dim3 gs(min(cdiv(N, 256), 256), V);
         k_sparse_splat<<<gs, 256, 0, s>>>(point_pixels, validation, N, res, point_size, w.params, w.winA, w.pp, w.minidx);
-        dim3 ge(res, V);
-        k_sparse_edges<<<ge, 256, res * sizeof(int), s>>>(w.mask_new, N, res, edge_point_size, w.params, w.minidx, w.winB,
-                                                         w.nn_idx);
+        k_sparse_edge_list<<<dim3(cdiv(res, EDGE_BAND), V), 1024, 0, s>>>(w.mask_new, res, w.params, w.edge_cnt, w.edge_list);
+        k_sparse_edges<<<dim3(256, V), 256, 0, s>>>(w.edge_list, w.edge_cnt, res, edge_point_size, w.params, w.minidx, w.winB, w.nn_idx);
     }
     k_sparse_compose<<<gm, 256, 0, s>>>(colors, res, point_size, edge_point_size, w.params, w.mask_new, w.winA, w.winB,
                                         w.nn_idx, sparse, mask0, mask2, scale_factors);
