@@ -9,45 +9,9 @@ using namespace pdhip;
 #define MAXV 32
 
 // ------------------------------------------------------------------------------ Uq1 + Uq2
+// (measured: four texels per thread with 16-byte position loads and 4-byte verdict stores is SLOWER, 34 vs 28 us -- the kernel is
+// bound by the eight scattered depth-map reads per texel, which want more threads in flight, not fewer instructions)
 __global__ void k_texel_visibility(const float* __restrict__ cams, int V, const float* __restrict__ gb_pos,
-                                   const uint8_t* __restrict__ mask, int A, const float* __restrict__ uv_centers,
-                                   const float* __restrict__ uv_scales, float pad9, const float* __restrict__ mesh,
-                                   int R, float offset, uint8_t* __restrict__ vis) {
-    // four consecutive texels per thread: the positions are three 16-byte loads, every view's verdicts one 4-byte store (a byte
-    // store per lane and view made the kernel store-issue bound).  A * A is a multiple of 4 on this path (checked by the caller).
-    const size_t n = (size_t)A * A;
-    for (size_t idx = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 4; idx < n; idx += (size_t)gridDim.x * blockDim.x * 4) {
-        const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mask + idx);
-        float p[12];
-        if (m4) {
-            const float4* g = reinterpret_cast<const float4*>(gb_pos + 3 * idx);
-            const float4 a = g[0], b = g[1], c = g[2];
-            p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w; p[8] = c.x; p[9] = c.y; p[10] = c.z; p[11] = c.w;
-        }
-        for (int v = 0; v < V; ++v) {
-            uint32_t o4 = 0;
-            if (m4) {
-                const Cam c = load_cam(cams + 16 * v);
-                const float ucx = uv_centers[2 * v], ucy = uv_centers[2 * v + 1], us = uv_scales[v];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (!((m4 >> (8 * t)) & 0xffu)) continue;
-                    float xn, yn, zn;
-                    cam_transform(c, p[3 * t], p[3 * t + 1], p[3 * t + 2], xn, yn, zn);
-                    const float u = ((xn - ucx) / us) * pad9 + 0.5f;
-                    const float w = ((yn - ucy) / us) * pad9 + 0.5f;
-                    const int col = clip_to_int(u * (float)R, R - 1);
-                    const int row = clip_to_int(w * (float)R, R - 1);
-                    const float ref = mesh[((size_t)v * R + row) * R + col];
-                    if ((zn - ref) <= offset) o4 |= 1u << (8 * t);
-                }
-            }
-            *reinterpret_cast<uint32_t*>(vis + (size_t)v * n + idx) = o4;
-        }
-    }
-}
-// (any atlas size: one texel per thread)
-__global__ void k_texel_visibility_1(const float* __restrict__ cams, int V, const float* __restrict__ gb_pos,
                                      const uint8_t* __restrict__ mask, int A, const float* __restrict__ uv_centers,
                                      const float* __restrict__ uv_scales, float pad9, const float* __restrict__ mesh,
                                      int R, float offset, uint8_t* __restrict__ vis) {
@@ -81,13 +45,8 @@ extern "C" int pdhip_texel_visibility(const float* cam_params, int V, const floa
     PD_REQUIRE(cam_params && gb_pos && mask && uv_centers && uv_scales && mesh_depths && visibility,
                "pdhip_texel_visibility: null pointer");
     const float pad9 = (float)(1.0 - 2.0 * padding);
-    const bool vec4 = ((long long)A * A) % 4 == 0 && ((uintptr_t)mask & 3) == 0 && ((uintptr_t)visibility & 3) == 0 && ((uintptr_t)gb_pos & 15) == 0;
-    if (vec4)
-        k_texel_visibility<<<min(cdiv((long long)A * A, 1024), 4096), 256, 0, as_stream(stream)>>>(
-            cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility);
-    else
-        k_texel_visibility_1<<<min(cdiv((long long)A * A, 256), 4096), 256, 0, as_stream(stream)>>>(
-            cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility);
+    k_texel_visibility<<<min(cdiv((long long)A * A, 256), 4096), 256, 0, as_stream(stream)>>>(
+        cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
