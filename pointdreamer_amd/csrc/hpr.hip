@@ -43,12 +43,16 @@ using namespace pdhip;
 
 #ifdef PD_HPR_STATS                                       // (lab builds only: round statistics of the two GJK passes)
 __device__ unsigned long long g_hpr_stats[2][16];
-__device__ unsigned long long g_hpr_t[8];                        // level 2: per-query wall time in 100 MHz ticks: sum, max, sum over coarse-set members, their count             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
+__device__ unsigned long long g_hpr_t[8];
+__device__ unsigned long long g_hpr_c[8];                        // level 1: core-clock cycles per phase, summed over wave rounds: B operands, scan, re-evaluation + join, step, rounds
+__device__ __forceinline__ unsigned long long lab_clock() { unsigned long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }                        // level 2: per-query wall time in 100 MHz ticks: sum, max, sum over coarse-set members, their count             // [pass][waves, wave rounds, queries, query rounds, unfinished, -, -, -, histogram of query rounds / 8]
 extern "C" int pdhip_lab_hpr_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hpr_stats), sizeof(g_hpr_stats)) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_hpr_t), sizeof(g_hpr_t)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out + 40, HIP_SYMBOL(g_hpr_c), sizeof(g_hpr_c)) != hipSuccess) return -1;
     if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_stats), z, sizeof(z)) != hipSuccess) return -1;
-                 if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_t), z, sizeof(g_hpr_t)) != hipSuccess) return -1; }
+                 if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_t), z, sizeof(g_hpr_t)) != hipSuccess) return -1;
+                 if (hipMemcpyToSymbol(HIP_SYMBOL(g_hpr_c), z, sizeof(g_hpr_c)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -193,7 +197,8 @@ __device__ __forceinline__ double key_f64(unsigned long long k) {
 __global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts, int N, const double* __restrict__ eyes, double radius,
                            double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/,
                            unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/,
-                           const uint8_t* __restrict__ skip, int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis) {
+                           const uint8_t* __restrict__ skip, int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis,
+                           int collect) {
     // open3d PointCloud::HiddenPointRemoval: p' = q + 2 (radius - |q|) q / |q| evaluated as q + ((2 (radius - n)) q) / n
     // Also here: the queries that still need the hull test -- all points, or only those a cheaper test (`skip`) has not already
     // accepted (those are marked visible) -- compacted into `list` with one returning atomic per 256-thread block and step.
@@ -215,20 +220,22 @@ __global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts
             m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
             b[0] = fmax(b[0], -x); b[1] = fmax(b[1], -y); b[2] = fmax(b[2], -z); b[3] = fmax(b[3], x); b[4] = fmax(b[4], y); b[5] = fmax(b[5], z);
         }
-        const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
-        const bool q = in && !sk;
-        const unsigned long long bal = __ballot(q);
-        if (lane == 0) s_wcnt[wave] = __popcll(bal);
-        __syncthreads();
-        int mine = 0, tot = 0;
+        if (collect) {                                               // (one-level mode; with two levels k_hpr_shield builds the list)
+            const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
+            const bool q = in && !sk;
+            const unsigned long long bal = __ballot(q);
+            if (lane == 0) s_wcnt[wave] = __popcll(bal);
+            __syncthreads();
+            int mine = 0, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { const int c = s_wcnt[w]; mine += w < wave ? c : 0; tot += c; }
-        if (threadIdx.x == 0) s_base = atomicAdd(&count[v], tot);
-        __syncthreads();
-        const int base = s_base + mine;
-        if (q) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        else if (sk) vis[(size_t)v * N + i] = 1;
-        __syncthreads();
+            for (int w = 0; w < 16; ++w) { const int c = s_wcnt[w]; mine += w < wave ? c : 0; tot += c; }
+            if (threadIdx.x == 0) s_base = atomicAdd(&count[v], tot);
+            __syncthreads();
+            const int base = s_base + mine;
+            if (q) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            else if (sk) vis[(size_t)v * N + i] = 1;
+            __syncthreads();
+        }
     }
     m = wave_max_f64(m);
 #pragma unroll
@@ -249,6 +256,107 @@ __global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts
     }
 }
 
+
+// ---- level 0, the shield: most of the points the depth test rejects are far behind the outer shell of the flipped cloud, and for
+// those a GJK iteration is a waste -- a fixed tetrahedron (eye, A, B, C) with A, B, C the outermost points of three cells of a
+// direction grid placed around the query's own cell almost always encloses them.  The grid is the gnomonic projection on the cube
+// face the view's bounding box points at (64 x 64 cells over the box's extent); a cell keeps its point of largest radius.  The
+// verdict is the same certificate as everywhere (four f64 determinants with the static filter, on cloud points), so nothing is
+// assumed about the grid: a failed test just leaves the query to level 1.  81 % of the hidden points of a 30 k cloud end here.
+#define HPR_GRID 64
+struct GridMap { int k, a, b, ok; double u0, us, w0, ws; };
+__device__ __forceinline__ GridMap grid_map(const unsigned long long* __restrict__ bbox, int v) {
+    double lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = -key_f64(bbox[6 * v + k]); hi[k] = key_f64(bbox[6 * v + 3 + k]); }
+    GridMap g;
+    const double cx = fabs(lo[0] + hi[0]), cy = fabs(lo[1] + hi[1]), cz = fabs(lo[2] + hi[2]);
+    g.k = (cx >= cy && cx >= cz) ? 0 : (cy >= cz ? 1 : 2);
+    g.a = (g.k + 1) % 3; g.b = (g.k + 2) % 3;
+    const double lk = g.k == 0 ? lo[0] : (g.k == 1 ? lo[1] : lo[2]), hk = g.k == 0 ? hi[0] : (g.k == 1 ? hi[1] : hi[2]);
+    const double la = g.a == 0 ? lo[0] : (g.a == 1 ? lo[1] : lo[2]), ha = g.a == 0 ? hi[0] : (g.a == 1 ? hi[1] : hi[2]);
+    const double lb = g.b == 0 ? lo[0] : (g.b == 1 ? lo[1] : lo[2]), hb = g.b == 0 ? hi[0] : (g.b == 1 ? hi[1] : hi[2]);
+    g.ok = (lk > 0.0 && hk > 0.0) || (lk < 0.0 && hk < 0.0);      // the whole cloud on one side of the eye along that axis
+    const double u1 = la / lk, u2 = la / hk, u3 = ha / lk, u4 = ha / hk, w1 = lb / lk, w2 = lb / hk, w3 = hb / lk, w4 = hb / hk;
+    const double umin = fmin(fmin(u1, u2), fmin(u3, u4)), umax = fmax(fmax(u1, u2), fmax(u3, u4));
+    const double wmin = fmin(fmin(w1, w2), fmin(w3, w4)), wmax = fmax(fmax(w1, w2), fmax(w3, w4));
+    g.u0 = umin; g.us = umax > umin ? HPR_GRID / (umax - umin) : 0.0;
+    g.w0 = wmin; g.ws = wmax > wmin ? HPR_GRID / (wmax - wmin) : 0.0;
+    return g;
+}
+__device__ __forceinline__ void grid_cell(const GridMap& g, const double x, const double y, const double z, int& iu, int& iw) {
+    const double pk = g.k == 0 ? x : (g.k == 1 ? y : z), pa = g.a == 0 ? x : (g.a == 1 ? y : z), pb = g.b == 0 ? x : (g.b == 1 ? y : z);
+    iu = min(HPR_GRID - 1, max(0, (int)((pa / pk - g.u0) * g.us)));
+    iw = min(HPR_GRID - 1, max(0, (int)((pb / pk - g.w0) * g.ws)));
+}
+__global__ void k_hpr_grid(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ bbox,
+                           unsigned long long* __restrict__ grid /*[V][G*G], zeroed: (f32 bits of |p'|^2, index + 1)*/) {
+    const int v = blockIdx.y;
+    const GridMap g = grid_map(bbox, v);
+    if (!g.ok) return;
+    const double* f = flipped + (size_t)v * 3 * N;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const double x = f[i], y = f[N + i], z = f[2 * (size_t)N + i];
+        int iu, iw;
+        grid_cell(g, x, y, z, iu, iw);
+        const float r2 = (float)(x * x + y * y + z * z);
+        atomicMax(&grid[(size_t)v * HPR_GRID * HPR_GRID + iu * HPR_GRID + iw], ((unsigned long long)__float_as_uint(r2) << 32) | (unsigned int)(i + 1));
+    }
+}
+// the shield test of every not-skipped point + the query list of level 1 (what the shield does not settle); skipped points: visible
+__global__ __launch_bounds__(1024) void k_hpr_shield(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ bbox,
+                                                     const unsigned long long* __restrict__ grid, const uint8_t* __restrict__ skip,
+                                                     int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis,
+                                                     int* __restrict__ counters) {
+    __shared__ int s_wcnt[16], s_base;
+    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const GridMap g = grid_map(bbox, v);
+    const double* f = flipped + (size_t)v * 3 * N;
+    const unsigned long long* gv = grid + (size_t)v * HPR_GRID * HPR_GRID;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < N;
+        const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
+        bool q = in && !sk;
+        if (q && g.ok) {
+            const d3 p = {f[i], f[N + i], f[2 * (size_t)N + i]};
+            int iu, iw;
+            grid_cell(g, p.x, p.y, p.z, iu, iw);
+            // four placements of the three cells around the query's (the triangle of ANY points of the three cells covers the cell)
+            const int pat[4][3][2] = {{{-2, -2}, {2, -2}, {0, 3}}, {{-2, 2}, {2, 2}, {0, -3}}, {{-2, -2}, {-2, 2}, {3, 0}}, {{2, -2}, {2, 2}, {-3, 0}}};
+#pragma unroll
+            for (int t = 0; t < 4 && q; ++t) {
+                int id[3];
+                bool have = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int x = iu + pat[t][c][0], y = iw + pat[t][c][1];
+                    id[c] = -1;
+                    if (x >= 0 && x < HPR_GRID && y >= 0 && y < HPR_GRID) id[c] = (int)(unsigned int)(gv[x * HPR_GRID + y] & 0xffffffffull) - 1;
+                    have = have && id[c] >= 0 && id[c] != i;
+                }
+                if (!have) continue;
+                const d3 a = d3{f[id[0]], f[N + id[0]], f[2 * (size_t)N + id[0]]} - p, b = d3{f[id[1]], f[N + id[1]], f[2 * (size_t)N + id[1]]} - p,
+                         c = d3{f[id[2]], f[N + id[2]], f[2 * (size_t)N + id[2]]} - p, d = neg(p);
+                const int s0 = -det_sign(b, c, d), s1 = det_sign(a, c, d), s2 = -det_sign(a, b, d), s3 = det_sign(a, b, c);
+                if (s0 != 0 && s0 == s1 && s1 == s2 && s2 == s3) q = false;           // certified strictly inside: hidden
+            }
+        }
+        const unsigned long long bal = __ballot(q);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int mine = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = s_wcnt[w]; mine += w < wave ? c : 0; tot += c; }
+        if (threadIdx.x == 0) s_base = atomicAdd(&count[v], tot);
+        __syncthreads();
+        const int base = s_base + mine;
+        if (q) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        else if (sk) vis[(size_t)v * N + i] = 1;
+        __syncthreads();
+    }
+    (void)counters;
+}
 
 // what a query lane does with the support point of its round: myv = the largest support value over the real points (real_pt: one
 // was found; sp / sp_idx = that point and its cloud index).  The support of S_i is that point or the eye (value 0).
@@ -300,13 +408,18 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
     const int KS = min(kcount[v], HPR_KC), KT = (KS + 31) >> 5;       // (the set is padded with the eye (0, 0, 0) to whole tiles)
     // the view's coarse set lives in LDS for the block's lifetime (f32 records for the scans, f64 records + cloud indices for the
     // GJK step): every round ends with two dependent look-ups into it, which from L2 were a third of the round's latency
-    __shared__ float4 s_csf[HPR_KC];
+    // (f32 coordinates as three arrays with 33 slots per 32-point tile: as [x y z -] records at a 512-byte tile stride, the lanes
+    // re-evaluating rows of DIFFERENT tiles all hit the same four banks -- a 64-way conflict on each of the 32 reads of a round,
+    // 60 % of this kernel)
+    __shared__ float s_cx[HPR_KC + HPR_KC / 32], s_cy[HPR_KC + HPR_KC / 32], s_cz[HPR_KC + HPR_KC / 32];
+#define CSLOT(j) ((j) + ((j) >> 5))
     __shared__ double s_csd[HPR_KC][3];
     __shared__ int s_cidx[HPR_KC];
     {
         const int KL = min(HPR_KC, ((KT + 2) & ~1) * 32);          // (whole tiles, an even number of them, one more for the prefetch)
         for (int i = threadIdx.x; i < KL; i += 256) {
-            s_csf[i] = csf[(size_t)v * HPR_KC + i];
+            const float4 rec = csf[(size_t)v * HPR_KC + i];
+            s_cx[CSLOT(i)] = rec.x; s_cy[CSLOT(i)] = rec.y; s_cz[CSLOT(i)] = rec.z;
             const double* cd = csd + ((size_t)v * HPR_KC + i) * 4;
             s_csd[i][0] = cd[0]; s_csd[i][1] = cd[1]; s_csd[i][2] = cd[2];
             s_cidx[i] = cidx[(size_t)v * HPR_KC + i];
@@ -314,7 +427,6 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         __syncthreads();
     }
     if ((COLS == 2 ? (qi & ~63) : (qi & ~31)) >= nq) return;
-    const float4* c = s_csf;
     const double* qf = flipped + (size_t)v * 3 * N;
     const double rb = __longlong_as_double((long long)maxabs[v]) * (8.0 * 1.1102230246251565e-16);
     const bool owner = qi < nq && (COLS == 2 || !hi);
@@ -334,6 +446,9 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
 #ifdef PD_HPR_STATS
         ++wave_rounds; if (g.state == 0) ++my_rounds;
 #endif
+#ifdef PD_HPR_STATS
+        const unsigned long long c0 = lab_clock();
+#endif
         // directions only matter up to scale: bring them into f32 range by their own magnitude (a power of two)
         const double mag = fmax(fabs(g.dir.x), fmax(fabs(g.dir.y), fabs(g.dir.z)));
         const double sc = mag > 0.0 ? __longlong_as_double((long long)((0x7feull - ((unsigned long long)__double_as_longlong(mag) >> 52)) << 52)) : 1.0;
@@ -342,13 +457,16 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         const float x0 = __shfl(dx, l31), y0 = __shfl(dy, l31), z0 = __shfl(dz, l31);
         const float x1 = COLS == 2 ? __shfl(dx, 32 + l31) : 0.0f, y1 = COLS == 2 ? __shfl(dy, 32 + l31) : 0.0f, z1 = COLS == 2 ? __shfl(dz, 32 + l31) : 0.0f;
         const float b1_0 = hi ? y0 : x0, b2_0 = hi ? 0.0f : z0, b1_1 = hi ? y1 : x1, b2_1 = hi ? 0.0f : z1;
+#ifdef PD_HPR_STATS
+        const unsigned long long c1 = lab_clock();
+#endif
         float best0 = -3.0e38f, best1 = -3.0e38f;
         int code0 = -1, code1 = -1;                               // tile * 16 + accumulator entry
         // two tiles in flight: the matrix cores work on one while the VALU reduces the other (KT2 even: the pad tiles are the eye)
         const f32x16 zero = {0};
 #define HPR_TILE_MFMA(ACC0, ACC1, PT)                                                                              \
         {                                                                                                          \
-            const float a1 = hi ? (PT).y : (PT).x, a2 = hi ? 0.0f : (PT).z;      /* lane l: A[point l & 31][k = l >> 5] */ \
+            const float a1 = (PT).x, a2 = (PT).y;            /* lane l: A[point l & 31][k = l >> 5]: x | y, then z | 0 */ \
             ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0);                                  \
             if (COLS == 2) ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);                   \
             ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, ACC0, 0, 0, 0);                                  \
@@ -362,18 +480,24 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         }
         const int KT2 = (KT + 1) & ~1, TMAX = HPR_KC / 32 - 1;
         f32x16 A0, A1 = zero, B0, B1 = zero;
-        float4 pa = c[l31], pb = c[32 + l31];
+        const float* s_cxy = hi ? s_cy : s_cx;                       // (the half-wave's first-MFMA operand array)
+#define HPR_TILE_LOAD(J) make_float2(s_cxy[CSLOT(J)], hi ? 0.0f : s_cz[CSLOT(J)])
+        float2 pa = HPR_TILE_LOAD(l31), pb = HPR_TILE_LOAD(32 + l31);
         HPR_TILE_MFMA(A0, A1, pa)
         for (int t = 0; t < KT2; t += 2) {
-            pa = c[min(t + 2, TMAX) * 32 + l31];
+            pa = HPR_TILE_LOAD(min(t + 2, TMAX) * 32 + l31);
             HPR_TILE_MFMA(B0, B1, pb)
             HPR_TILE_REDUCE(A0, A1, t)
-            pb = c[min(t + 3, TMAX) * 32 + l31];
+            pb = HPR_TILE_LOAD(min(t + 3, TMAX) * 32 + l31);
             HPR_TILE_MFMA(A0, A1, pa)
             HPR_TILE_REDUCE(B0, B1, t + 1)
         }
 #undef HPR_TILE_MFMA
 #undef HPR_TILE_REDUCE
+#undef HPR_TILE_LOAD
+#ifdef PD_HPR_STATS
+        const unsigned long long c2 = lab_clock() + (best0 == 1.2345f ? 1 : 0) + (best1 == 1.2345f ? 1 : 0);
+#endif
         // accumulator entry i of lane l is point row 8 (i / 4) + 4 (l >> 5) + (i % 4) of the tile: the lane re-evaluates its 16 rows of
         // the tile its maximum came from (the same fmaf chain as the matrix core: bitwise the same values), for both query columns
         int j0 = -1, j1 = -1;
@@ -383,12 +507,12 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = 8 * (i / 4) + (i % 4);
-                const float4 u0 = c[base0 + row];
-                const float w0 = fmaf(u0.z, z0, fmaf(u0.y, y0, u0.x * x0));
+                const int sl0 = CSLOT(base0 + row);
+                const float w0 = fmaf(s_cz[sl0], z0, fmaf(s_cy[sl0], y0, s_cx[sl0] * x0));
                 if (w0 > r0) { r0 = w0; j0 = base0 + row; }
                 if (COLS == 2) {
-                    const float4 u1 = c[base1 + row];
-                    const float w1 = fmaf(u1.z, z1, fmaf(u1.y, y1, u1.x * x1));
+                    const int sl1 = CSLOT(base1 + row);
+                    const float w1 = fmaf(s_cz[sl1], z1, fmaf(s_cy[sl1], y1, s_cx[sl1] * x1));
                     if (w1 > r1) { r1 = w1; j1 = base1 + row; }
                 }
             }
@@ -404,6 +528,9 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         }
         int bi = (COLS == 2 && hi) ? j1 : j0;                                    // query lane l is column l & 31 of query tile l >> 5
         if (bi >= KS) bi = -1;                                    // a pad entry: the eye
+#ifdef PD_HPR_STATS
+        const unsigned long long c3 = lab_clock() + (bi == 123456789 ? 1 : 0);
+#endif
         if (g.state == 0) {
             d3 sp = {0, 0, 0};
             int si = -1;
@@ -416,6 +543,10 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
             if (si == q) g.state = 3;                             // the query is itself a member of the coarse set: level 2 decides
             else gjk_round(g, pi, myv, bi >= 0, sp, si, rb);
         }
+#ifdef PD_HPR_STATS
+        { const unsigned long long c4 = lab_clock() + (g.state == 77 ? 1 : 0);
+          if ((threadIdx.x & 63) == 0) { atomicAdd(&g_hpr_c[0], c1 - c0); atomicAdd(&g_hpr_c[1], c2 - c1); atomicAdd(&g_hpr_c[2], c3 - c2); atomicAdd(&g_hpr_c[3], c4 - c3); atomicAdd(&g_hpr_c[4], 1ull); } }
+#endif
     }
 #ifdef PD_HPR_STATS
     if ((threadIdx.x & 63) == 0) { atomicAdd(&g_hpr_stats[0][0], 1ull); atomicAdd(&g_hpr_stats[0][1], (unsigned long long)wave_rounds); }
@@ -1303,7 +1434,8 @@ static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int
 #define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
     return HPR_HEAD_BYTES + 3 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
-           a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V) + a256((size_t)HPR_KC * 4 * sizeof(double));
+           a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V) + a256((size_t)HPR_KC * 4 * sizeof(double)) +
+           a256((size_t)V * HPR_GRID * HPR_GRID * sizeof(unsigned long long));
 }
 
 extern "C" int pdhip_hidden_point_removal(const float* points, int N, const double* eyes_dev, int V, double radius,
@@ -1327,6 +1459,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_KC * sizeof(unsigned long long));
     int* pos_of = reinterpret_cast<int*>(p); p += lists_bytes(V, N);   // (the extremes' claim flags until the scatter fills it)
     int* mdir = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
+    unsigned long long* sgrid = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_GRID * HPR_GRID * sizeof(unsigned long long));
     const size_t zero_bytes = (size_t)(p - reinterpret_cast<char*>(ws));
     double* flipped = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     double* ss = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);          // level-2 support set, cell-sorted
@@ -1344,12 +1477,14 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     double* fdir = reinterpret_cast<double*>(p); p += a256((size_t)HPR_KC * 4 * sizeof(double));
     double* qdir = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     dim3 gf(min(cdiv(N, 256), 256), V);
+    const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
     k_hpr_flip<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>
-       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility);      // (+ marks the skipped points visible; `list` = the queries)
+       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility, two_level ? 0 : 1);      // (one level: + marks the skipped points visible; `list` = the queries)
     constexpr int KC = HPR_KC;
-    const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     if (two_level) {
+        k_hpr_grid<<<gf, 256, 0, s>>>(flipped, N, bbox, sgrid);
+        k_hpr_shield<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, bbox, sgrid, skip, count, list, visibility, counters);
         k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, ekeys);
         k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir, fdir);
         k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs, qdir);
