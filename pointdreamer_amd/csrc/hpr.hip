@@ -390,6 +390,7 @@ __device__ __forceinline__ void gjk_round(Gjk<double>& g, const d3 pi, const dou
 // no cross-lane work except joining the two half-waves at the end.  The VALU is left with the compare / select (3 per pair
 // instead of 7 with the products) and the GJK step; the chosen support point is then re-evaluated in f64.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float tile_max(const f32x16 a) {          // (v_max3_f32: eight instructions)
     const float m0 = fmaxf(fmaxf(a[0], a[1]), a[2]), m1 = fmaxf(fmaxf(a[3], a[4]), a[5]), m2 = fmaxf(fmaxf(a[6], a[7]), a[8]),
                 m3 = fmaxf(fmaxf(a[9], a[10]), a[11]), m4 = fmaxf(fmaxf(a[12], a[13]), a[14]);
@@ -415,6 +416,10 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
     // 60 % of this kernel)
     __shared__ float s_cx[HPR_KC + HPR_KC / 32], s_cy[HPR_KC + HPR_KC / 32], s_cz[HPR_KC + HPR_KC / 32];
 #define CSLOT(j) ((j) + ((j) >> 5))
+    // the scan's matrix operands: every coordinate split into two f16 (hi + lo: 22 bits), the nine products x_h d_h, x_h d_l, x_l d_h
+    // (x, y, z) laid along K = 16 of ONE v_mfma_f32_32x32x16_f16 (32 cycles) instead of two f32 MFMAs of 64 cycles each:
+    //   A (lanes 0-31: k 0-7 | lanes 32-63: k 8-15) = [xh yh zh xh yh zh xl yl | zl 0 ...],  B = [dxh dyh dzh dxl dyl dzl dxh dyh | dzh 0 ...]
+    __shared__ f16x8 s_alo[HPR_KC], s_ahi[HPR_KC];
     __shared__ double s_csd[HPR_KC][3];
     __shared__ int s_cidx[HPR_KC];
     {
@@ -422,6 +427,10 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         for (int i = threadIdx.x; i < KL; i += 256) {
             const float4 rec = csf[(size_t)v * HPR_KC + i];
             s_cx[CSLOT(i)] = rec.x; s_cy[CSLOT(i)] = rec.y; s_cz[CSLOT(i)] = rec.z;
+            const _Float16 xh = (_Float16)rec.x, yh = (_Float16)rec.y, zh = (_Float16)rec.z;
+            const _Float16 xl = (_Float16)(rec.x - (float)xh), yl = (_Float16)(rec.y - (float)yh), zl = (_Float16)(rec.z - (float)zh);
+            s_alo[i] = f16x8{xh, yh, zh, xh, yh, zh, xl, yl};
+            s_ahi[i] = f16x8{zl, 0, 0, 0, 0, 0, 0, 0};
             const double* cd = csd + ((size_t)v * HPR_KC + i) * 4;
             s_csd[i][0] = cd[0]; s_csd[i][1] = cd[1]; s_csd[i][2] = cd[2];
             s_cidx[i] = cidx[(size_t)v * HPR_KC + i];
@@ -458,7 +467,15 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         // B operands (lane l: B[k = l >> 5][query column l & 31]) for the wave's two columns of 32 queries
         const float x0 = __shfl(dx, l31), y0 = __shfl(dy, l31), z0 = __shfl(dz, l31);
         const float x1 = COLS == 2 ? __shfl(dx, 32 + l31) : 0.0f, y1 = COLS == 2 ? __shfl(dy, 32 + l31) : 0.0f, z1 = COLS == 2 ? __shfl(dz, 32 + l31) : 0.0f;
-        const float b1_0 = hi ? y0 : x0, b2_0 = hi ? 0.0f : z0, b1_1 = hi ? y1 : x1, b2_1 = hi ? 0.0f : z1;
+        f16x8 bq0, bq1;                                            // (directions are scaled to [1, 2): well inside the f16 range)
+        {
+            const _Float16 xh = (_Float16)x0, yh = (_Float16)y0, zh = (_Float16)z0;
+            const _Float16 xl = (_Float16)(x0 - (float)xh), yl = (_Float16)(y0 - (float)yh), zl = (_Float16)(z0 - (float)zh);
+            bq0 = hi ? f16x8{zh, 0, 0, 0, 0, 0, 0, 0} : f16x8{xh, yh, zh, xl, yl, zl, xh, yh};
+            const _Float16 uh = (_Float16)x1, vh = (_Float16)y1, wh = (_Float16)z1;
+            const _Float16 ul = (_Float16)(x1 - (float)uh), vl = (_Float16)(y1 - (float)vh), wl = (_Float16)(z1 - (float)wh);
+            bq1 = hi ? f16x8{wh, 0, 0, 0, 0, 0, 0, 0} : f16x8{uh, vh, wh, ul, vl, wl, uh, vh};
+        }
 #ifdef PD_HPR_STATS
         const unsigned long long c1 = lab_clock();
 #endif
@@ -468,11 +485,8 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         const f32x16 zero = {0};
 #define HPR_TILE_MFMA(ACC0, ACC1, PT)                                                                              \
         {                                                                                                          \
-            const float a1 = (PT).x, a2 = (PT).y;            /* lane l: A[point l & 31][k = l >> 5]: x | y, then z | 0 */ \
-            ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0);                                  \
-            if (COLS == 2) ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);                   \
-            ACC0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, ACC0, 0, 0, 0);                                  \
-            if (COLS == 2) ACC1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, ACC1, 0, 0, 0);                   \
+            ACC0 = __builtin_amdgcn_mfma_f32_32x32x16_f16((PT), bq0, zero, 0, 0, 0);                               \
+            if (COLS == 2) ACC1 = __builtin_amdgcn_mfma_f32_32x32x16_f16((PT), bq1, zero, 0, 0, 0);                \
         }
 #define HPR_TILE_REDUCE(ACC0, ACC1, T)                                                                             \
         {   /* per tile only WHICH tile holds the lane's maximum; the position inside it is found once, after the scan */ \
@@ -482,9 +496,9 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         }
         const int KT2 = (KT + 1) & ~1, TMAX = HPR_KC / 32 - 1;
         f32x16 A0, A1 = zero, B0, B1 = zero;
-        const float* s_cxy = hi ? s_cy : s_cx;                       // (the half-wave's first-MFMA operand array)
-#define HPR_TILE_LOAD(J) make_float2(s_cxy[CSLOT(J)], hi ? 0.0f : s_cz[CSLOT(J)])
-        float2 pa = HPR_TILE_LOAD(l31), pb = HPR_TILE_LOAD(32 + l31);
+        const f16x8* s_aop = hi ? s_ahi : s_alo;                      // (lane l: A[point l & 31][k = 8 (l >> 5) ..])
+#define HPR_TILE_LOAD(J) s_aop[J]
+        f16x8 pa = HPR_TILE_LOAD(l31), pb = HPR_TILE_LOAD(32 + l31);
         HPR_TILE_MFMA(A0, A1, pa)
         for (int t = 0; t < KT2; t += 2) {
             pa = HPR_TILE_LOAD(min(t + 2, TMAX) * 32 + l31);
@@ -501,7 +515,7 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
         const unsigned long long c2 = lab_clock() + (best0 == 1.2345f ? 1 : 0) + (best1 == 1.2345f ? 1 : 0);
 #endif
         // accumulator entry i of lane l is point row 8 (i / 4) + 4 (l >> 5) + (i % 4) of the tile: the lane re-evaluates its 16 rows of
-        // the tile its maximum came from (the same fmaf chain as the matrix core: bitwise the same values), for both query columns
+        // the tile its maximum came from (in f32: close to the matrix core's split-f16 values, and this level only proposes), for both columns
         int j0 = -1, j1 = -1;
         {
             float r0 = -3.0e38f, r1 = -3.0e38f;
