@@ -290,8 +290,16 @@ __device__ __forceinline__ void grid_cell(const GridMap& g, const double x, cons
     iw = min(HPR_GRID - 1, max(0, (int)((pb / pk - g.w0) * g.ws)));
 }
 __global__ void k_hpr_grid(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ bbox,
-                           unsigned long long* __restrict__ grid /*[V][G*G], zeroed: (f32 bits of |p'|^2, index + 1)*/) {
+                           unsigned long long* __restrict__ grid /*[V][G*G], zeroed: (f32 bits of |p'|^2, index + 1)*/,
+                           double* __restrict__ fdir /*[KC][4]: the Fibonacci directions of level 1, computed here on the side*/) {
     const int v = blockIdx.y;
+    if (v == 0) {
+        const int k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k < HPR_KC) {
+            const double zk = 1.0 - (2.0 * k + 1.0) / HPR_KC, rk = sqrt(fmax(0.0, 1.0 - zk * zk)), pk = k * 2.399963229728653;
+            fdir[4 * k] = rk * cos(pk); fdir[4 * k + 1] = rk * sin(pk); fdir[4 * k + 2] = zk; fdir[4 * k + 3] = 0.0;
+        }
+    }
     const GridMap g = grid_map(bbox, v);
     if (!g.ok) return;
     const double* f = flipped + (size_t)v * 3 * N;
@@ -1342,9 +1350,10 @@ __global__ __launch_bounds__(256) void k_hpr_boxes(const double* __restrict__ ss
 // other point), so this is the same approximate f32 GEMM + column maximum as the level-1 scan: A = 32 points, B = 64 of the
 // directions, a wave keeps the best tile per lane and locates the row afterwards.  The cloud is cut into HPR_EXT_POINTS-point
 // slabs (one wave per slab and 64 directions); the slabs meet in an atomicMax on (value, index) keys.
-#define HPR_EXT_POINTS 2048
+#define HPR_EXT_POINTS 2048      // (512-point slabs: four times the waves, but also four times the atomics on the same keys: 94 us against 42)
 __device__ __forceinline__ unsigned int f32_key(float x) { const unsigned int b = __float_as_uint(x); return (b >> 31) ? ~b : (b | 0x80000000u); }
-__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, unsigned long long* __restrict__ keys /*[V][KC], zeroed*/) {
+__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, const double* __restrict__ fdir /*[KC][4]*/,
+                                                      unsigned long long* __restrict__ keys /*[V][KC], zeroed*/) {
     const int v = blockIdx.z, lane = threadIdx.x & 63, l31 = lane & 31;
     const bool hi = lane >= 32;
     const int grp = blockIdx.y * 4 + (threadIdx.x >> 6);                  // 64 directions
@@ -1353,39 +1362,49 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
     const double* fx = flipped + (size_t)v * 3 * N;
     const double* fy = fx + N;
     const double* fz = fy + N;
-    float x0, y0, z0, x1, y1, z1;                                          // the lane's two directions (query columns l31 and 32 + l31)
+    const int k0 = grp * 64 + l31, k1 = k0 + 32;                           // the lane's two directions (query columns l31 and 32 + l31)
+    const float x0 = (float)fdir[4 * k0], y0 = (float)fdir[4 * k0 + 1], z0 = (float)fdir[4 * k0 + 2];
+    const float x1 = (float)fdir[4 * k1], y1 = (float)fdir[4 * k1 + 1], z1 = (float)fdir[4 * k1 + 2];
+    // split-f16 operands as in k_hpr_coarse: A (lanes 0-31 | 32-63) = [xh yh zh xh yh zh xl yl | zl 0 ...], B = [dxh dyh dzh dxl dyl dzl dxh dyh | dzh 0 ...]
+    f16x8 bq0, bq1;
     {
-        const int k0 = grp * 64 + l31, k1 = k0 + 32;
-        const double za = 1.0 - (2.0 * k0 + 1.0) / HPR_KC, ra = sqrt(fmax(0.0, 1.0 - za * za)), pa = k0 * 2.399963229728653;
-        const double zb = 1.0 - (2.0 * k1 + 1.0) / HPR_KC, rb = sqrt(fmax(0.0, 1.0 - zb * zb)), pb = k1 * 2.399963229728653;
-        x0 = (float)(ra * cos(pa)); y0 = (float)(ra * sin(pa)); z0 = (float)za;
-        x1 = (float)(rb * cos(pb)); y1 = (float)(rb * sin(pb)); z1 = (float)zb;
+        const _Float16 xh = (_Float16)x0, yh = (_Float16)y0, zh = (_Float16)z0;
+        const _Float16 xl = (_Float16)(x0 - (float)xh), yl = (_Float16)(y0 - (float)yh), zl = (_Float16)(z0 - (float)zh);
+        bq0 = hi ? f16x8{zh, 0, 0, 0, 0, 0, 0, 0} : f16x8{xh, yh, zh, xl, yl, zl, xh, yh};
+        const _Float16 uh = (_Float16)x1, vh = (_Float16)y1, wh = (_Float16)z1;
+        const _Float16 ul = (_Float16)(x1 - (float)uh), vl = (_Float16)(y1 - (float)vh), wl = (_Float16)(z1 - (float)wh);
+        bq1 = hi ? f16x8{wh, 0, 0, 0, 0, 0, 0, 0} : f16x8{uh, vh, wh, ul, vl, wl, uh, vh};
     }
-    const float b1_0 = hi ? y0 : x0, b2_0 = hi ? 0.0f : z0, b1_1 = hi ? y1 : x1, b2_1 = hi ? 0.0f : z1;
     const f32x16 zero = {0};
     float best0 = -3.0e38f, best1 = -3.0e38f;
     int t0 = 0, t1 = 0;
-    const double* fa = hi ? fy : fx;                                       // lane l: A[point l & 31][k = l >> 5]: x | y, then z | 0
-    // operands are requested four trips (256 points) ahead: a trip is 0.2 us of matrix work against an L2 round trip of 1-2 us
-    double ra[4], rz[4], rc[4], rw[4];
+    // operands are requested two trips (128 points) ahead: a trip is a fraction of a microsecond of work against an L2 round trip of 1-2 us
+    double rx[2][2], ry[2][2], rz[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int ja = min(p_lo + 64 * u + l31, N - 1), jb = min(p_lo + 64 * u + 32 + l31, N - 1);      // (a repeated point cannot change a maximum)
-        ra[u] = fa[ja]; rz[u] = fz[ja]; rc[u] = fa[jb]; rw[u] = fz[jb];
-    }
-    for (int jo = p_lo; jo < p_hi; jo += 256) {
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                                     // two tiles per trip
+        for (int h = 0; h < 2; ++h) {
+            const int j = min(p_lo + 64 * u + 32 * h + l31, N - 1);        // (a repeated point cannot change a maximum)
+            rz[u][h] = fz[j];
+            if (!hi) { rx[u][h] = fx[j]; ry[u][h] = fy[j]; } else { rx[u][h] = 0.0; ry[u][h] = 0.0; }
+        }
+    for (int jo = p_lo; jo < p_hi; jo += 128) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                                     // two tiles per trip
             const int j0 = jo + 64 * u;
-            const float a1 = (float)ra[u], a2 = hi ? 0.0f : (float)rz[u], c1 = (float)rc[u], c2 = hi ? 0.0f : (float)rw[u];
-            {
-                const int ja = min(j0 + 256 + l31, N - 1), jb = min(j0 + 288 + l31, N - 1);
-                ra[u] = fa[ja]; rz[u] = fz[ja]; rc[u] = fa[jb]; rw[u] = fz[jb];
+            f16x8 ap[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float x = (float)rx[u][h], y = (float)ry[u][h], z = (float)rz[u][h];
+                const _Float16 xh = (_Float16)x, yh = (_Float16)y, zh = (_Float16)z;
+                const _Float16 xl = (_Float16)(x - (float)xh), yl = (_Float16)(y - (float)yh), zl = (_Float16)(z - (float)zh);
+                ap[h] = hi ? f16x8{zl, 0, 0, 0, 0, 0, 0, 0} : f16x8{xh, yh, zh, xh, yh, zh, xl, yl};
+                const int j = min(j0 + 128 + 32 * h + l31, N - 1);
+                rz[u][h] = fz[j];
+                if (!hi) { rx[u][h] = fx[j]; ry[u][h] = fy[j]; }
             }
-            f32x16 A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_0, zero, 0, 0, 0), A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1_1, zero, 0, 0, 0);
-            f32x16 B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_0, zero, 0, 0, 0), B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1_1, zero, 0, 0, 0);
-            A0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2_1, A1, 0, 0, 0);
-            B0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_0, B0, 0, 0, 0); B1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2_1, B1, 0, 0, 0);
+            const f32x16 A0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[0], bq0, zero, 0, 0, 0), A1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[0], bq1, zero, 0, 0, 0);
+            const f32x16 B0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[1], bq0, zero, 0, 0, 0), B1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[1], bq1, zero, 0, 0, 0);
             const float ma0 = tile_max(A0), ma1 = tile_max(A1), mb0 = tile_max(B0), mb1 = tile_max(B1);
             if (ma0 > best0) { best0 = ma0; t0 = j0; }
             if (ma1 > best1) { best1 = ma1; t1 = j0; }
@@ -1393,7 +1412,7 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
             if (mb1 > best1) { best1 = mb1; t1 = j0 + 32; }
         }
     }
-    // the row inside the best tile: the lane's 16 rows, the same fmaf chain (bitwise the matrix core's values)
+    // the row inside the best tile: the lane's 16 rows in f32 (close to the matrix core's split-f16 values; the set only has to be good)
     int i0 = -1, i1 = -1;
     {
         float r0 = -3.0e38f, r1 = -3.0e38f;
@@ -1407,10 +1426,18 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
             if (w1 > r1) { r1 = w1; i1 = jb; }
         }
     }
-    // both half-waves hold a candidate for the same two directions: let the atomics join them (ties: the smaller index)
+    // both half-waves hold a candidate for the same two directions: join them, then one atomic per direction joins the slabs (same-key
+    // atomics are what this kernel waits for at the end; ties: the smaller index)
+    {
+        const float ob0 = __shfl_xor(best0, 32), ob1 = __shfl_xor(best1, 32);
+        const int oi0 = __shfl_xor(i0, 32), oi1 = __shfl_xor(i1, 32);
+        if (ob0 > best0 || (ob0 == best0 && oi0 >= 0 && (i0 < 0 || oi0 < i0))) { best0 = ob0; i0 = oi0; }
+        if (ob1 > best1 || (ob1 == best1 && oi1 >= 0 && (i1 < 0 || oi1 < i1))) { best1 = ob1; i1 = oi1; }
+    }
     unsigned long long* kv = keys + (size_t)v * HPR_KC + grp * 64;
-    if (i0 >= 0) atomicMax(&kv[l31], ((unsigned long long)f32_key(best0) << 32) | (unsigned int)(0x7fffffff - i0));
-    if (i1 >= 0) atomicMax(&kv[32 + l31], ((unsigned long long)f32_key(best1) << 32) | (unsigned int)(0x7fffffff - i1));
+    const float bq = hi ? best1 : best0;
+    const int iq = hi ? i1 : i0;
+    if (iq >= 0) atomicMax(&kv[lane], ((unsigned long long)f32_key(bq) << 32) | (unsigned int)(0x7fffffff - iq));
 }
 // The hull is that of the cloud AND the eye (the origin of the flipped space): in a direction where every point has a negative
 // projection the eye is the extreme element and no point is taken (the GJK step supplies the eye itself, support value 0).
@@ -1418,14 +1445,9 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
 __global__ void k_hpr_extremes_fin(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ keys,
                                    float4* __restrict__ csf, double* __restrict__ csd /*[V][KC][4]: the same points in f64*/,
                                    int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/,
-                                   int* __restrict__ mdir /*[V][N], zeroed: 1 + the direction that found the point*/,
-                                   double* __restrict__ fdir /*[KC][4]: the directions in f64*/) {
+                                   int* __restrict__ mdir /*[V][N], zeroed: 1 + the direction that found the point*/) {
     const int v = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= HPR_KC) return;
-    if (v == 0) {
-        const double zk = 1.0 - (2.0 * k + 1.0) / HPR_KC, rk = sqrt(fmax(0.0, 1.0 - zk * zk)), pk = k * 2.399963229728653;
-        fdir[4 * k] = rk * cos(pk); fdir[4 * k + 1] = rk * sin(pk); fdir[4 * k + 2] = zk; fdir[4 * k + 3] = 0.0;
-    }
     const unsigned long long key = keys[(size_t)v * HPR_KC + k];
     const unsigned int vb = (unsigned int)(key >> 32);
     const int id = 0x7fffffff - (int)(unsigned int)(key & 0xffffffffu);
@@ -1499,10 +1521,10 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
        (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility, two_level ? 0 : 1);      // (one level: + marks the skipped points visible; `list` = the queries)
     constexpr int KC = HPR_KC;
     if (two_level) {
-        k_hpr_grid<<<gf, 256, 0, s>>>(flipped, N, bbox, sgrid);
+        k_hpr_grid<<<gf, 256, 0, s>>>(flipped, N, bbox, sgrid, fdir);
         k_hpr_shield<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, bbox, sgrid, skip, count, list, visibility, counters);
-        k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, ekeys);
-        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir, fdir);
+        k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, fdir, ekeys);
+        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir);
         k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs, qdir);
     }
     k_hpr_bin<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
