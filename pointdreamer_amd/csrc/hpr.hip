@@ -8,11 +8,14 @@
 // iteration.  Every verdict is CERTIFIED on the f64 coordinates: "visible" by a separating direction d with
 // d.p'_i - max(max_j d.p'_j, 0) > rounding bound, "hidden" by a tetrahedron of cloud points (or the eye) whose four
 // orientation determinants around p'_i pass Shewchuk's static filter.  How a candidate direction / tetrahedron is FOUND is free,
-// which is what the three levels exploit:
-//   level 1  k_hpr_extremes + k_hpr_coarse: all queries against a coarse set of <= 1024 cloud points (the extreme points in
+// which is what the levels exploit:
+//   level 0  k_hpr_grid + k_hpr_shield: a fixed tetrahedron (eye + the outermost points of three cells of a direction grid around
+//            the query's own cell) per query; certified like everything else.  90 % of the hidden points of a cloud end here.
+//   level 1  k_hpr_extremes + k_hpr_coarse: the rest against a coarse set of <= 1024 cloud points (the extreme points in
 //            Fibonacci directions).  conv(subset) is inside conv(cloud): "enclosed" there is final.  Lane = query; the support
-//            scans are an f32 GEMM on the matrix cores (points x directions, v_mfma_f32_32x32x2_f32) followed by a column
-//            maximum -- approximate, but the verdict is certified on the true coordinates.  ~2/3 of a cloud ends here.
+//            scans are a GEMM on the matrix cores (points x directions, coordinates split into two f16 so that one
+//            v_mfma_f32_32x32x16_f16 carries the nine hi/lo products) followed by a column maximum -- approximate, but the
+//            verdict is certified on the true coordinates.
 //   level 2  k_hpr_fine_dist: what level 1 could not enclose, against the points outside the coarse hull (a point strictly
 //            inside it is never a support point).  That set is Morton-sorted and cut into 64-point chunks with oriented boxes
 //            (the flipped cloud is a thin shell around the eye); one wavefront per query runs the distance form of GJK on a
@@ -25,7 +28,7 @@
 // The result is therefore the vertex set of the exact hull of the f64 flipped points; qhull (open3d, scipy) differs from it only
 // for points within its own merge tolerance (~1e-13 * radius) of a facet.  open3d itself is absent (PARITY UNPINNED); the oracle
 // drives the same qhull through scipy.  8 views x 30 k points behind the depth-test skip mask: 2.66 ms (round 2's first form:
-// wave-cooperative f64 scans) -> 0.56 ms; all points queried: 17 -> 1.5 ms.
+// wave-cooperative f64 scans) -> 0.38 ms; all points queried: 17 -> 1.3 ms.
 // The order of the sorted support set inside a Morton cell comes from atomics; the scans break ties by cloud index and every
 // verdict is certified, so the visibility does not depend on it (the fallback counters may differ by a query between runs).
 #include "common.h"
