@@ -807,6 +807,9 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
 #ifdef PD_HPR_STATS
         ++my_rounds;
 #endif
+#ifdef PD_HPR_STATS
+        const unsigned long long f0 = lab_clock();
+#endif
         const double dx = dir.x, dy = dir.y, dz = dir.z;
         double best = -1.0e300, bx = 0.0, by = 0.0, bz = 0.0;
         int bidx = 0x7fffffff;
@@ -829,6 +832,9 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
         const double vv = dot(vclose, vclose);
         // is the working set's answer enough?  Not if it does not pass the origin (only the whole set can certify "visible"), nor
         // if it is already a vertex of the simplex or brings the simplex no closer (only the whole set can say "no progress")
+#ifdef PD_HPR_STATS
+        const unsigned long long f1 = lab_clock() + (have ? 0 : 0);
+#endif
         bool weak = true;
         if (have && myv > 0.0 && di - myv <= 0.0) {
             weak = (n >= 1 && si == I0) || (n >= 2 && si == I1) || (n >= 3 && si == I2);
@@ -856,6 +862,9 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
                 n_extra = min(n_extra + 1, 64);
             }
         }
+#ifdef PD_HPR_STATS
+        const unsigned long long f2 = lab_clock() + (have ? 0 : 0);
+#endif
         // the support point of S_i in this direction is now exact: that point, or the eye (value 0)
         const bool real = have && myv > 0.0;
         const double gap = di - (real ? myv : 0.0);
@@ -875,6 +884,10 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
         }
         if (zero3(vclose)) { state = 3; break; }
         dir = neg(vclose);
+#ifdef PD_HPR_STATS
+        { const unsigned long long f3 = lab_clock() + (n == 77 ? 1 : 0);
+          if (lane == 0) { atomicAdd(&g_hpr_c[5], f1 - f0); atomicAdd(&g_hpr_c[6], f2 - f1); atomicAdd(&g_hpr_c[7], f3 - f2); } }
+#endif
     }
 #ifdef PD_HPR_STATS
     if (lane == 0) { const unsigned long long dt = wall_clock64() - t_begin + (state == 77 ? 1 : 0);

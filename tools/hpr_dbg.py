@@ -35,6 +35,8 @@ try:
     fn(buf, 1); got2 = hpr.hidden_point_removal(P, eyes2, 100, already_valid=vis0); torch.cuda.synchronize(); fn(buf, 1)
     r = max(buf[44], 1)
     print(f'level 1, cycles per wave round (s_memtime): B operands {buf[40] / r:.0f}, scan {buf[41] / r:.0f}, re-evaluation + join {buf[42] / r:.0f}, gather + step {buf[43] / r:.0f}; wave rounds {buf[44]}')
+    fr = max(buf[19], 1)
+    print(f'level 2, cycles per query round (rounds that reach the solve): working-set scan {buf[45] / fr:.0f}, weak test + global scan {buf[46] / fr:.0f}, verdict + solve {buf[47] / fr:.0f}')
     nm = max(buf[18] - buf[35], 1)
     print(f'level 2 per-query wall time (100 MHz ticks -> us): mean {buf[32] / max(buf[18], 1) / 100:.1f}, max {buf[33] / 100:.1f}; members {buf[35]}: mean {buf[34] / max(buf[35], 1) / 100:.1f}; others {nm}: mean {(buf[32] - buf[34]) / nm / 100:.1f}')
     print('level 2: max scans per query', buf[36], '; queries with > 3 scans', buf[37], '; max candidate chunks of a query', buf[38], '; queries above 20000 ticks', buf[39])
