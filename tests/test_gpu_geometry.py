@@ -372,6 +372,23 @@ def test_p3b_cloud_zoo_vs_qhull(pd, kind):
     assert len(bad) <= max(2, st['unresolved']), (kind, len(bad), st)
 
 
+def test_p3b_eye_inside_the_cloud(pd):
+    """Eyes inside the cloud's bounding box (the direction grid of level 0 has no face to project on: that level switches itself
+    off) and just outside a dense blob."""
+    from pointdreamer_amd import hpr
+    rng = np.random.default_rng(21)
+    pts = rng.standard_normal((6000, 3)); pts = (0.5 * pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.7, 1.0, (6000, 1))).astype(np.float32)
+    eyes = np.array([[0.1, 0.05, 0.0], [0.0, 0.0, 0.3], [0.45, 0.45, 0.45], [0.0, 0.6, 0.0]], np.float64)
+    got, st = hpr.hidden_point_removal(T(pts), eyes, 100, return_stats=True)
+    got = N_(got)
+    want = oproj.point_validation_by_hpr(pts, eyes, 100)
+    bad = np.argwhere(got != want)
+    for v, i in bad[:50]:
+        m = oproj.hpr_margin(oproj.hpr_flip(pts, eyes[v], 100), i)
+        assert abs(m) < 1e-9 and bool(got[v, i]) == (m > 0), (v, i, m)
+    assert len(bad) <= 2 and st['unresolved'] == 0, (len(bad), st)
+
+
 def test_p3b_duplicates_and_tiny_clouds(pd):
     """Coinciding points: the smallest index is the hull vertex, the copies are hidden (qhull keeps one of them, which one is
     its processing order); clouds below the two-level threshold and of a handful of points take the one-level path."""
