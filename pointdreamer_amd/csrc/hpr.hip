@@ -1366,7 +1366,9 @@ __global__ __launch_bounds__(256) void k_hpr_boxes(const double* __restrict__ ss
 // other point), so this is the same approximate f32 GEMM + column maximum as the level-1 scan: A = 32 points, B = 64 of the
 // directions, a wave keeps the best tile per lane and locates the row afterwards.  The cloud is cut into HPR_EXT_POINTS-point
 // slabs (one wave per slab and 64 directions); the slabs meet in an atomicMax on (value, index) keys.
-#define HPR_EXT_POINTS 2048      // (512-point slabs: four times the waves, but also four times the atomics on the same keys: 94 us against 42)
+#ifndef HPR_EXT_POINTS
+#define HPR_EXT_POINTS 2048
+#endif
 __device__ __forceinline__ unsigned int f32_key(float x) { const unsigned int b = __float_as_uint(x); return (b >> 31) ? ~b : (b | 0x80000000u); }
 __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, const double* __restrict__ fdir /*[KC][4]*/,
                                                       unsigned long long* __restrict__ keys /*[V][KC], zeroed*/) {
