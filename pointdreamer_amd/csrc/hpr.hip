@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
 // themselves in f64.  Equal support values: the smaller cloud index, so the result does not depend on the order inside a cell.
 #define HPR_BOX_FLOATS 16        // e0, e1, e2, lo, hi (3 each), pad
 #define HPR_BOUND_SLACK 1.0e-5   // x |d|_1 max|coordinate|: f32 evaluation of the bound (<= 3e-6) with margin
-struct Support { double val, x, y, z; int pos, idx; };      // wave-uniform; pos < 0: no point of S_i reaches the threshold
+struct Support { double val, x, y, z; int pos, idx;           // wave-uniform; pos < 0: no point of S_i reaches the threshold
+                 double lx, ly, lz; int lidx; };            // lane-private: the best point THIS lane came across (lidx < 0: none)
 // DUPX: also exclude the points that coincide with the query and have a larger cloud index (the distance iteration's rule)
 template <bool DUPX, int BATCH>        // BATCH candidate chunks per trip (their loads are in flight together)
 __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
@@ -679,6 +680,7 @@ __device__ __forceinline__ Support support_scan(const double* __restrict__ fx, c
         }
     }
     Support r;
+    r.lx = bx; r.ly = by; r.lz = bz; r.lidx = bpos >= 0 ? bidx : -1;
     r.val = wave_max_f64(best);
     r.idx = wave_min_i32(best == r.val ? bidx : 0x7fffffff);
     const unsigned long long who = __ballot(best == r.val && bidx == r.idx && bpos >= 0);
@@ -786,7 +788,6 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
         li[u] = (j < NS && id != q) ? id : -2;
     }
     lx[HPR_LOCAL] = ly[HPR_LOCAL] = lz[HPR_LOCAL] = 0.0; li[HPR_LOCAL] = -2;       // the slot for what the global scans return
-    int n_extra = 0;
     // (everything below is identical in every lane, except inside closest_with_newest)
     d3 W0 = {0, 0, 0}, W1 = {0, 0, 0}, W2 = {0, 0, 0}, vclose = pi, dir = pi;     // first direction: straight out along the point's own ray
     // ... except for a member of the coarse set (most of this level's queries): it was found as the extreme point of a known
@@ -858,9 +859,10 @@ __global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict_
                                                      base >> 6, (base >> 6) + HPR_LOCAL);      // (the working set's own chunks are in myv already)
             if (r.pos >= 0 && (!have || r.val > myv || (r.val == myv && r.idx < si))) {
                 myv = r.val; si = r.idx; sp = d3{r.x, r.y, r.z}; have = true;
-                if (lane == n_extra) { lx[HPR_LOCAL] = r.x; ly[HPR_LOCAL] = r.y; lz[HPR_LOCAL] = r.z; li[HPR_LOCAL] = r.idx; }
-                n_extra = min(n_extra + 1, 64);
             }
+            // what the scan came across joins the working set: every lane keeps the best far point IT saw (the winner is among them) --
+            // the next directions are close to this one, and the next violator is most likely one of these 64
+            if (r.lidx >= 0) { lx[HPR_LOCAL] = r.lx; ly[HPR_LOCAL] = r.ly; lz[HPR_LOCAL] = r.lz; li[HPR_LOCAL] = r.lidx; }
         }
 #ifdef PD_HPR_STATS
         const unsigned long long f2 = lab_clock() + (have ? 0 : 0);
