@@ -36,7 +36,7 @@ def test_argument_validation_sets_error_message():
     assert rc == -1
     assert b'pdhip_raster_mesh' in L.pdhip_last_error()
     rc = L.pdhip_nearest_fill(None, None, 1, 3, 8, 8, 0, 0, 0, None, 0, 0, None, None)
-    assert L.pdhip_nearest_fill_ws_ints(2, 256, 256) == 2 * 256 * 256 + 2 * 2 * 4 * 256
+    assert L.pdhip_nearest_fill_ws_ints(2, 256, 256) == 2 * 256 * 256 + 2 * 2 * 16 * 256      # near_row + first / last site per 16-row column segment
     assert rc == -1
 
 
