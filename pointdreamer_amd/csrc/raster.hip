@@ -157,7 +157,9 @@ __global__ void k_raster_setup(const float* __restrict__ pos, int Vn, const int3
 __global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restrict__ setup, const short4* __restrict__ bbox, int F,
                                                        int R, uint8_t* __restrict__ hard, int64_t* __restrict__ fid,
                                                        float* __restrict__ depth) {
-    __shared__ unsigned long long s_z[RT * RT];
+    // (rows 72 words apart: at 64, the eight rows of an 8x8 lane block fall on the same 16 banks -- an 8-way conflict on every atomic)
+    constexpr int RTS = RT + 8;
+    __shared__ unsigned long long s_z[RT * RTS];
     __shared__ unsigned short s_list[1024 + 4096];                // (this path takes meshes of at most 65 536 faces)
     __shared__ int s_wcnt[16];
     const int v = blockIdx.y, tiles_x = (R + RT - 1) / RT;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restri
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const FaceSetup* S = setup + (size_t)v * F;
     const short4* B = bbox + (size_t)v * F;
-    for (int k = t; k < RT * RT; k += 1024) s_z[k] = ~0ull;
+    for (int k = t; k < RT * RTS; k += 1024) s_z[k] = ~0ull;
     int count = 0;                                                   // faces waiting in s_list (block-uniform)
     const double lx = (double)(lane & 7), ly = (double)(lane >> 3);
 
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restri
                         const double zd = (E0 * z0 + E1 * z1) + E2 * z2;
                         const float z = (float)(zd / darea);
                         if (z >= -1.0f && z <= 1.0f)
-                            atomicMin(&s_z[(i - ty0) * RT + (j - tx0)], ((unsigned long long)f2ord(z) << 32) | (uint32_t)fidx);
+                            atomicMin(&s_z[(i - ty0) * RTS + (j - tx0)], ((unsigned long long)f2ord(z) << 32) | (uint32_t)fidx);
                     }
                     E0 += sx0; E1 += sx1; E2 += sx2;
                 }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restri
         const int i = ty0 + (k >> 6), j = tx0 + (k & 63);
         if (i >= R || j >= R) continue;
         const size_t o = ((size_t)v * R + i) * R + j;
-        const unsigned long long key = s_z[k];
+        const unsigned long long key = s_z[(k >> 6) * RTS + (k & 63)];
         const bool hit = key != ~0ull;
         hard[o] = hit ? 1 : 0;
         fid[o] = hit ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
