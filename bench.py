@@ -82,9 +82,11 @@ def cpu_baseline(timed=3, max_workers=32):
     """Reference CPU 'nearest' path next to the GPU number.  kind = "port": the reference has no runnable
     CPU pipeline (demo.py:12,19 hard-code CUDA; kaolin / nvdiffrast are CUDA-only), so this is the oracle's CPU restatement of
     it -- project, raster, depth test + hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF
-    unproject, atlas dilate -- at BASELINE sizes.  All host cores are used the way a CPU deployment of this throughput metric
-    would use them: one independent shape stream per core (the per-shape code is serial numpy / scipy, as the reference's is);
-    every worker runs 1 warm-up + `timed` shapes (about 20 s of wall time), the aggregate rate is shapes / slowest worker's
+    unproject, atlas dilate -- at BASELINE sizes.  Host cores are used the way a CPU deployment of this throughput metric would
+    use them: one independent shape stream per core (the per-shape code is serial numpy / scipy, as the reference's is), on
+    min(`max_workers`, host cores) cores -- bounded so that the default bench run stays within minutes and ~1 GB per worker fits
+    any box of the pool; `cores`, `host_cores` and the per-core rate are reported, so the all-core figure can be read off.
+    Every worker runs 1 warm-up + `timed` shapes (about 40 s of wall time), the aggregate rate is shapes / slowest worker's
     wall time."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
