@@ -11,7 +11,7 @@ SHAPES = [(8, 64, 64, 512, 512, 9), (8, 32, 32, 512, 512, 9), (8, 32, 32, 1024, 
           (8, 8, 8, 1024, 1024, 9), (8, 8, 8, 2048, 1024, 9), (8, 32, 32, 512, 1536, 1), (8, 32, 32, 512, 512, 1),
           (8, 16, 16, 1024, 3072, 1), (8, 16, 16, 1024, 1024, 1), (8, 8, 8, 1024, 3072, 1), (8, 8, 8, 1024, 1024, 1)]
 import argparse
-ap = argparse.ArgumentParser(); ap.add_argument('--custom', type=int, nargs='*', default=None); ap.add_argument('--geos', type=int, nargs='*', default=[2, 8])
+ap = argparse.ArgumentParser(); ap.add_argument('--custom', type=int, nargs='*', default=None); ap.add_argument('--geos', type=int, nargs='*', default=[0, 2, 8, 32])
 a = ap.parse_args()
 if a.custom:
     SHAPES = [tuple(a.custom[i:i + 6]) for i in range(0, len(a.custom), 6)]
@@ -27,7 +27,7 @@ for (N, H, W, Cin, Cout, taps) in SHAPES:
     y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev)
     fl = 2.0 * N * H * W * Cout * taps * Cin
     print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} taps{taps} ({fl/1e9:6.1f} GFLOP)")
-    for geo in (2, 8, 32):
+    for geo in a.geos:
         row = []
         for sp in (0, 1, 2, 3, 4, 6, 8, 12, 16):
             L.pdhip_debug_set_conv_tile(geo); L.pdhip_debug_set_conv_splitk(P(ws), ws.numel(), sp)
