@@ -90,11 +90,11 @@ __global__ void k_raster_faces(const float* __restrict__ pos, int Vn, const int3
 
 // ---- LDS-tiled path
 struct __attribute__((aligned(16))) FaceSetup {     // edge functions as exact doubles (integers below 2^52), winding made positive
-    double e0, e1, e2;             // edge functions at the centre of pixel (0, 0)
-    double ax0, ax1, ax2;          // step per +1 pixel column
-    double ay0, ay1, ay2;          // step per +1 pixel row
-    double z0, z1, z2, darea;
-    int jmin, jmax, imin, imax;    // pixel bounding box, empty (jmin > jmax) for culled / degenerate faces
+    double e0, e1, e2;             // edge functions at the centre of pixel (0, 0), biased by the tie rule (see k_raster_setup)
+    double ax0, ax1, ax2;          // step per +8 pixel columns
+    double ay0, ay1, ay2;          // step per +8 pixel rows
+    double z0, z1, z2, darea, rinv;   // rinv = 1 / darea (correctly rounded)
+    short jmin, jmax, imin, imax;  // pixel bounding box, empty (jmin > jmax) for culled / degenerate faces
     int inc, pad;                  // bit k of inc = tie rule of edge k
 };
 
@@ -105,7 +105,7 @@ __global__ void k_raster_setup(const float* __restrict__ pos, int Vn, const int3
     if (f >= F) return;
     FaceSetup fs;
     fs.e0 = fs.e1 = fs.e2 = fs.ax0 = fs.ax1 = fs.ax2 = fs.ay0 = fs.ay1 = fs.ay2 = 0.0; fs.jmin = 1; fs.jmax = 0; fs.imin = 1; fs.imax = 0; fs.inc = 0; fs.pad = 0;
-    fs.z0 = fs.z1 = fs.z2 = 0.0; fs.darea = 1.0;
+    fs.z0 = fs.z1 = fs.z2 = 0.0; fs.darea = 1.0; fs.rinv = 1.0;
     const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)v * Vn;
     const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
     if ((unsigned)i0 < (unsigned)Vn && (unsigned)i1 < (unsigned)Vn && (unsigned)i2 < (unsigned)Vn) {
@@ -125,84 +125,116 @@ __global__ void k_raster_setup(const float* __restrict__ pos, int Vn, const int3
             }
             const long long minx = min(x0, min(x1, x2)), maxx = max(x0, max(x1, x2));
             const long long miny = min(y0, min(y1, y2)), maxy = max(y0, max(y1, y2));
-            fs.jmin = (int)max(0ll, -floor_div(-(minx - 128), SUBPIX));
-            fs.jmax = (int)min((long long)R - 1, floor_div(maxx - 128, SUBPIX));
-            fs.imin = (int)max(0ll, -floor_div(-(miny - 128), SUBPIX));
-            fs.imax = (int)min((long long)R - 1, floor_div(maxy - 128, SUBPIX));
+            // (clamped to [0, R] / [-1, R - 1] before the 16-bit store: an off-screen face stays an empty box)
+            fs.jmin = (short)min((long long)R, max(0ll, -floor_div(-(minx - 128), SUBPIX)));
+            fs.jmax = (short)max(-1ll, min((long long)R - 1, floor_div(maxx - 128, SUBPIX)));
+            fs.imin = (short)min((long long)R, max(0ll, -floor_div(-(miny - 128), SUBPIX)));
+            fs.imax = (short)max(-1ll, min((long long)R - 1, floor_div(maxy - 128, SUBPIX)));
             const long long dx0 = x2 - x1, dy0 = y2 - y1, dx1 = x0 - x2, dy1 = y0 - y2, dx2 = x1 - x0, dy2 = y1 - y0;
             fs.inc = (((dy0 > 0) || (dy0 == 0 && dx0 > 0)) ? 1 : 0) | (((dy1 > 0) || (dy1 == 0 && dx1 > 0)) ? 2 : 0) |
                      (((dy2 > 0) || (dy2 == 0 && dx2 > 0)) ? 4 : 0);
-            // E_k(j, i) = E_k(0, 0) + j ax_k + i ay_k at pixel centres (256 j + 128, 256 i + 128): every term an integer below 2^52
-            fs.e0 = (double)(dx0 * (128 - y1) - dy0 * (128 - x1)); fs.e1 = (double)(dx1 * (128 - y2) - dy1 * (128 - x2));
-            fs.e2 = (double)(dx2 * (128 - y0) - dy2 * (128 - x0));
-            fs.ax0 = (double)(-dy0 * SUBPIX); fs.ax1 = (double)(-dy1 * SUBPIX); fs.ax2 = (double)(-dy2 * SUBPIX);
-            fs.ay0 = (double)(dx0 * SUBPIX); fs.ay1 = (double)(dx1 * SUBPIX); fs.ay2 = (double)(dx2 * SUBPIX);
-            fs.z0 = z0; fs.z1 = z1; fs.z2 = z2; fs.darea = (double)area;
+            // E_k(j, i) = E_k(0, 0) + j ax_k + i ay_k at pixel centres (256 j + 128, 256 i + 128): every term an integer below 2^52.
+            // Stored: the steps per EIGHT pixels, and e_k = E_k(0, 0) + t_k - 1 (t_k = tie rule of edge k): a pixel is inside
+            // edge k iff E_k > 0 or (E_k = 0 and t_k), i.e. iff the biased value is >= 0 -- a sign-bit test.
+            fs.e0 = (double)(dx0 * (128 - y1) - dy0 * (128 - x1) + (fs.inc & 1) - 1);
+            fs.e1 = (double)(dx1 * (128 - y2) - dy1 * (128 - x2) + ((fs.inc >> 1) & 1) - 1);
+            fs.e2 = (double)(dx2 * (128 - y0) - dy2 * (128 - x0) + ((fs.inc >> 2) & 1) - 1);
+            fs.ax0 = (double)(-dy0 * SUBPIX * 8); fs.ax1 = (double)(-dy1 * SUBPIX * 8); fs.ax2 = (double)(-dy2 * SUBPIX * 8);
+            fs.ay0 = (double)(dx0 * SUBPIX * 8); fs.ay1 = (double)(dx1 * SUBPIX * 8); fs.ay2 = (double)(dx2 * SUBPIX * 8);
+            fs.z0 = z0; fs.z1 = z1; fs.z2 = z2; fs.darea = (double)area; fs.rinv = 1.0 / (double)area;
             if (fs.imin > fs.imax) { fs.jmin = 1; fs.jmax = 0; }
         }
     }
     setup[(size_t)v * F + f] = fs;
-    bbox[(size_t)v * F + f] = make_short4((short)fs.jmin, (short)fs.jmax, (short)fs.imin, (short)fs.imax);
+    bbox[(size_t)v * F + f] = make_short4(fs.jmin, fs.jmax, fs.imin, fs.imax);
 }
 
+#ifndef RT
 #define RT 64                      // tile edge (pixels); the tile's z-key buffer lives in LDS
+#endif
+#ifndef RNT
+#define RNT 1024                   // threads per tile
+#endif
+#ifndef RWPE
+#define RWPE 8                     // waves per SIMD the register allocation has to admit: TWO tiles per CU.  Unconstrained, the compiler
+#endif                             // takes 106 SGPRs = 6 waves per SIMD = one 16-wave tile per CU (P1+P2 131 us; 12-wave tiles, two per CU:
+                                   // 108-111; 16-wave tiles at 78 SGPRs, two per CU: 105)
+#define RNW (RNT / 64)
 // One workgroup per (view, 64x64 tile).  The faces whose bounding box touches the tile are compacted into an LDS list
 // (ballot + per-wave counts, four faces per thread and step); every wave then takes faces off the list: the face's setup record
 // is wave-uniform, its edge functions at the clipped bounding box's corner are three exact FMAs on the record, and the box is
 // covered in 8x8 lane blocks, stepping the edge functions by additions and depth-testing with 64-bit LDS atomicMin on the same
 // (z-order, face) key as the fallback path.  Measured on 8 views x 9 800 faces x 512^2 (100 us): binning + clear + write-out 23 us,
-// the f64 division per covered pixel 17 us, the LDS atomics 8 us; the rest is the per-face loop itself (one L2 round trip per
-// record, hidden one face deep).  A staging pass that re-derived tile-local records from the snapped integer vertices, 256 faces
+// the f64 division per covered pixel 17 us, the LDS atomics 8 us; the rest is the per-face loop itself.  A staging pass that re-derived tile-local records from the snapped integer vertices, 256 faces
 // at a time behind two barriers, was no faster (101 us).
-__global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restrict__ setup, const short4* __restrict__ bbox, int F,
+__global__ __launch_bounds__(RNT, RWPE) void k_raster_tiles(const FaceSetup* __restrict__ setup, const short4* __restrict__ bbox, int F, int V,
                                                        int R, uint8_t* __restrict__ hard, int64_t* __restrict__ fid,
                                                        float* __restrict__ depth) {
     // (rows 72 words apart: at 64, the eight rows of an 8x8 lane block fall on the same 16 banks -- an 8-way conflict on every atomic)
     constexpr int RTS = RT + 8;
     __shared__ unsigned long long s_z[RT * RTS];
-    __shared__ unsigned short s_list[1024 + 4096];                // (this path takes meshes of at most 65 536 faces)
-    __shared__ int s_wcnt[16];
-    const int v = blockIdx.y, tiles_x = (R + RT - 1) / RT;
-    const int tx0 = (blockIdx.x % tiles_x) * RT, ty0 = (blockIdx.x / tiles_x) * RT;
+    __shared__ unsigned short s_list[RNT + 4 * RNT];              // (this path takes meshes of at most 65 536 faces)
+    __shared__ int s_wcnt[RNW];
+    // view = fastest index of the 1-D grid: workgroup b runs on XCD b % 8, so every XCD gets tiles of every screen position (with the
+    // tile as the fastest index an XCD received one tile COLUMN of all views -- the empty border columns or the full centre ones)
+    const int v = blockIdx.x % V, tile = blockIdx.x / V, tiles_x = (R + RT - 1) / RT;
+    const int tx0 = (tile % tiles_x) * RT, ty0 = (tile / tiles_x) * RT;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const FaceSetup* S = setup + (size_t)v * F;
     const short4* B = bbox + (size_t)v * F;
-    for (int k = t; k < RT * RTS; k += 1024) s_z[k] = ~0ull;
+    for (int k = t; k < RT * RTS; k += RNT) s_z[k] = ~0ull;
     int count = 0;                                                   // faces waiting in s_list (block-uniform)
-    const double lx = (double)(lane & 7), ly = (double)(lane >> 3);
+    const double lx = (double)(lane & 7) * 0.125, ly = (double)(lane >> 3) * 0.125;
 
     auto resolve = [&](int n) {                                      // rasterise faces s_list[0 .. n) into s_z
-        // (the next face's record is requested before the current one is rasterised: the loop is otherwise one exposed L2
-        // round trip per face)
-        int fnext = wave < n ? __builtin_amdgcn_readfirstlane((int)s_list[wave]) : 0;
-        FaceSetup qn = S[fnext];
-        for (int k = wave; k < n; k += 16) {
-            const int fidx = fnext;
-            const FaceSetup q = qn;
-            if (k + 16 < n) { fnext = __builtin_amdgcn_readfirstlane((int)s_list[k + 16]); qn = S[fnext]; }
-            const int j0 = max(q.jmin, tx0), j1 = min(q.jmax, tx0 + RT - 1);
-            const int i0 = max(q.imin, ty0), i1 = min(q.imax, ty0 + RT - 1);
+        // (one L2 round trip per record, covered by the other seven waves of the SIMD: requesting the next record one face
+        // ahead costs 32 more SGPRs and, with them, the second resident tile)
+#ifdef PD_LAB_RASTER_NORESOLVE
+        n = 0;
+#endif
+        for (int k = wave; k < n; k += RNW) {
+            const int fidx = __builtin_amdgcn_readfirstlane((int)s_list[k]);
+            const FaceSetup q = S[fidx];
+#ifdef PD_LAB_RASTER_LOADONLY
+            if (q.darea == 123.456) s_z[0] = 0;
+            continue;
+#endif
+            const int j0 = max((int)q.jmin, tx0), j1 = min((int)q.jmax, tx0 + RT - 1);
+            const int i0 = max((int)q.imin, ty0), i1 = min((int)q.imax, ty0 + RT - 1);
             const int nbx = (j1 - j0 + 8) >> 3, nby = (i1 - i0 + 8) >> 3;
             const int inc = q.inc;
-            const double ax0 = q.ax0, ax1 = q.ax1, ax2 = q.ax2, ay0 = q.ay0, ay1 = q.ay1, ay2 = q.ay2;
+            const double sx0 = q.ax0, sx1 = q.ax1, sx2 = q.ax2, sy0 = q.ay0, sy1 = q.ay1, sy2 = q.ay2;
             const double z0 = q.z0, z1 = q.z1, z2 = q.z2, darea = q.darea;
-            const double px = (double)j0 + lx, py = (double)i0 + ly;
-            double r0 = fma(py, ay0, fma(px, ax0, q.e0));            // exact: integers below 2^52
-            double r1 = fma(py, ay1, fma(px, ax1, q.e1));
-            double r2 = fma(py, ay2, fma(px, ax2, q.e2));
-            const double sx0 = 8.0 * ax0, sx1 = 8.0 * ax1, sx2 = 8.0 * ax2;
-            const double sy0 = 8.0 * ay0, sy1 = 8.0 * ay1, sy2 = 8.0 * ay2;
-            const bool t0 = inc & 1, t1 = inc & 2, t2 = inc & 4;
+            const double px = fma((double)j0, 0.125, lx), py = fma((double)i0, 0.125, ly);     // in units of eight pixels (exact)
+            double r0 = fma(py, sy0, fma(px, sx0, q.e0));            // exact: integers below 2^52
+            double r1 = fma(py, sy1, fma(px, sx1, q.e1));
+            double r2 = fma(py, sy2, fma(px, sx2, q.e2));
+            const double b0 = (inc & 1) ? 0.0 : 1.0, b1 = (inc & 2) ? 0.0 : 1.0, b2 = (inc & 4) ? 0.0 : 1.0;   // E_k = biased + b_k
+#ifndef PD_LAB_RASTER_DIV
+            const double rinv = q.rinv;
+#endif
             for (int by = 0; by < nby; ++by) {
                 double E0 = r0, E1 = r1, E2 = r2;
                 const int i = i0 + by * 8 + (lane >> 3);
                 for (int bx = 0; bx < nbx; ++bx) {
                     const int j = j0 + bx * 8 + (lane & 7);
-                    const bool in = j <= j1 && i <= i1 && (E0 > 0.0 || (E0 == 0.0 && t0)) && (E1 > 0.0 || (E1 == 0.0 && t1)) &&
-                                    (E2 > 0.0 || (E2 == 0.0 && t2));
+                    const bool in = j <= j1 && i <= i1 && (__double2hiint(E0) | __double2hiint(E1) | __double2hiint(E2)) >= 0;
                     if (in) {
-                        const double zd = (E0 * z0 + E1 * z1) + E2 * z2;
+                        const double zd = ((E0 + b0) * z0 + (E1 + b1) * z1) + (E2 + b2) * z2;
+#ifdef PD_LAB_RASTER_DIV
                         const float z = (float)(zd / darea);
+#else
+                        // z = float(zd / darea) without the division: zd * (1 / darea) is within 2.5 ulp of the correctly rounded
+                        // quotient, so both round to the same float unless a float rounding boundary (low 29 mantissa bits =
+                        // 2^28) lies that close -- then, and below the float normal range, divide.
+                        const double qa = zd * rinv;
+                        const bool near = (unsigned)((__double2loint(qa) & 0x1fffffff) - (0x10000000 - 8)) <= 16u || !(fabs(qa) >= 0x1p-120);
+                        float z = (float)qa;
+                        if (__ballot(near) != 0ull) {                                  // (a real, wave-uniform branch: the empty asm keeps the compiler
+                            asm volatile("" ::: "memory");                             // from turning it into a select that divides every time)
+                            z = (float)(zd / darea);
+                        }
+#endif
                         if (z >= -1.0f && z <= 1.0f)
                             atomicMin(&s_z[(i - ty0) * RTS + (j - tx0)], ((unsigned long long)f2ord(z) << 32) | (uint32_t)fidx);
                     }
@@ -215,12 +247,12 @@ __global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restri
     };
 
     // binning: four faces per thread and step (one block-wide compaction per 4096 faces instead of per 1024)
-    for (int base = 0; base < F; base += 4096) {
+    for (int base = 0; base < F; base += 4 * RNT) {
         bool ov[4];
         int wtot = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int f = base + u * 1024 + t;
+            const int f = base + u * RNT + t;
             ov[u] = false;
             if (f < F) {
                 const short4 bb = B[f];                                        // (jmin, jmax, imin, imax)
@@ -234,27 +266,27 @@ __global__ __launch_bounds__(1024) void k_raster_tiles(const FaceSetup* __restri
         __syncthreads();
         int off = count, tot = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) {
+        for (int w = 0; w < RNW; ++w) {
             const int c = s_wcnt[w];
             off += w < wave ? c : 0;
             tot += c;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (ov[u]) s_list[off + __popcll(bal[u] & ((1ull << lane) - 1ull))] = (unsigned short)(base + u * 1024 + t);
+            if (ov[u]) s_list[off + __popcll(bal[u] & ((1ull << lane) - 1ull))] = (unsigned short)(base + u * RNT + t);
             off += __popcll(bal[u]);
         }
         count += tot;
         __syncthreads();
-        if (count >= 1024) { resolve(count); count = 0; }
+        if (count >= RNT) { resolve(count); count = 0; }
     }
     if (count > 0) resolve(count);
     __syncthreads();
-    for (int k = t; k < RT * RT; k += 1024) {
-        const int i = ty0 + (k >> 6), j = tx0 + (k & 63);
+    for (int k = t; k < RT * RT; k += RNT) {
+        const int i = ty0 + k / RT, j = tx0 + k % RT;
         if (i >= R || j >= R) continue;
         const size_t o = ((size_t)v * R + i) * R + j;
-        const unsigned long long key = s_z[(k >> 6) * RTS + (k & 63)];
+        const unsigned long long key = s_z[(k / RT) * RTS + k % RT];
         const bool hit = key != ~0ull;
         hard[o] = hit ? 1 : 0;
         fid[o] = hit ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
@@ -289,7 +321,7 @@ extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t*
         short4* bbox = reinterpret_cast<short4*>(setup + (size_t)V * F);
         k_raster_setup<<<dim3(cdiv(F, 256), V), 256, 0, s>>>(pos, Vn, faces, F, R, setup, bbox);
         const int tiles = cdiv(R, RT) * cdiv(R, RT);
-        k_raster_tiles<<<dim3(tiles, V), 1024, 0, s>>>(setup, bbox, F, R, hard_masks, face_idxs, depths);
+        k_raster_tiles<<<tiles * V, RNT, 0, s>>>(setup, bbox, F, V, R, hard_masks, face_idxs, depths);
         PD_LAUNCH_CHECK();
         return PDHIP_OK;
     }

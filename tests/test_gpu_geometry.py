@@ -91,6 +91,48 @@ def test_p1_p2_project_and_raster_vs_oracle(pd, n_points, stacks, slices, V, R):
     assert out2[4] == 0 and out2[5] == 2 and out2[6] == 0
 
 
+def hostile_triangles():
+    rng = np.random.default_rng(11)
+    c = rng.uniform(-1.1, 1.1, (100, 1, 2))
+    small = (c + rng.uniform(-0.15, 0.15, (100, 3, 2))).reshape(300, 2)                  # 100 small triangles, some across the border
+    mid = rng.uniform(-400, 400, (9, 2)); mid[::3] = rng.uniform(-1, 1, (3, 2))          # 3 long slivers reaching far outside
+    huge = rng.uniform(-3e4, 3e4, (6, 2))                                                # 2 triangles with vertices beyond the fixed-point clamp
+    far = np.array([[300.0, 0.1], [301.0, 0.3], [300.5, 0.9], [-300.0, 0.1], [-301.0, 0.3], [-300.5, 0.9],
+                    [0.1, 500.0], [0.3, 501.0], [0.9, 500.5], [0.1, -500.0], [0.3, -501.0], [0.9, -500.5],
+                    [1000.0, 0.1], [1001.0, 0.3], [1000.5, 0.9], [-1000.0, 0.1], [-1001.0, 0.3], [-1000.5, 0.9],
+                    [0.1, 1400.0], [0.3, 1401.0], [0.9, 1400.5], [0.1, -1400.0], [0.3, -1401.0], [0.9, -1400.5]])   # wholly off-screen, each side (the last four beyond +-32767 pixels)
+    xy = np.concatenate([small, mid, huge, far]).astype(np.float32)
+    n = xy.shape[0]
+    z = rng.uniform(-1.3, 1.3, n).astype(np.float32)                                     # part of the depths outside [-1, 1]
+    pos = np.stack([xy[:, 0], xy[:, 1], z, np.ones(n, np.float32)], 1)[None].repeat(2, 0).copy()
+    pos[1, :, :2] = pos[1, :, 1::-1] * np.float32(0.7)                                   # a second, different view
+    pos[1, 5, 0] = np.nan; pos[1, 7, 1] = np.inf
+    faces = np.arange(n).reshape(-1, 3)
+    extra = np.array([[0, 0, 1], [3, 4, 4], [6, 6, 6], [0, 1, 2], [2, 1, 0], [9, 10, 12], [9, 12, 13], [0, 4, 8], [0, 8, 12]])  # zero-area, duplicates, shared edges
+    return pos, np.concatenate([faces, extra]).astype(np.int64)
+
+
+def test_p2_raster_offscreen_huge_and_degenerate_faces_vs_oracle(pd):
+    """P2 on hostile triangles: wholly outside the screen on every side (bounding boxes beyond the 16-bit pixel range), vertices beyond
+    the fixed-point clamp, slivers straddling the border, zero-area faces, duplicated faces in both windings, shared edges (fill
+    rule), depths outside [-1, 1], non-finite vertices.  Both paths (LDS tiles, global atomics) against the oracle, bit for bit."""
+    from pointdreamer_amd import extract_texture_map as etm, _lib
+    R = 96
+    pos, faces = hostile_triangles()
+    oh, of, od = oproj.rasterize(pos, faces, R)
+    assert oh.any() and (~oh).any() and len(np.unique(of)) > 40
+    L = _lib.lib()
+    for path in (0, 1):
+        old = L.pdhip_debug_set_raster_path(path)
+        try:
+            fidx, _, depth, hard = etm.rasterize(T(pos), T(faces), R)
+        finally:
+            L.pdhip_debug_set_raster_path(old)
+        assert np.array_equal(N_(hard), oh), path
+        assert np.array_equal(N_(fidx), of), path
+        assert np.array_equal(N_(depth), od), path
+
+
 @pytest.mark.parametrize("name", ["proj_sparse_dense.npz", "proj_sparse_rescale.npz", "proj_sparse_ps2.npz",
                                   "proj_sparse_scale_near1.npz"])
 def test_p1_to_p6_vs_reference_golden(pd, name):

@@ -13,3 +13,5 @@ for _ in range(3): r = ou.get_rendered_hard_mask_and_face_idx_batch(cams, V, F, 
 torch.cuda.synchronize(); t=time.time()
 for _ in range(20): r = ou.get_rendered_hard_mask_and_face_idx_batch(cams, V, F, P, None, True, 0.05)
 torch.cuda.synchronize(); print('P1+P2 us', (time.time()-t)/20*1e6)
+if len(sys.argv) > 2:                                   # save the outputs for a comparison between builds
+    np.savez(sys.argv[2], **{f'o{i}': (x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)) for i, x in enumerate(r) if torch.is_tensor(x)})
