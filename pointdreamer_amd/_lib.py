@@ -120,3 +120,39 @@ def ptr(t, dtype=None, allow_none=False):
 def as_u8(t):
     """torch.bool <-> uint8 views share storage (bool is one byte, values 0/1)."""
     return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+# ---- derived constants of long-lived inputs (a mesh's int32 face table, the stacked camera parameters, the eye positions on the
+# device ...): recomputed only when the source object changes.  An entry is valid while the very same tensor object is alive and
+# unmodified (weak reference + torch's version counter), so a recycled address can never serve a stale result.
+import weakref as _weakref
+_MEMO = {}
+
+
+def memo(src, tag, fn):
+    """fn(src) cached per (tensor object, tag).  `src`: a tensor, or a tuple / list of tensors (all must be the same objects)."""
+    items = tuple(src) if isinstance(src, (tuple, list)) else (src,)
+    key = (tag,) + tuple(id(t) for t in items)
+    hit = _MEMO.get(key)
+    if hit is not None:
+        refs, vers, val = hit
+        if all(r() is t for r, t in zip(refs, items)) and vers == tuple(t._version for t in items):
+            return val
+    val = fn(src)
+    if len(_MEMO) > 256:
+        _MEMO.clear()
+    _MEMO[key] = (tuple(_weakref.ref(t) for t in items), tuple(t._version for t in items), val)
+    return val
+
+
+_CONST = {}
+
+
+def const_vec(n, value, dev):
+    """A read-only [n] float32 vector of one value on `dev` (the kernels' form of the reference's python-scalar crop parameters)."""
+    key = (int(n), float(value), str(dev))
+    v = _CONST.get(key)
+    if v is None:
+        v = _CONST[key] = torch.full((int(n),), float(value), device=dev)
+    return v
+

@@ -58,7 +58,8 @@ class Camera:
 
 
 def stack_params(cams):
-    return torch.stack([c.params for c in cams], 0).contiguous()
+    from . import _lib
+    return _lib.memo([c.params for c in cams], 'stack_params', lambda ps: torch.stack(list(ps), 0).contiguous())
 
 
 def create_cameras(num_views=8, distance=1.6, res=512, distribution='fibonacci_sphere',

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_hpr_shield(const double* __restrict__ 
         __syncthreads();
         const int base = s_base + mine;
         if (q) list[(size_t)v * N + base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        else if (sk) vis[(size_t)v * N + i] = 1;
+        else if (in) vis[(size_t)v * N + i] = sk ? 1 : 0;           // skipped: visible; certified behind the shield: hidden
         __syncthreads();
     }
     (void)counters;
@@ -411,7 +411,7 @@ template <int COLS>          // query columns of 32 per wavefront: 2 = a query i
 __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                     const int* __restrict__ list, const float4* __restrict__ csf /*[V][KC]*/,
                                                     const double* __restrict__ csd /*[V][KC][4]*/, const int* __restrict__ cidx /*[V][KC]*/,
-                                                    const int* __restrict__ kcount, uint8_t* __restrict__ outside,
+                                                    const int* __restrict__ kcount, uint8_t* __restrict__ outside, uint8_t* __restrict__ vis,
                                                     const unsigned long long* __restrict__ maxabs, double* __restrict__ qdir /*[V][N][3]*/) {
     const int v = blockIdx.y;
     const int nq = count[v];
@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
                  atomicAdd(&g_hpr_stats[0][8 + min(my_rounds, 63) / 8], 1ull); }
 #endif
     if (owner) outside[(size_t)v * N + q] = g.state != 2;        // 0: CERTIFIED enclosed by the coarse hull: hidden, and never a support point
+    if (owner && g.state == 2) vis[(size_t)v * N + q] = 0;       // (the verdict array is written in full: callers need not clear it)
     if (owner && g.state != 2) {                                  // level 2 starts where this level stopped looking
         double* qd = qdir + ((size_t)v * N + q) * 3;
         qd[0] = g.dir.x; qd[1] = g.dir.y; qd[2] = g.dir.z;
@@ -1545,7 +1546,7 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
         k_hpr_shield<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, bbox, sgrid, skip, count, list, visibility, counters);
         k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, fdir, ekeys);
         k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir);
-        k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, maxabs, qdir);
+        k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, visibility, maxabs, qdir);
     }
     k_hpr_bin<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);

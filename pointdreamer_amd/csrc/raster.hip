@@ -162,11 +162,14 @@ __global__ void k_raster_setup(const float* __restrict__ pos, int Vn, const int3
 #define RNW (RNT / 64)
 // One workgroup per (view, 64x64 tile).  The faces whose bounding box touches the tile are compacted into an LDS list
 // (ballot + per-wave counts, four faces per thread and step); every wave then takes faces off the list: the face's setup record
-// is wave-uniform, its edge functions at the clipped bounding box's corner are three exact FMAs on the record, and the box is
-// covered in 8x8 lane blocks, stepping the edge functions by additions and depth-testing with 64-bit LDS atomicMin on the same
-// (z-order, face) key as the fallback path.  Measured on 8 views x 9 800 faces x 512^2 (100 us): binning + clear + write-out 23 us,
-// the f64 division per covered pixel 17 us, the LDS atomics 8 us; the rest is the per-face loop itself.  A staging pass that re-derived tile-local records from the snapped integer vertices, 256 faces
-// at a time behind two barriers, was no faster (101 us).
+// is wave-uniform (scalar loads), its biased edge functions at the clipped bounding box's corner are three exact FMAs on the
+// record, and the box is covered in 8x8 lane blocks, stepping the edge functions by additions, testing coverage on their sign
+// bits and depth-testing with 64-bit LDS atomicMin on the same (z-order, face) key as the fallback path.
+// Measured on 8 views x 9 800 faces x 512^2 (100 k face-tile pairs, 256 k lane blocks; 64 us): clear + binning + write-out 12 us,
+// the record loads 13 us, the rest is VALU work whose slowest CU (two tiles: up to 2.6x the mean tile) sets the time.
+// History: 98 us with one resident tile per CU (106 SGPRs) and the tile as the fastest grid index; 71 us with two tiles per CU
+// and the view as the fastest index; 66 us with the sign-bit coverage test; 64 us with the reciprocal depth.  A staging pass that
+// re-derived tile-local records from the snapped integer vertices, 256 faces at a time behind two barriers, was no faster.
 __global__ __launch_bounds__(RNT, RWPE) void k_raster_tiles(const FaceSetup* __restrict__ setup, const short4* __restrict__ bbox, int F, int V,
                                                        int R, uint8_t* __restrict__ hard, int64_t* __restrict__ fid,
                                                        float* __restrict__ depth) {

@@ -10,6 +10,9 @@ from . import _lib
 from ._lib import ptr, as_u8, stream, check
 
 
+_EYES = {}
+
+
 def hidden_point_removal(points, eye_positions, radius, already_valid=None, return_stats=False):
     """points [N,3] (GPU), eye_positions [V,3] (numpy / list, as create_cameras returns them) -> [V,N] bool.
     already_valid [V,N] bool (optional): points another test accepted; they are not queried and the result is the OR.
@@ -19,9 +22,15 @@ def hidden_point_removal(points, eye_positions, radius, already_valid=None, retu
     pts = points.detach().float().contiguous()
     if not pts.is_cuda:
         raise _lib.PdhipError("hidden_point_removal needs a GPU tensor; there is no CPU path")
-    eyes = torch.as_tensor(np.asarray(eye_positions, np.float64), dtype=torch.float64).reshape(-1, 3).to(pts.device).contiguous()
+    eyes_h = np.ascontiguousarray(np.asarray(eye_positions, np.float64).reshape(-1, 3))
+    key = (eyes_h.tobytes(), str(pts.device))
+    eyes = _EYES.get(key)                                             # (the camera set is fixed for a run: one upload, not one per shape)
+    if eyes is None:
+        if len(_EYES) > 64:
+            _EYES.clear()
+        eyes = _EYES[key] = torch.from_numpy(eyes_h).to(pts.device).contiguous()
     V, N = eyes.shape[0], pts.shape[0]
-    vis = torch.zeros((V, N), dtype=torch.bool, device=pts.device)
+    vis = torch.empty((V, N), dtype=torch.bool, device=pts.device)   # (every verdict is written by the kernels)
     ws = torch.empty((L.pdhip_hpr_ws_bytes(V, N),), dtype=torch.uint8, device=pts.device)
     skip = None if already_valid is None else as_u8(already_valid.contiguous())
     check(L.pdhip_hidden_point_removal(ptr(pts), N, ptr(eyes), V, float(radius), ptr(skip, allow_none=True), ptr(as_u8(vis)), ptr(ws),

@@ -32,7 +32,7 @@ def crop_params(V, dev, uv_centers, uv_scales, padding, inpaint_scale_factors):
         if torch.is_tensor(x):
             x = x.to(dev).float().reshape(-1)
             return (x.expand(n) if x.numel() == 1 else x.reshape(n)).contiguous()
-        return torch.full((n,), float(x), device=dev)
+        return _lib.const_vec(n, x, dev)
     if torch.is_tensor(uv_centers) and uv_centers.numel() == 2 * V:
         uvc = uv_centers.to(dev).float().reshape(V, 2).contiguous()
     else:
@@ -63,7 +63,7 @@ def get_rendered_hard_mask_and_face_idx_batch(cams, vertices, faces, points, glc
     dev = _dev(vertices)
     vertices = vertices.float().contiguous()
     points = points.float().contiguous()
-    faces32 = faces.to(torch.int32).contiguous()
+    faces32 = _lib.memo(faces, 'int32', lambda f: f.to(torch.int32).contiguous())
     V, Vn, N, F = len(cams), vertices.shape[0], points.shape[0], faces32.shape[0]
     R = int(cams[0].height)
     cp = stack_params(cams)

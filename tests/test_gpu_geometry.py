@@ -465,6 +465,29 @@ def test_p3b_skip_mask_gives_the_or(pd):
     assert bool(allv.all())
 
 
+def test_p3b_writes_every_verdict_into_a_dirty_buffer(pd):
+    """The verdict array need not be cleared by the caller: the C entry on a buffer full of 0xAA gives the wrapper's result, with and
+    without a skip mask, for a two-level (30 k points) and a one-level (3 k points) cloud."""
+    import ctypes as C
+    from pointdreamer_amd import hpr, _lib
+    L = _lib.lib()
+    _, _, eyes, _ = pd['cu'].create_cameras(4, 1.6, 512, device=DEV)
+    eyes_d = torch.from_numpy(np.asarray(eyes, np.float64).reshape(-1, 3)).to(DEV).contiguous()
+    for n in (30000, 3000):
+        pts, _ = pd['syn'].sphere_points(n, seed=3)
+        p = T(pts).float().contiguous()
+        pre = torch.from_numpy(np.random.default_rng(2).uniform(0, 1, (4, n)) > 0.6).to(DEV)
+        for skip in (None, pre):
+            want = hpr.hidden_point_removal(p, eyes, 100, already_valid=skip)
+            vis = torch.full((4, n), 0xAA, dtype=torch.uint8, device=DEV)
+            ws = torch.full((L.pdhip_hpr_ws_bytes(4, n),), 0x55, dtype=torch.uint8, device=DEV)
+            sk = None if skip is None else _lib.as_u8(skip.contiguous())
+            rc = L.pdhip_hidden_point_removal(_lib.ptr(p), n, _lib.ptr(eyes_d), 4, 100.0, _lib.ptr(sk, allow_none=True), _lib.ptr(vis),
+                                              _lib.ptr(ws), _lib.stream())
+            assert rc == 0
+            assert torch.equal(vis, _lib.as_u8(want)), (n, skip is not None, int((vis != _lib.as_u8(want)).sum()))
+
+
 def test_uv_atlas_producer_vs_oracle(pd):
     """rasterise the UV triangles + interpolate world positions (extract_texture_map.py:48-64)."""
     from pointdreamer_amd import extract_texture_map as etm
