@@ -201,7 +201,7 @@ __global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts
                            double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/,
                            unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/,
                            const uint8_t* __restrict__ skip, int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis,
-                           int collect) {
+                           int collect, float4* __restrict__ f32pts /*[V][N] (x, y, z, 0) rounded to f32, or null*/) {
     // open3d PointCloud::HiddenPointRemoval: p' = q + 2 (radius - |q|) q / |q| evaluated as q + ((2 (radius - n)) q) / n
     // Also here: the queries that still need the hull test -- all points, or only those a cheaper test (`skip`) has not already
     // accepted (those are marked visible) -- compacted into `list` with one returning atomic per 256-thread block and step.
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts
             double* f = flipped + (size_t)v * 3 * N;
             const double x = qx + (k * qx) / n, y = qy + (k * qy) / n, z = qz + (k * qz) / n;
             f[i] = x; f[N + i] = y; f[2 * (size_t)N + i] = z;
+            if (f32pts != nullptr) f32pts[(size_t)v * N + i] = make_float4((float)x, (float)y, (float)z, 0.0f);
             m = fmax(m, fmax(fabs(x), fmax(fabs(y), fabs(z))));
             b[0] = fmax(b[0], -x); b[1] = fmax(b[1], -y); b[2] = fmax(b[2], -z); b[3] = fmax(b[3], x); b[4] = fmax(b[4], y); b[5] = fmax(b[5], z);
         }
@@ -1367,23 +1368,32 @@ __global__ __launch_bounds__(256) void k_hpr_boxes(const double* __restrict__ ss
 // ---- coarse set: the extreme point of the flipped cloud in each of KC Fibonacci-sphere directions, without repeats.  Any set of
 // cloud points serves level 1 (its only verdict is certified on the points themselves, and its members are queried like every
 // other point), so this is the same approximate f32 GEMM + column maximum as the level-1 scan: A = 32 points, B = 64 of the
-// directions, a wave keeps the best tile per lane and locates the row afterwards.  The cloud is cut into HPR_EXT_POINTS-point
-// slabs (one wave per slab and 64 directions); the slabs meet in an atomicMax on (value, index) keys.
+// directions, a wave keeps the best tile per lane and locates the row afterwards.  The cloud is cut into at most HPR_EXT_SLABS slabs
+// of >= HPR_EXT_POINTS points (one wave per slab and 64 directions); every slab stores its (value, index) keys and k_hpr_extremes_fin
+// takes the maximum over the slabs.  The points are read from an (x, y, z, 0) f32 copy of the flipped cloud that k_hpr_flip writes:
+// the row search touches 32 scattered points per lane, and from the three f64 planes that was 96 separate cache lines per lane --
+// 19 us of the texture addresser's time per shape (41 -> 24 us; slabs of 512 / 1024 / 2048 points: 36 / 26 / 24 us -- a wave's
+// fixed costs, the row search first, outweigh the shorter scan).
 #ifndef HPR_EXT_POINTS
 #define HPR_EXT_POINTS 2048
 #endif
+#ifndef HPR_EXT_SLABS
+#define HPR_EXT_SLABS 64
+#endif
+static int ext_slab_points(int N) {                                       // multiple of 128 (a trip of the scan)
+    const int per = (N + HPR_EXT_SLABS - 1) / HPR_EXT_SLABS;
+    return ((per > HPR_EXT_POINTS ? per : HPR_EXT_POINTS) + 127) / 128 * 128;
+}
 __device__ __forceinline__ unsigned int f32_key(float x) { const unsigned int b = __float_as_uint(x); return (b >> 31) ? ~b : (b | 0x80000000u); }
-__global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__ flipped, int N, const double* __restrict__ fdir /*[KC][4]*/,
-                                                      unsigned long long* __restrict__ keys /*[V][KC], zeroed*/) {
+__global__ __launch_bounds__(256) void k_hpr_extremes(const float4* __restrict__ f32pts /*[V][N]*/, int N, const double* __restrict__ fdir /*[KC][4]*/,
+                                                      int slab_points, unsigned long long* __restrict__ keys /*[slabs][V][KC]*/) {
     const int v = blockIdx.z, lane = threadIdx.x & 63, l31 = lane & 31;
     const bool hi = lane >= 32;
     const int grp = blockIdx.y * 4 + (threadIdx.x >> 6);                  // 64 directions
-    const int p_lo = blockIdx.x * HPR_EXT_POINTS, p_hi = min(N, p_lo + HPR_EXT_POINTS);
+    const int p_lo = blockIdx.x * slab_points, p_hi = min(N, p_lo + slab_points);
     if (grp * 64 >= HPR_KC || p_lo >= N) return;
-    const double* fx = flipped + (size_t)v * 3 * N;
-    const double* fy = fx + N;
-    const double* fz = fy + N;
-    const int k0 = grp * 64 + l31, k1 = k0 + 32;                           // the lane's two directions (query columns l31 and 32 + l31)
+    const float4* fp = f32pts + (size_t)v * N;                            // (one 16-byte load per point: the f64 planes cost three
+    const int k0 = grp * 64 + l31, k1 = k0 + 32;                           // scattered lines per point in the row search below)
     const float x0 = (float)fdir[4 * k0], y0 = (float)fdir[4 * k0 + 1], z0 = (float)fdir[4 * k0 + 2];
     const float x1 = (float)fdir[4 * k1], y1 = (float)fdir[4 * k1 + 1], z1 = (float)fdir[4 * k1 + 2];
     // split-f16 operands as in k_hpr_coarse: A (lanes 0-31 | 32-63) = [xh yh zh xh yh zh xl yl | zl 0 ...], B = [dxh dyh dzh dxl dyl dzl dxh dyh | dzh 0 ...]
@@ -1399,16 +1409,12 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
     const f32x16 zero = {0};
     float best0 = -3.0e38f, best1 = -3.0e38f;
     int t0 = 0, t1 = 0;
-    // operands are requested two trips (128 points) ahead: a trip is a fraction of a microsecond of work against an L2 round trip of 1-2 us
-    double rx[2][2], ry[2][2], rz[2][2];
+    // operands are requested two tiles-of-64 (one trip of 128 points) ahead
+    float4 rp[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int j = min(p_lo + 64 * u + 32 * h + l31, N - 1);        // (a repeated point cannot change a maximum)
-            rz[u][h] = fz[j];
-            if (!hi) { rx[u][h] = fx[j]; ry[u][h] = fy[j]; } else { rx[u][h] = 0.0; ry[u][h] = 0.0; }
-        }
+        for (int h = 0; h < 2; ++h) rp[u][h] = fp[min(p_lo + 64 * u + 32 * h + l31, N - 1)];     // (a repeated point cannot change a maximum)
     for (int jo = p_lo; jo < p_hi; jo += 128) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {                                     // two tiles per trip
@@ -1416,13 +1422,11 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
             f16x8 ap[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float x = (float)rx[u][h], y = (float)ry[u][h], z = (float)rz[u][h];
+                const float x = rp[u][h].x, y = rp[u][h].y, z = rp[u][h].z;
                 const _Float16 xh = (_Float16)x, yh = (_Float16)y, zh = (_Float16)z;
                 const _Float16 xl = (_Float16)(x - (float)xh), yl = (_Float16)(y - (float)yh), zl = (_Float16)(z - (float)zh);
                 ap[h] = hi ? f16x8{zl, 0, 0, 0, 0, 0, 0, 0} : f16x8{xh, yh, zh, xh, yh, zh, xl, yl};
-                const int j = min(j0 + 128 + 32 * h + l31, N - 1);
-                rz[u][h] = fz[j];
-                if (!hi) { rx[u][h] = fx[j]; ry[u][h] = fy[j]; }
+                rp[u][h] = fp[min(j0 + 128 + 32 * h + l31, N - 1)];
             }
             const f32x16 A0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[0], bq0, zero, 0, 0, 0), A1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[0], bq1, zero, 0, 0, 0);
             const f32x16 B0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[1], bq0, zero, 0, 0, 0), B1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ap[1], bq1, zero, 0, 0, 0);
@@ -1441,35 +1445,42 @@ __global__ __launch_bounds__(256) void k_hpr_extremes(const double* __restrict__
         for (int i = 0; i < 16; ++i) {
             const int row = 8 * (i / 4) + (i % 4) + (hi ? 4 : 0);
             const int ja = min(t0 + row, N - 1), jb = min(t1 + row, N - 1);
-            const float w0 = fmaf((float)fz[ja], z0, fmaf((float)fy[ja], y0, (float)fx[ja] * x0));
-            const float w1 = fmaf((float)fz[jb], z1, fmaf((float)fy[jb], y1, (float)fx[jb] * x1));
+            const float4 pa = fp[ja], pb = fp[jb];
+            const float w0 = fmaf(pa.z, z0, fmaf(pa.y, y0, pa.x * x0));
+            const float w1 = fmaf(pb.z, z1, fmaf(pb.y, y1, pb.x * x1));
             if (w0 > r0) { r0 = w0; i0 = ja; }
             if (w1 > r1) { r1 = w1; i1 = jb; }
         }
     }
-    // both half-waves hold a candidate for the same two directions: join them, then one atomic per direction joins the slabs (same-key
-    // atomics are what this kernel waits for at the end; ties: the smaller index)
+    // both half-waves hold a candidate for the same two directions: join them (ties: the smaller index), then one key per direction
     {
         const float ob0 = __shfl_xor(best0, 32), ob1 = __shfl_xor(best1, 32);
         const int oi0 = __shfl_xor(i0, 32), oi1 = __shfl_xor(i1, 32);
         if (ob0 > best0 || (ob0 == best0 && oi0 >= 0 && (i0 < 0 || oi0 < i0))) { best0 = ob0; i0 = oi0; }
         if (ob1 > best1 || (ob1 == best1 && oi1 >= 0 && (i1 < 0 || oi1 < i1))) { best1 = ob1; i1 = oi1; }
     }
-    unsigned long long* kv = keys + (size_t)v * HPR_KC + grp * 64;
+    unsigned long long* kv = keys + ((size_t)blockIdx.x * gridDim.z + v) * HPR_KC + grp * 64;
     const float bq = hi ? best1 : best0;
     const int iq = hi ? i1 : i0;
-    if (iq >= 0) atomicMax(&kv[lane], ((unsigned long long)f32_key(bq) << 32) | (unsigned int)(0x7fffffff - iq));
+    kv[lane] = iq >= 0 ? ((unsigned long long)f32_key(bq) << 32) | (unsigned int)(0x7fffffff - iq) : 0ull;
 }
 // The hull is that of the cloud AND the eye (the origin of the flipped space): in a direction where every point has a negative
 // projection the eye is the extreme element and no point is taken (the GJK step supplies the eye itself, support value 0).
 // A point joins the coarse set the first time a direction finds it (many directions share their extreme point).
-__global__ void k_hpr_extremes_fin(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ keys,
+__global__ void k_hpr_extremes_fin(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ keys, int slabs,
                                    float4* __restrict__ csf, double* __restrict__ csd /*[V][KC][4]: the same points in f64*/,
                                    int* __restrict__ cidx, int* __restrict__ kcount, int* __restrict__ claim /*[V][N], zeroed*/,
                                    int* __restrict__ mdir /*[V][N], zeroed: 1 + the direction that found the point*/) {
     const int v = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= HPR_KC) return;
-    const unsigned long long key = keys[(size_t)v * HPR_KC + k];
+    unsigned long long key = 0ull;                                        // maximum over the slabs: largest value, then smallest index
+    for (int sl = 0; sl < slabs; sl += 8) {
+        unsigned long long kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kk[u] = keys[((size_t)min(sl + u, slabs - 1) * gridDim.y + v) * HPR_KC + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) key = kk[u] > key ? kk[u] : key;
+    }
     const unsigned int vb = (unsigned int)(key >> 32);
     const int id = 0x7fffffff - (int)(unsigned int)(key & 0xffffffffu);
     if (vb <= 0x80000000u || id < 0 || id >= N) return;                   // no point with a positive projection
@@ -1492,7 +1503,7 @@ static size_t hist_bytes(int V) { return a256((size_t)V * HPR_NCELL * sizeof(int
 // maxabs u64[64] at 1024, bounding-box keys u64[64][6] at 2048, six per-view counters int[64] at 5120
 #define HPR_HEAD_BYTES 8192
 extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
-    return HPR_HEAD_BYTES + 3 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)V * HPR_KC * sizeof(unsigned long long)) +
+    return HPR_HEAD_BYTES + 3 * flipped_bytes(V, N) + 16 * lists_bytes(V, N) + a256((size_t)V * N) + a256((size_t)V * HPR_KC * sizeof(float4)) + a256((size_t)V * HPR_KC * 4 * sizeof(double)) + a256((size_t)HPR_EXT_SLABS * V * HPR_KC * sizeof(unsigned long long)) + a256((size_t)V * (size_t)(N > 0 ? N : 1) * sizeof(float4)) +
            a256((size_t)V * HPR_KC * sizeof(int)) + boxes_bytes(V, N) + hist_bytes(V) + a256((size_t)HPR_KC * 4 * sizeof(double)) +
            a256((size_t)V * HPR_GRID * HPR_GRID * sizeof(unsigned long long));
 }
@@ -1515,7 +1526,6 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     int* hist = reinterpret_cast<int*>(p); p += hist_bytes(V);
     uint8_t* outside = reinterpret_cast<uint8_t*>(p); p += a256((size_t)V * N);
     float4* csf = reinterpret_cast<float4*>(p); p += a256((size_t)V * HPR_KC * sizeof(float4));      // (entries past the set's end: the eye)
-    unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_KC * sizeof(unsigned long long));
     int* pos_of = reinterpret_cast<int*>(p); p += lists_bytes(V, N);   // (the extremes' claim flags until the scatter fills it)
     int* mdir = reinterpret_cast<int*>(p); p += lists_bytes(V, N);
     unsigned long long* sgrid = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)V * HPR_GRID * HPR_GRID * sizeof(unsigned long long));
@@ -1535,17 +1545,20 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     float4* boxes = reinterpret_cast<float4*>(p); p += boxes_bytes(V, N);
     double* fdir = reinterpret_cast<double*>(p); p += a256((size_t)HPR_KC * 4 * sizeof(double));
     double* qdir = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
+    unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)HPR_EXT_SLABS * V * HPR_KC * sizeof(unsigned long long));   // [slab][V][KC]
+    float4* f32pts = reinterpret_cast<float4*>(p); p += a256((size_t)V * (size_t)(N > 0 ? N : 1) * sizeof(float4));
     dim3 gf(min(cdiv(N, 256), 256), V);
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
     k_hpr_flip<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>
-       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility, two_level ? 0 : 1);      // (one level: + marks the skipped points visible; `list` = the queries)
+       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility, two_level ? 0 : 1, two_level ? f32pts : nullptr);      // (one level: + marks the skipped points visible; `list` = the queries)
     constexpr int KC = HPR_KC;
     if (two_level) {
         k_hpr_grid<<<gf, 256, 0, s>>>(flipped, N, bbox, sgrid, fdir);
         k_hpr_shield<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, bbox, sgrid, skip, count, list, visibility, counters);
-        k_hpr_extremes<<<dim3(cdiv(N, HPR_EXT_POINTS), KC / 256, V), 256, 0, s>>>(flipped, N, fdir, ekeys);
-        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, csf, csd, cidx, kcount, pos_of, mdir);
+        const int slab_points = ext_slab_points(N), slabs = cdiv(N, slab_points);
+        k_hpr_extremes<<<dim3(slabs, KC / 256, V), 256, 0, s>>>(f32pts, N, fdir, slab_points, ekeys);
+        k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, slabs, csf, csd, cidx, kcount, pos_of, mdir);
         k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, visibility, maxabs, qdir);
     }
     k_hpr_bin<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
