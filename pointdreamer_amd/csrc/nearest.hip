@@ -40,20 +40,45 @@ __global__ void k_nearest_cols(const void* __restrict__ mask, int64_t mask_bstri
     if (c >= W) return;
     int32_t* nr = near_row + (size_t)b * H * W;
     const size_t base = (size_t)b * mask_bstride;
-    int last = -1, next = -1;                  // carries: nearest site above this segment / below this segment
-    for (int t = s - 1; t >= 0 && last < 0; --t) last = seg_last[((size_t)b * nseg + t) * W + c];
-    for (int t = s + 1; t < nseg && next < 0; ++t) next = seg_first[((size_t)b * nseg + t) * W + c];
-    const int r0 = s * SEG, r1 = min(H, (s + 1) * SEG);
-    for (int r = r0; r < r1; ++r) {            // nearest site at or above
-        if (is_site<F32MASK>(mask, base, (size_t)r * W + c)) last = r;
-        nr[(size_t)r * W + c] = last;
+    // carries: nearest site above this segment / below this segment.  Rows grow with the segment index, so the carries are a
+    // maximum / minimum over the other segments' summaries: eight independent loads per step instead of a dependent chain
+    int last = -1, next = 0x7fffffff;
+    for (int t0 = s - 1; t0 >= 0; t0 -= 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = seg_last[((size_t)b * nseg + max(t0 - u, 0)) * W + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) last = max(last, v[u]);
+        if (!__any(last < 0)) break;
     }
-    for (int r = r1 - 1; r >= r0; --r) {       // merge with nearest site at or below; ties -> up (smaller row)
-        if (is_site<F32MASK>(mask, base, (size_t)r * W + c)) next = r;
-        int up = nr[(size_t)r * W + c];
-        int pick = up;
-        if (next >= 0 && (up < 0 || (next - r) < (r - up))) pick = next;
-        nr[(size_t)r * W + c] = pick;
+    for (int t0 = s + 1; t0 < nseg; t0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = seg_first[((size_t)b * nseg + min(t0 + u, nseg - 1)) * W + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) next = min(next, v[u] >= 0 ? v[u] : 0x7fffffff);
+        if (!__any(next == 0x7fffffff)) break;
+    }
+    if (next == 0x7fffffff) next = -1;
+    const int r0 = s * SEG;
+    // the segment's mask column in registers: every load and every store of the segment is independent of the others (the two
+    // sweeps used to go through near_row in memory, a store -> load round trip per row)
+    bool site[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) site[k] = r0 + k < H && is_site<F32MASK>(mask, base, (size_t)(r0 + k) * W + c);
+    int up[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; ++k) {            // nearest site at or above
+        if (site[k]) last = r0 + k;
+        up[k] = last;
+    }
+#pragma unroll
+    for (int k = SEG - 1; k >= 0; --k) {       // merge with nearest site at or below; ties -> up (smaller row)
+        const int r = r0 + k;
+        if (site[k]) next = r;
+        int pick = up[k];
+        if (next >= 0 && (up[k] < 0 || (next - r) < (r - up[k]))) pick = next;
+        if (r < H) nr[(size_t)r * W + c] = pick;
     }
 }
 

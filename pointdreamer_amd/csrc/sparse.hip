@@ -76,7 +76,21 @@ __global__ void k_sparse_counts(const uint8_t* __restrict__ hard, const uint8_t*
     } else {
         for (int i = threadIdx.x; i < rr; i += blockDim.x) fg += hard[hb + i] ? 1 : 0;
     }
-    for (int i = threadIdx.x; i < N; i += blockDim.x) va += valid[(size_t)v * N + i] ? 1 : 0;
+    {   // the validation bytes, 16 per load where the view's row allows it (30 byte loads in a row per thread were most of this kernel)
+        const uint8_t* vb = valid + (size_t)v * N;
+        const int head = min(N, (int)((16 - (reinterpret_cast<uintptr_t>(vb) & 15)) & 15));
+        const int groups = (N - head) / 16;
+        const uint4* v4 = reinterpret_cast<const uint4*>(vb + head);
+        for (int i = threadIdx.x; i < groups; i += blockDim.x) {
+            const uint4 q = v4[i];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                va += ((w[k] & 0xffu) != 0) + ((w[k] & 0xff00u) != 0) + ((w[k] & 0xff0000u) != 0) + ((w[k] & 0xff000000u) != 0);
+        }
+        for (int i = threadIdx.x; i < head; i += blockDim.x) va += vb[i] ? 1 : 0;
+        for (int i = head + groups * 16 + threadIdx.x; i < N; i += blockDim.x) va += vb[i] ? 1 : 0;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { fg += __shfl_xor(fg, off); va += __shfl_xor(va, off); }
     if ((threadIdx.x & 63) == 0) { s_fg[threadIdx.x >> 6] = fg; s_va[threadIdx.x >> 6] = va; }
