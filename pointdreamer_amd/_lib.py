@@ -139,10 +139,20 @@ def memo(src, tag, fn):
         if all(r() is t for r, t in zip(refs, items)) and vers == tuple(t._version for t in items):
             return val
     val = fn(src)
+    _settle(val)
     if len(_MEMO) > 256:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()                 # (an evicted value may still be in use on another stream)
         _MEMO.clear()
     _MEMO[key] = (tuple(_weakref.ref(t) for t in items), tuple(t._version for t in items), val)
     return val
+
+
+def _settle(val):
+    """A cached value is handed to whichever HIP stream asks next (pipeline.colorize_meshes_batched runs shapes on streams of their
+    own): finish computing it before it enters the cache.  Once per new entry."""
+    if torch.is_tensor(val) and val.is_cuda:
+        torch.cuda.current_stream(val.device).synchronize()
 
 
 _CONST = {}
@@ -154,5 +164,6 @@ def const_vec(n, value, dev):
     v = _CONST.get(key)
     if v is None:
         v = _CONST[key] = torch.full((int(n),), float(value), device=dev)
+        _settle(v)
     return v
 

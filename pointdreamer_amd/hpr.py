@@ -29,6 +29,7 @@ def hidden_point_removal(points, eye_positions, radius, already_valid=None, retu
         if len(_EYES) > 64:
             _EYES.clear()
         eyes = _EYES[key] = torch.from_numpy(eyes_h).to(pts.device).contiguous()
+        _lib._settle(eyes)
     V, N = eyes.shape[0], pts.shape[0]
     vis = torch.empty((V, N), dtype=torch.bool, device=pts.device)   # (every verdict is written by the kernels)
     ws = torch.empty((L.pdhip_hpr_ws_bytes(V, N),), dtype=torch.uint8, device=pts.device)

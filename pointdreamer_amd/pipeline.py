@@ -107,11 +107,22 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
     return vertices, xatlas_dict.get('uvs'), faces, xatlas_dict.get('mesh_tex_idx'), atlas, xatlas_dict['mask']
 
 
+_STREAMS = {}
+
+
+def _shape_streams(dev, n):
+    key = str(dev)
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpainter=None, texture_gen_method='DDNM_inpaint',
                             point_size=1, edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82,
                             edge_dilate_kernels=(21,), point_validation_by_o3d=True, hidden_point_removal_radius=100,
                             complete_unseen_by='unproject', optimize_from=None, save_img_paths=None, return_full=False,
-                            refine_point_validation_by_remove_abnormal_depth=False, **unused):
+                            refine_point_validation_by_remove_abnormal_depth=False, concurrent=True, **unused):
     """Several independent shapes in one pass (BASELINE configs[4]: a batch of shapes per GPU): the projection / sparse-image
     stage runs per shape, the views of ALL shapes go through the inpainter together (one UNet batch of len(shapes) * V views --
     the 8x8 .. 32x32 levels of the UNet fill the chip better), unprojection / completion / optimisation run per shape.
@@ -123,20 +134,55 @@ def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpaint
     for sh in shapes:
         _check_options(sh['xatlas'], refine_point_validation_by_remove_abnormal_depth, complete_unseen_by, optimize_from)
     paths = list(save_img_paths) if save_img_paths is not None else [None] * len(shapes)
+    # The per-shape stages of different shapes are independent and mostly latency-bound (a few hundred wavefronts per kernel): each
+    # shape's stages are queued on a HIP stream of its own so that the GPU overlaps them; the inpainter runs on the caller's stream.
+    dev = shapes[0]['coords'].device
+    use_streams = concurrent and len(shapes) > 1 and dev.type == 'cuda'
+    main = torch.cuda.current_stream(dev) if use_streams else None
+    streams = _shape_streams(dev, len(shapes)) if use_streams else [None] * len(shapes)
+
+    def on_stream(st, fn):
+        if st is None:
+            return fn()
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            return fn()
+
+    def back_to_main(st, value):              # results of a side stream: the caller's stream waits, the allocator learns the new user
+        if st is None:
+            return
+        main.wait_stream(st)
+        for t in (value.values() if isinstance(value, dict) else (value if isinstance(value, (tuple, list)) else (value,))):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+
     with torch.no_grad():
-        pres = [_before_inpaint(sh['coords'], sh['colors'], sh['vertices'], sh['faces'], camera_info, view_num, res, cam_res, pth,
-                                point_validation_by_o3d, hidden_point_removal_radius, point_size, edge_point_size, crop_img,
-                                crop_padding, mask_ratio_thresh) for sh, pth in zip(shapes, paths)]
+        pres = [on_stream(st, lambda sh=sh, pth=pth: _before_inpaint(
+                    sh['coords'], sh['colors'], sh['vertices'], sh['faces'], camera_info, view_num, res, cam_res, pth,
+                    point_validation_by_o3d, hidden_point_removal_radius, point_size, edge_point_size, crop_img, crop_padding,
+                    mask_ratio_thresh)) for sh, pth, st in zip(shapes, paths, streams)]
+        for st, pr in zip(streams, pres):
+            back_to_main(st, pr)
         cat = lambda k: torch.cat([pr[k] for pr in pres], 0).contiguous()
         inpainted = ou.get_inpainted_images(cat('sparse'), cat('mask0'), cat('mask2'), None, inpainter, view_num * len(shapes),
                                             method=texture_gen_method)
-        outs = []
-        for i, (sh, pr, pth) in enumerate(zip(shapes, pres, paths)):
+        outs, atlases = [], []
+        for i, (sh, pr, pth, st) in enumerate(zip(shapes, pres, paths, streams)):
             inp = inpainted[i * view_num:(i + 1) * view_num].contiguous()
             if pth is not None:
                 ou.save_inpainted_images(inp, pr['mask0'], pth, view_num, texture_gen_method)
-            atlas, _ = _after_inpaint(pr, inp, sh['vertices'], sh['faces'], sh['f_normals'], sh['xatlas'], camera_info, res,
-                                      cam_res, edge_dilate_kernels, complete_unseen_by, optimize_from, None, pth)
+            atlas = on_stream(st, lambda sh=sh, pr=pr, pth=pth, inp=inp: _after_inpaint(
+                pr, inp, sh['vertices'], sh['faces'], sh['f_normals'], sh['xatlas'], camera_info, res, cam_res, edge_dilate_kernels,
+                complete_unseen_by, optimize_from, None, pth)[0])
+            if st is not None:
+                inp.record_stream(st)
+                for t in pr.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(st)
+            atlases.append(atlas)
+        for st, atlas in zip(streams, atlases):
+            back_to_main(st, atlas)
+        for sh, atlas in zip(shapes, atlases):
             xat = sh['xatlas']
             outs.append((sh['vertices'], xat.get('uvs'), sh['faces'], xat.get('mesh_tex_idx'), atlas, xat['mask']) if return_full
                         else atlas)
