@@ -92,7 +92,8 @@ int pdhip_point_visibility(int cam_res, const float* point_uvs /*[V,N,2]*/, cons
 
 /* ---- P3b: ours_utils.get_point_validation_by_o3d (ours_utils.py:204-225), i.e. Open3D hidden_point_removal:
  *      spherical flip about each eye + convex-hull vertex test, all V views in one call, float64 on the device.
- *      eyes: V*3 float64 (device).  ws: pdhip_hpr_ws_bytes(V, N) bytes.  visibility[V,N] u8.
+ *      eyes: V*3 float64 (device).  ws: pdhip_hpr_ws_bytes(V, N) bytes.  visibility[V,N] u8, written in full (it need
+ *      not be cleared by the caller).
  *      skip (may be NULL): [V,N] u8; points already accepted by another test (demo.py:110 ORs the depth test with
  *      this one) are not queried and come back as 1, so the result is directly the OR-ed validation.
  *      Every verdict carries a floating-point certificate (separating direction / enclosing tetrahedron with error
