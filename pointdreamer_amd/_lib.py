@@ -85,7 +85,19 @@ def check(rc, what):
         raise PdhipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
+# (the host needs ~10 us per kernel launch on this path; torch's python wrappers around "current device" / "current stream" were
+# a quarter of it, so the raw bindings are used where this torch build has them)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _current_device():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
 def stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -107,7 +119,7 @@ def ptr(t, dtype=None, allow_none=False):
     if not t.is_cuda:
         raise PdhipError("pointdreamer_amd needs tensors on the GPU (cuda:N == HIP device); got a CPU tensor. "
                          "There is no CPU path.")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _current_device():
         raise PdhipError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: call "
                          "torch.cuda.set_device / use `with torch.cuda.device(...)` around pointdreamer_amd calls")
     if not t.is_contiguous():
