@@ -197,6 +197,29 @@ def test_i0_nearest_vs_oracle_and_reference(pd, name):
     assert np.array_equal(N_(single), out[0])
 
 
+@pytest.mark.parametrize("H,W", [(37, 70), (16, 64), (17, 65), (130, 33), (5, 3)])
+def test_i0_nearest_ragged_sizes_vs_oracle(pd, H, W):
+    """Nearest fill at sizes that are not multiples of the 16-row segment / the 64-column wavefront: sparse sites, empty columns
+    and rows, one image with a single site; uint8 and float masks, CHW and HWC layouts -- bit-identical to the oracle."""
+    rng = np.random.default_rng(H * 131 + W)
+    B = 3
+    img = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
+    sites = rng.uniform(0, 1, (B, H, W)) > 0.93
+    sites[0, :, : W // 2] = False                                   # empty left half
+    sites[0, H // 2, W - 1] = True
+    sites[1] = False
+    sites[1, H - 1, 0] = True                                        # a single site in a corner
+    sites[2, : H // 3] = False                                       # empty top rows
+    sites[2, H - 1, W // 2] = True
+    want = np.stack([img[b][:, rr, cc] for b in range(B) for rr, cc in [oinp.nearest_site_index(sites[b])]])
+    got = pd['ou'].nearest_fill(T(img), T(sites), 'CHW')
+    assert np.array_equal(N_(got), want)
+    got = pd['ou'].nearest_fill(T(img), T(sites.astype(np.float32)), 'CHW')
+    assert np.array_equal(N_(got), want)
+    got = pd['ou'].nearest_fill(T(np.ascontiguousarray(img.transpose(0, 2, 3, 1))), T(sites), 'HWC')
+    assert np.array_equal(N_(got), want.transpose(0, 2, 3, 1))
+
+
 def test_i0_nearest_full_size_properties(pd):
     rng = np.random.default_rng(7)
     B, H = 8, 256
