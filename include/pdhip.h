@@ -110,6 +110,10 @@ int pdhip_hpr_read_counters(const void* ws, int V, long long* out /*[4]*/, void*
 /* ---- demo.py:121-125: point_pixels = clip(long(uv*res)) as (row,col). */
 int pdhip_point_pixels(const float* point_uvs /*[V,N,2]*/, int V, int N, int res,
                        int64_t* point_pixels /*[V,N,2]*/, void* stream);
+/* both of the above in one pass over the points: the depth test at cam_res and the (row, col) pixels at res. */
+int pdhip_point_visibility_pixels(int cam_res, const float* point_uvs, const float* point_depths, const float* mesh_depths,
+                                  int V, int N, float offset, uint8_t* visibility /*[V,N]*/, int res,
+                                  int64_t* point_pixels /*[V,N,2]*/, void* stream);
 
 /* ---- P4-P6: ours_utils.get_sparse_images -> get_one_sparse_img -> paint_pixels /
  *      get_forground_inner_edge_mask (ours_utils.py:848-882, 954-1044, 456-532), all V views.

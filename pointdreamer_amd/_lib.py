@@ -33,6 +33,7 @@ _SIGS = {
     'pdhip_hidden_point_removal': (C.c_int, [vp, i32, vp, i32, f64, vp, vp, vp, vp]),
     'pdhip_hpr_read_counters': (C.c_int, [vp, i32, vp, vp]),
     'pdhip_point_pixels': (C.c_int, [vp, i32, i32, i32, vp, vp]),
+    'pdhip_point_visibility_pixels': (C.c_int, [i32, vp, vp, vp, i32, i32, f32, vp, i32, vp, vp]),
     'pdhip_sparse_views_ws_bytes': (sz, [i32, i32, i32]),
     'pdhip_sparse_views': (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
     'pdhip_nearest_fill_ws_ints': (sz, [i32, i32, i32]),

@@ -12,5 +12,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace pdhip
 
-extern "C" int pdhip_version(void) { return 201; }
+extern "C" int pdhip_version(void) { return 202; }
 extern "C" const char* pdhip_last_error(void) { return pdhip::g_err; }

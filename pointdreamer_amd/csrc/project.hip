@@ -8,7 +8,7 @@ using namespace pdhip;
 // ---------------------------------------------------------------------------------------------
 // P1 pass A: transform mesh vertices for every view, write pos = (x,y,z,1), reduce xy min/max.
 __global__ void k_project_verts(const float* __restrict__ cams, const float* __restrict__ verts, int Vn,
-                                float* __restrict__ pos, uint32_t* __restrict__ minmax) {
+                                float* __restrict__ pos, uint32_t* __restrict__ minmax, int single) {
     const int v = blockIdx.y;
     const Cam c = load_cam(cams + 16 * v);
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
@@ -27,7 +27,7 @@ __global__ void k_project_verts(const float* __restrict__ cams, const float* __r
         mny = fminf(mny, __shfl_xor(mny, off)); mxy = fmaxf(mxy, __shfl_xor(mxy, off));
     }
     // one set of atomics per block (same-address atomics cost ~0.2 us each: per wave they were most of this kernel's 17 us)
-    __shared__ float s_mm[4][4];
+    __shared__ float s_mm[16][4];
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s_mm[wave][0] = mnx; s_mm[wave][1] = mny; s_mm[wave][2] = mxx; s_mm[wave][3] = mxy; }
     __syncthreads();
@@ -35,7 +35,8 @@ __global__ void k_project_verts(const float* __restrict__ cams, const float* __r
         const int k = threadIdx.x, nw = (blockDim.x + 63) >> 6;
         float r = s_mm[0][k];
         for (int w = 1; w < nw; ++w) r = k < 2 ? fminf(r, s_mm[w][k]) : fmaxf(r, s_mm[w][k]);
-        if (k < 2) atomicMin(&minmax[4 * v + k], f2ord(r)); else atomicMax(&minmax[4 * v + k], f2ord(r));
+        if (single) minmax[4 * v + k] = f2ord(r);          // one workgroup per view: its extrema are the view's (no init pass, no atomics)
+        else if (k < 2) atomicMin(&minmax[4 * v + k], f2ord(r)); else atomicMax(&minmax[4 * v + k], f2ord(r));
     }
 }
 
@@ -109,9 +110,13 @@ extern "C" int pdhip_project_points(const float* cam_params, int V, const float*
                "pdhip_project_points: null pointer");
     PD_REQUIRE(!rescale || (uv_centers && uv_scales), "pdhip_project_points: rescale needs uv_centers/uv_scales");
     hipStream_t s = as_stream(stream);
-    k_init_minmax<<<cdiv(4 * V, 64), 64, 0, s>>>(minmax_ws, V);
-    dim3 ga(min(cdiv(Vn, 256), 64), V);
-    k_project_verts<<<ga, 256, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws);
+    if (Vn <= 65536) {                                     // one 1024-lane workgroup per view reduces its own extrema
+        k_project_verts<<<dim3(1, V), 1024, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws, 1);
+    } else {
+        k_init_minmax<<<cdiv(4 * V, 64), 64, 0, s>>>(minmax_ws, V);
+        dim3 ga(min(cdiv(Vn, 256), 64), V);
+        k_project_verts<<<ga, 256, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws, 0);
+    }
     dim3 gb(min(cdiv(Vn + N, 256), 256), V);
     const float pad9 = (float)(1.0 - 2.0 * padding);
     k_project_finish<<<gb, 256, 0, s>>>(cam_params, minmax_ws, points, N, Vn, rescale, pad9, pos, vertice_uvs,
@@ -149,6 +154,40 @@ extern "C" int pdhip_point_visibility(int cam_res, const float* point_uvs, const
     dim3 g(min(cdiv(N, 256), 1024), V);
     k_point_visibility<<<g, 256, 0, as_stream(stream)>>>(cam_res, point_uvs, point_depths, mesh_depths, N, offset,
                                                         visibility, point_pixels);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
+// P3 + demo.py:121-125 in one pass over the points (the pipeline's pair: the depth test at cam_res, the pixel coordinates at res)
+__global__ void k_point_visibility_pixels(int R, const float* __restrict__ uvs, const float* __restrict__ dep,
+                                          const float* __restrict__ mesh, int N, float offset, uint8_t* __restrict__ vis, int res,
+                                          int64_t* __restrict__ pix) {
+    const int v = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const float2 uv = reinterpret_cast<const float2*>(uvs)[(size_t)v * N + i];
+        const int col = clip_to_int(uv.x * (float)R, R - 1);
+        const int row = clip_to_int(uv.y * (float)R, R - 1);
+        const float ref = mesh[((size_t)v * R + row) * R + col];
+        const float d = dep[(size_t)v * N + i];
+        vis[(size_t)v * N + i] = ((d - ref) <= offset) ? 1 : 0;
+        const float a = fminf(fmaxf(uv.x * (float)res, -1.0e9f), 1.0e9f);
+        const float b = fminf(fmaxf(uv.y * (float)res, -1.0e9f), 1.0e9f);
+        longlong2 o;
+        o.x = min(max((int)b, 0), res - 1);                      // (row, col)
+        o.y = min(max((int)a, 0), res - 1);
+        reinterpret_cast<longlong2*>(pix)[(size_t)v * N + i] = o;
+    }
+}
+
+extern "C" int pdhip_point_visibility_pixels(int cam_res, const float* point_uvs, const float* point_depths,
+                                             const float* mesh_depths, int V, int N, float offset, uint8_t* visibility,
+                                             int res, int64_t* point_pixels, void* stream) {
+    PD_REQUIRE(V > 0 && N >= 0 && cam_res > 0 && res > 0, "pdhip_point_visibility_pixels: bad sizes");
+    if (N == 0) return PDHIP_OK;
+    PD_REQUIRE(point_uvs && point_depths && mesh_depths && visibility && point_pixels, "pdhip_point_visibility_pixels: null pointer");
+    dim3 g(min(cdiv(N, 256), 1024), V);
+    k_point_visibility_pixels<<<g, 256, 0, as_stream(stream)>>>(cam_res, point_uvs, point_depths, mesh_depths, N, offset,
+                                                               visibility, res, point_pixels);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -113,6 +113,21 @@ def get_point_validation_by_depth(cam_res, point_uvs, point_depths, mesh_depths,
     return visb, pix
 
 
+def get_point_validation_and_pixels(cam_res, point_uvs, point_depths, mesh_depths, res, offset=0):
+    """get_point_validation_by_depth (its visibility) and get_point_pixels(point_uvs, res) in one pass over the points."""
+    L = _lib.lib()
+    dev = _dev(point_uvs)
+    point_uvs = point_uvs.float().contiguous()
+    point_depths = point_depths.float().contiguous()
+    mesh_depths = mesh_depths.float().contiguous()
+    V, N = point_depths.shape
+    visb = torch.empty((V, N), dtype=torch.bool, device=dev)
+    pix = torch.empty((V, N, 2), dtype=torch.int64, device=dev)
+    check(L.pdhip_point_visibility_pixels(int(cam_res), ptr(point_uvs), ptr(point_depths), ptr(mesh_depths), V, N, float(offset),
+                                          ptr(as_u8(visb)), int(res), ptr(pix), stream()), 'pdhip_point_visibility_pixels')
+    return visb, pix
+
+
 def get_point_pixels(point_uvs, res):
     """demo.py:121-125."""
     L = _lib.lib()

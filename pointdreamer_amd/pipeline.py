@@ -35,13 +35,12 @@ def _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res,
                                                      padding=crop_padding)
     if cam_res != res:
         hard_masks = ou.resize_masks(hard_masks, res)
-    point_validation, _ = ou.get_point_validation_by_depth(cam_res, point_uvs, point_depths, mesh_depths, offset=0.0001)
+    point_validation, point_pixels = ou.get_point_validation_and_pixels(cam_res, point_uvs, point_depths, mesh_depths, res, offset=0.0001)
     if point_validation_by_o3d:
         from .hpr import hidden_point_removal
         # demo.py:108-110 ORs the two tests: only points the depth test rejected need the hull query
         point_validation = hidden_point_removal(coords, camera_info['eye_positions'], hidden_point_removal_radius,
                                                 already_valid=point_validation)
-    point_pixels = ou.get_point_pixels(point_uvs, res)
     sparse_imgs, hard_mask0s, hard_mask2s, scale_factors = ou.get_sparse_images(
         point_pixels, colors, point_validation, hard_masks, save_img_path, view_num, res, point_size,
         edge_point_size, mask_ratio_thresh, view_offset=view_offset)

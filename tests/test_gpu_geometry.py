@@ -91,6 +91,21 @@ def test_p1_p2_project_and_raster_vs_oracle(pd, n_points, stacks, slices, V, R):
     assert out2[4] == 0 and out2[5] == 2 and out2[6] == 0
 
 
+def test_p3_fused_visibility_and_pixels_equal_the_two_entries(pd):
+    """pdhip_point_visibility_pixels = pdhip_point_visibility (its verdicts) + pdhip_point_pixels, bit for bit, incl. out-of-range uvs."""
+    rng = np.random.default_rng(4)
+    V, N, R, res = 3, 5003, 128, 64
+    uvs = rng.uniform(-0.2, 1.2, (V, N, 2)).astype(np.float32)
+    uvs[0, :5] = [[0, 0], [1, 1], [np.nan, 0.5], [np.inf, -np.inf], [0.999999, 1e-8]]
+    dep = rng.uniform(-1, 1, (V, N)).astype(np.float32)
+    mesh = rng.uniform(-1, 1, (V, R, R)).astype(np.float32)
+    ou = pd['ou']
+    v1, _ = ou.get_point_validation_by_depth(R, T(uvs), T(dep), T(mesh), offset=0.0001)
+    p1 = ou.get_point_pixels(T(uvs), res)
+    v2, p2 = ou.get_point_validation_and_pixels(R, T(uvs), T(dep), T(mesh), res, offset=0.0001)
+    assert torch.equal(v1, v2) and torch.equal(p1, p2)
+
+
 def hostile_triangles():
     rng = np.random.default_rng(11)
     c = rng.uniform(-1.1, 1.1, (100, 1, 2))
