@@ -36,9 +36,9 @@ us, pr = timed(lambda: ou.get_rendered_hard_mask_and_face_idx_batch(cams, g['ver
 hard, fidx, depth, vuv, uvc, uvs, pad, puv, pdep = pr
 add('P1+P2 project + raster (8 views)', us, V * (41 * N - 5 * N + F * 36 + R * R * 9))
 us, hard_r = timed(lambda: ou.resize_masks(hard, r)); add('P2b mask 512->256', us, V * (R * R + r * r))
-us, pv = timed(lambda: ou.get_point_validation_by_depth(R, puv, pdep, depth, 0.0001)); add('P3 depth visibility', us, V * N * 17)
+us, pv = timed(lambda: ou.get_point_validation_and_pixels(R, puv, pdep, depth, r, 0.0001)); add('P3 depth visibility + pixel coordinates (one pass, as the pipeline calls it)', us, V * N * (17 + 16))
 us, pv2 = timed(lambda: hpr.hidden_point_removal(g['points'], eyes, 100, already_valid=pv[0]), 5); add('P3b hidden-point removal (certified GJK: grid shield, split-f16 MFMA coarse level, f64 working-set level)', us, V * N * 24)
-pp = ou.get_point_pixels(puv, r)
+pp = pv[1]
 us, sp = timed(lambda: ou.get_sparse_images(pp, g['colors'], pv2, hard_r, None, V, r, 1, 1, 0.82)); add('P4-P6 sparse views', us, V * r * r * 20)
 sparse, m0, m2, sf = sp
 us, inp = timed(lambda: ou.get_inpainted_images(sparse, m0, m2, None, None, V, method='nearest')); add('I0 nearest inpaint', us, V * r * r * 28)
