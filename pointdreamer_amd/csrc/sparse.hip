@@ -164,13 +164,13 @@ __global__ void k_sparse_mask(const uint8_t* __restrict__ hard, int res, const V
 }
 
 // P5: splat valid points (write index -> atomicMax), remember the (rescaled) pixel of every point
-__global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* __restrict__ valid, int N, int res,
+__device__ __forceinline__ void sparse_splat_body(int bx, int nbx, const int64_t* __restrict__ pix, const uint8_t* __restrict__ valid, int N, int res,
                                int point_size, const ViewParams* __restrict__ params, uint32_t* __restrict__ winA,
                                int32_t* __restrict__ pp, uint32_t* __restrict__ minidx) {
     const int v = blockIdx.y;
     const ViewParams p = params[v];
     const int g = 2 * point_size - 1;
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    for (int n = bx * blockDim.x + threadIdx.x; n < N; n += nbx * blockDim.x) {
         size_t o = (size_t)v * N + n;
         int packed = -1;
         if (valid[o] && !p.degenerate) {
@@ -206,12 +206,12 @@ __global__ void k_sparse_splat(const int64_t* __restrict__ pix, const uint8_t* _
 // atomic per image row).  P6b then gives every edge pixel a wavefront of its own: with one workgroup per row the rows tangent to
 // the silhouette (up to ~100 edge pixels) were the whole kernel time (38 us).
 #define EDGE_BAND 8             // image rows per workgroup: ONE returning atomic per band (same-address atomics cost ~0.1-0.2 us each)
-__global__ __launch_bounds__(1024) void k_sparse_edge_list(const uint8_t* __restrict__ mask_new, int res, const ViewParams* __restrict__ params,
-                                                           uint32_t* __restrict__ edge_cnt, int32_t* __restrict__ edge_list) {
-    const int v = blockIdx.y, row0 = blockIdx.x * EDGE_BAND;
+__device__ __forceinline__ void sparse_edge_list_body(int band, int* s_wcnt, int& s_base, const uint8_t* __restrict__ mask_new, int res,
+                                                      const ViewParams* __restrict__ params, uint32_t* __restrict__ edge_cnt,
+                                                      int32_t* __restrict__ edge_list) {
+    const int v = blockIdx.y, row0 = band * EDGE_BAND;
     const ViewParams p = params[v];
     if (p.degenerate) return;
-    __shared__ int s_wcnt[16], s_base;
     const uint8_t* m = mask_new + (size_t)v * res * res;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int npix = min(EDGE_BAND, res - row0) * res;
@@ -254,6 +254,18 @@ __global__ __launch_bounds__(1024) void k_sparse_edge_list(const uint8_t* __rest
             __syncthreads();
         }
     }
+}
+
+// P5 splat (over the points) and P6a edge list (over the pixels) do not depend on each other: one launch, the first `splat_blocks`
+// workgroups of a view splat, the others take an 8-row band each (a launch boundary and the shorter kernel's time less per shape)
+__global__ __launch_bounds__(1024) void k_sparse_splat_edge_list(int splat_blocks, const int64_t* __restrict__ pix, const uint8_t* __restrict__ valid,
+                                                                 int N, int res, int point_size, const ViewParams* __restrict__ params,
+                                                                 uint32_t* __restrict__ winA, int32_t* __restrict__ pp, uint32_t* __restrict__ minidx,
+                                                                 const uint8_t* __restrict__ mask_new, uint32_t* __restrict__ edge_cnt,
+                                                                 int32_t* __restrict__ edge_list) {
+    __shared__ int s_wcnt[16], s_base;
+    if ((int)blockIdx.x < splat_blocks) sparse_splat_body(blockIdx.x, splat_blocks, pix, valid, N, res, point_size, params, winA, pp, minidx);
+    else sparse_edge_list_body(blockIdx.x - splat_blocks, s_wcnt, s_base, mask_new, res, params, edge_cnt, edge_list);
 }
 
 __global__ void k_sparse_edges(const int32_t* __restrict__ edge_list, const uint32_t* __restrict__ edge_cnt, int res, int edge_point_size,
@@ -366,9 +378,9 @@ extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colo
     dim3 gm(min(cdiv((long long)res * res, 256), 256), V);
     k_sparse_mask<<<gm, 256, 0, s>>>(hard_masks, res, w.params, w.mask_new, w.winA, w.winB, w.minidx, w.edge_cnt);
     if (N > 0) {
-        dim3 gs(min(cdiv(N, 256), 256), V);
-        k_sparse_splat<<<gs, 256, 0, s>>>(point_pixels, validation, N, res, point_size, w.params, w.winA, w.pp, w.minidx);
-        k_sparse_edge_list<<<dim3(cdiv(res, EDGE_BAND), V), 1024, 0, s>>>(w.mask_new, res, w.params, w.edge_cnt, w.edge_list);
+        const int splat_blocks = min(cdiv(N, 1024), 64);
+        k_sparse_splat_edge_list<<<dim3(splat_blocks + cdiv(res, EDGE_BAND), V), 1024, 0, s>>>(
+            splat_blocks, point_pixels, validation, N, res, point_size, w.params, w.winA, w.pp, w.minidx, w.mask_new, w.edge_cnt, w.edge_list);
         k_sparse_edges<<<dim3(256, V), 256, 0, s>>>(w.edge_list, w.edge_cnt, res, edge_point_size, w.params, w.minidx, w.winB, w.nn_idx);
     }
     k_sparse_compose<<<gm, 256, 0, s>>>(colors, res, point_size, edge_point_size, w.params, w.mask_new, w.winA, w.winB,
