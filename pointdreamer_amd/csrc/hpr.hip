@@ -747,7 +747,12 @@ __device__ __forceinline__ bool closest_with_newest(const d3 a, d3& W0, d3& W1, 
     n = 1 + (b0 ? 1 : 0) + (b1 ? 1 : 0) + (b2 ? 1 : 0);
     return true;
 }
-__global__ __launch_bounds__(256) void k_hpr_fine_dist(const double* __restrict__ flipped, int N, const int* __restrict__ count,
+// (lab: waves per SIMD the allocation must admit.  128 VGPRs = 4 waves; 5 waves = 96 VGPRs + 148 B of scratch: 122 instead of 105 us,
+// 6 waves = 80 VGPRs + 280 B: 286 us)
+#ifndef HPR_FINE_WPE
+#define HPR_FINE_WPE 1
+#endif
+__global__ __launch_bounds__(256, HPR_FINE_WPE) void k_hpr_fine_dist(const double* __restrict__ flipped, int N, const int* __restrict__ count,
                                                        const int* __restrict__ list, uint8_t* __restrict__ vis, const double* __restrict__ ss,
                                                        const int* __restrict__ sidx_all, const int* __restrict__ scount,
                                                        const float4* __restrict__ boxes_all, const int* __restrict__ pos_of,
