@@ -3,6 +3,9 @@ events, and achieved GB/s against the algorithmic byte counts of SURVEY 8(d).  U
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from pointdreamer_amd import _lib as _l
+if os.environ.get('PDHIP_LAB_LIB'):                      # lab builds: PDHIP_LAB_LIB=path/to/lab.so python tools/time_stages.py
+    _l.LIB_PATH = os.path.abspath(os.environ['PDHIP_LAB_LIB'])
 from pointdreamer_amd import synthetic, hpr
 import pointdreamer_amd.ours_utils as ou, pointdreamer_amd.unproject as up, pointdreamer_amd.camera_utils as cu
 from pointdreamer_amd import optimize as popt
