@@ -263,6 +263,7 @@ int pdhip_gn_silu_conv3x3_nhwc_f16(const void* x, const float* gamma, const floa
 int pdhip_debug_conv3x3_apply(const void* x, const float* table /*[N][Cin/8][16]*/, const void* w_packed, const float* bias, const void* residual,
                               void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, const void* zero_page, void* stream);   /* tuning hook */
 int pdhip_debug_set_fold_resample(int on);   /* 1 (default): the resampled x branch of up / down ResBlocks is folded into its consumers; 0: k_resample passes */
+int pdhip_debug_set_fold_finalize(int max_batch);   /* largest UNet batch at which GroupNorm-apply reduces the conv epilogues' statistics partials itself (no k_gn_finalize_oct launch); default 4, 0 = never */
 int pdhip_debug_set_fuse_gn(int on);   /* 1: the UNet uses the fused form wherever the halo kernel serves a conv; 0 (default, measured faster): stand-alone passes */
 /* ---- complete_unseen_by='neighbor' (pointdreamer/unproject.py:93-196, demo.py:180-200).
  * The mesh subdivision stays on the host (as in the reference); these are the per-texel / per-vertex kernels. */

@@ -156,9 +156,11 @@ __global__ __launch_bounds__(256, 2) void k_linear_tri(const float* __restrict__
                 double px = -aby, py = abx;                                          // perpendicular to ab, turned towards q
                 const double t = px * (q.x - pb.x) + py * (q.y - pb.y);
                 if (t < 0.0) { px = -px; py = -py; }
-                if (t == 0.0) {                                                      // q ON segment ab: interpolate along it
-                    ic = ib; pc = pb; state = 1; continue;
-                }
+                // t == 0: q lies strictly inside segment ab (sv > 0 put b beyond q), but a and b are far-apart EXTREME sites, not
+                // Delaunay neighbours -- never interpolate along ab.  Keep either perpendicular: a site strictly on that side closes a
+                // triangle with q on its edge ab (the containment tests are inclusive) and phase 1 pivots to the Delaunay triangle;
+                // no site on that side (sv == 0 next round) makes line ab a supporting line of the hull: k_linear_boundary takes the
+                // nearest site on either side of q along it -- which is also the answer when ALL sites are collinear.
                 A = px; B = py; dim = 2; continue;
             }
             pc = p; ic = j;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_tri(const float* __restrict__
         A = -Nx; B = -Ny; Cc = -Nz; K = (Nx * pa.x + Ny * pa.y) + Nz * ar;
     }
     if (!owner) return;
-    if (state == 0) { atomicAdd(unresolved, 1); state = 2; }
+    if (state == 0) { atomicAdd(unresolved, 1); state = phase == 1 ? 1 : 2; }   // round cap: phase 1 holds a triangle that contains q (valid, not Delaunay)
     if (state == 4) {                                     // on the hull boundary: finished by k_linear_boundary
         const int k = atomicAdd(bcount, 1);
         blist[3 * k] = b * n + qi; blist[3 * k + 1] = (int)A; blist[3 * k + 2] = (int)B;

@@ -27,7 +27,7 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
 extern thread_local int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
-extern thread_local int g_fuse_gn, g_fold_resample;                                                   // tuning hook (nn_unet.hip)
+extern thread_local int g_fuse_gn, g_fold_resample, g_fold_finalize;                                                   // tuning hook (nn_unet.hip)
 extern thread_local float* g_dbg_splitk_ws; extern thread_local size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
@@ -46,10 +46,14 @@ int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB,
 int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, float* ws, size_t ws_floats, hipStream_t s);
 // y = silu?( GN(x)*gamma+beta [*(1+scale)+shift] ), optional 2x resample; RESAMPLE: 0 none, 1 avgpool2, 2 nearest-up2.
 // film: rows of (scale[C] | shift[C]) f32, row n at film + n*film_stride, or null.  Output f16 NHWC (or f32 when out_f32).
+// parts != NULL (stats == NULL): the statistics are reduced inside the apply kernel from the producing convs' octet partials
+// (what gn_finalize_oct would read) -- the small-batch form, one launch less per GroupNorm
+struct GnPartsArg { const float* partA; int Ca, chunksA; const float* partB; int Cb, chunksB; float eps; };
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
              const half_t* XB = nullptr, int Ca = 0,      // XB: second tensor of a never-materialised channel concat
-             half_t* Yraw = nullptr);                     // resample 1 only: also AvgPool2d(2) of the RAW input (the x branch of a down-ResBlock)
+             half_t* Yraw = nullptr,                      // resample 1 only: also AvgPool2d(2) of the RAW input (the x branch of a down-ResBlock)
+             const GnPartsArg* parts = nullptr);
 // GroupNorm (+ FiLM) as one affine map per (image, channel): table [N][C/8][16] = (A0..A7, B0..B7) per channel octet, y = silu(A x + B) -- the
 // input transform of the APPLY variant of the halo conv (the stand-alone gn_apply pass disappears)
 int gn_table(const float* stats, const float* gamma, const float* beta, const float* film, long long film_stride, int N, int C,

@@ -174,15 +174,49 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // registers for the whole chunk; consecutive threads touch consecutive 16-byte octets (full 128-B lines).
 // RES: 0 none, 1 avgpool2 (of activated values), 2 nearest-up2.
 #define GNA_ITERS 32
-template <int RES, bool OUT_F32, bool FILM>
+// The statistics come either finished (stats [N][32][2], FIN = false) or as the producing convs' octet partials (GnParts, FIN = true):
+// at small batches every workgroup re-reduces its image's few hundred partials itself (L2-resident, f64, fixed order) and the
+// k_gn_finalize_oct launch -- 94 per forward, 5 us each at batch 1 -- disappears.
+struct GnParts { const float* a; const float* b; int Ca, Cb, chunksA, chunksB; float eps; };
+template <int RES, bool OUT_F32, bool FILM, bool FIN>
 __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ film, long long film_stride, int H, int W,
                                                   int C, int silu, void* __restrict__ Yv, const half_t* __restrict__ XB, int Ca, int iters,
-                                                  half_t* __restrict__ Yraw) {
+                                                  half_t* __restrict__ Yraw, GnParts gp) {
     const int opp = C >> 3, cg = C / 32;
     const int pps = max(1, 256 / opp);
     const int Ho = RES == 1 ? H / 2 : (RES == 2 ? H * 2 : H), Wo = RES == 1 ? W / 2 : (RES == 2 ? W * 2 : W);
+    __shared__ double s_fin[FIN ? 512 : 1];
+    __shared__ float s_st[FIN ? 64 : 1];
+    if (FIN) {
+        // thread (slot, octet) sums chunks slot, slot + pps, ... of its octet; thread g < 32 then combines its group's octets
+        // over the slots in a fixed order (host guarantees opp <= 256 and a group size that is a multiple of 8 channels)
+        const int img = blockIdx.y, fs = threadIdx.x / opp, fo = threadIdx.x - fs * opp;
+        if (fs < pps) {
+            const int oa = gp.Ca >> 3;
+            const bool inA = fo < oa;
+            const int chunks = inA ? gp.chunksA : gp.chunksB, os = inA ? oa : (gp.Cb >> 3);
+            const float2* src = reinterpret_cast<const float2*>(inA ? gp.a : gp.b) + (size_t)img * chunks * os + (inA ? fo : fo - oa);
+            double ds = 0.0, dq = 0.0;
+#pragma unroll 8
+            for (int c = fs; c < chunks; c += pps) { const float2 v = src[(size_t)c * os]; ds += (double)v.x; dq += (double)v.y; }
+            s_fin[(fs * opp + fo) * 2] = ds; s_fin[(fs * opp + fo) * 2 + 1] = dq;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int opg = cg >> 3, g = threadIdx.x;
+            double ds = 0.0, dq = 0.0;
+            for (int k = 0; k < opg; ++k)
+                for (int sl = 0; sl < pps; ++sl) { ds += s_fin[(sl * opp + g * opg + k) * 2]; dq += s_fin[(sl * opp + g * opg + k) * 2 + 1]; }
+            const double cnt = (double)H * W * cg;
+            const double mean = ds / cnt;
+            double var = dq / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_st[2 * g] = (float)mean; s_st[2 * g + 1] = (float)(1.0 / sqrt(var + (double)gp.eps));
+        }
+        __syncthreads();
+    }
     // (lab: descending image / chunk order so that the pass starts on what the producing conv wrote last and ends on what the
     // consuming conv reads first -- measured 1 % slower per DDNM step than the plain order; PD_LAB_GN_REV)
 #ifdef PD_LAB_GN_REV
@@ -203,7 +237,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c0 + e, grp = c / cg;
-            const float mean = stats[((size_t)n * 32 + grp) * 2], rstd = stats[((size_t)n * 32 + grp) * 2 + 1];
+            const float mean = FIN ? s_st[2 * grp] : stats[((size_t)n * 32 + grp) * 2], rstd = FIN ? s_st[2 * grp + 1] : stats[((size_t)n * 32 + grp) * 2 + 1];
             ga[e] = rstd * gamma[c];
             gb[e] = beta[c] - mean * ga[e];
             if (FILM) {
@@ -310,7 +344,14 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
 
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
-             const half_t* XB, int Ca, half_t* Yraw) {
+             const half_t* XB, int Ca, half_t* Yraw, const GnPartsArg* parts) {
+    GnParts gp{nullptr, nullptr, 0, 0, 0, 0, 0.f};
+    if (parts != nullptr) {
+        PD_REQUIRE(stats == nullptr && parts->partA != nullptr && (C >> 3) <= 256 && ((C / 32) % 8) == 0 && parts->Ca + parts->Cb == C &&
+                   parts->Ca % 8 == 0 && parts->Cb % 8 == 0 && (parts->Cb == 0 || parts->partB != nullptr),
+                   "gn_apply: bad octet partials for the in-kernel statistics");
+        gp = GnParts{parts->partA, parts->partB, parts->Ca, parts->Cb, parts->chunksA, parts->chunksB, parts->eps};
+    }
     PD_REQUIRE(Yraw == nullptr || (resample == 1 && XB == nullptr), "gn_apply: the raw avg-pool output belongs to resample 1");
     PD_REQUIRE(XB == nullptr || (Ca > 0 && Ca < C && Ca % 8 == 0), "gn_apply: bad two-source split");
     PD_REQUIRE(C % 32 == 0 && resample >= 0 && resample <= 2, "gn_apply: bad arguments");
@@ -324,11 +365,15 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     int iters = GNA_ITERS;
     while (iters > 1 && (long long)cdiv((long long)Ho * Wo, pps * iters) * N < 2048) iters >>= 1;
     dim3 grid(cdiv((long long)Ho * Wo, pps * iters), N);
-    if (out_f32) k_gn_apply<0, true, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
-    else if (film) k_gn_apply<0, false, true><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
-    else if (resample == 0) k_gn_apply<0, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
-    else if (resample == 1) k_gn_apply<1, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
-    else k_gn_apply<2, false, false><<<grid, 256, 0, s>>>(X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw);
+#define GNA_ARGS X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw, gp
+#define GNA_LAUNCH(R, O, F) do { if (parts) k_gn_apply<R, O, F, true><<<grid, 256, 0, s>>>(GNA_ARGS); else k_gn_apply<R, O, F, false><<<grid, 256, 0, s>>>(GNA_ARGS); } while (0)
+    if (out_f32) GNA_LAUNCH(0, true, false);
+    else if (film) GNA_LAUNCH(0, false, true);
+    else if (resample == 0) GNA_LAUNCH(0, false, false);
+    else if (resample == 1) GNA_LAUNCH(1, false, false);
+    else GNA_LAUNCH(2, false, false);
+#undef GNA_LAUNCH
+#undef GNA_ARGS
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

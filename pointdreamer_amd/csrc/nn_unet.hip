@@ -38,6 +38,9 @@ namespace pdnn { thread_local int g_fuse_gn = 0; }
 // k_resample pass: AvgPool2d(2) of the raw input comes out of the GroupNorm-apply kernel that reads the same pixels anyway, the
 // nearest x2 copy is replaced by index arithmetic in the residual read of the consuming conv (unsplit halo layers)
 namespace pdnn { thread_local int g_fold_resample = 1; }
+// tuning / test hook (pdhip_debug_set_fold_finalize): largest batch at which GroupNorm-apply reduces the conv epilogues' octet
+// partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never)
+namespace pdnn { thread_local int g_fold_finalize = 4; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
@@ -210,6 +213,13 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
     out->p = arena_take(c.u, (size_t)c.N * out->H * out->W * x.C);
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
+    // small batches: the apply kernel reduces the octet partials itself (no k_gn_finalize_oct launch); large batches: every
+    // workgroup re-reducing its image's partials costs more than the 5 us launch it removes
+    if (x.gn_part != nullptr && ((x.C / 32) % 8) == 0 && (x.C >> 3) <= 256 && g_fold_finalize > 0 && c.N <= g_fold_finalize) {
+        const GnPartsArg pa{x.gn_part, x.Ca, x.gn_chunks, x.gn_partB, x.C - x.Ca, x.gn_chunksB, 1e-5f};
+        return gn_apply(x.p, nullptr, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2,
+                        x.p2 ? x.Ca : 0, raw_pool, &pa);
+    }
     PD_TRY(run_gn_stats(c, x));
     return gn_apply(x.p, c.u->stats, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2, x.p2 ? x.Ca : 0,
                     raw_pool);
@@ -773,6 +783,7 @@ extern "C" int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int sp
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }
+extern "C" int pdhip_debug_set_fold_finalize(int max_batch) { int old = pdnn::g_fold_finalize; pdnn::g_fold_finalize = max_batch; return old; }
 extern "C" int pdhip_debug_set_fuse_gn(int on) { int old = pdnn::g_fuse_gn; pdnn::g_fuse_gn = on; return old; }
 /* stand-alone: y = conv3x3( silu( GroupNorm32(x) [* (1 + scale) + shift] ) ) (+ residual) with the transform applied inside the
  * conv (halo-resident kernel; W in {32, 64, 128, 256}, H * W % 512 == 0, Cin % 32 == 0).  ws: N*64 + N*64*ceil(HW/256) + N*Cin*2 floats. */

@@ -20,10 +20,11 @@ def shard_range(n_items, rank, world):
     return range(start, start + q + (1 if rank < r else 0))
 
 
-def all_gather_views(local, n_views, rank, world, group=None):
+def all_gather_views(local, n_views, rank, world, group=None, force_collective=False):
     """local [v_local, ...] (this rank's block of views, in shard_range order) -> [n_views, ...] on every rank.
-    One all_gather; ragged blocks are padded to the largest block."""
-    if world == 1:
+    One all_gather; ragged blocks are padded to the largest block.  force_collective: run the collective at world size 1 too
+    (a one-rank RCCL group: exercises the exact device-tensor path of the multi-GPU run on a single GPU)."""
+    if world == 1 and not force_collective:
         return local
     vmax = (n_views + world - 1) // world
     pad = torch.zeros((vmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -101,13 +102,19 @@ def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, 
                                     point_size=1, edge_point_size=1, crop_img=True, crop_padding=0.05,
                                     mask_ratio_thresh=0.82, edge_dilate_kernels=(21,), point_validation_by_o3d=True,
                                     hidden_point_removal_radius=100, complete_unseen_by='unproject', optimize_from=None,
-                                    save_img_path=None, group=None, stages=None, shape_key=None, return_full=False, **unused):
+                                    save_img_path=None, group=None, stages=None, shape_key=None, return_full=False,
+                                    force_collective=False, **unused):
     """View-parallel demo.colorize_one_mesh: same keyword surface and defaults as pipeline.colorize_one_mesh, same atlas on
     every rank (bit-identical to the single-process result for the index / copy stages; for DDNM the noise of view k is keyed by
     its global index, so the result does not depend on `world` either).  shape_key: running index of the shape (noise key base
     = shape_key * view_num); default = the inpainter's own image counter, which every rank advances by view_num."""
     from . import pipeline as pl
     pl._check_options(xatlas_dict, False, complete_unseen_by, optimize_from)
+    if world > view_num:
+        # a rank without views would enter the per-view stages with V = 0 (the HIP entry points require V > 0) while the others
+        # block in the all_gather: refuse up front, on every rank alike
+        raise ValueError(f"view-parallel needs world size <= view_num (world {world}, view_num {view_num}): "
+                         f"use shape-parallel for the remaining GPUs")
     st = default_stages() if stages is None else stages
     mine = shard_range(view_num, rank, world)
     sl = slice(mine.start, mine.stop)
@@ -128,7 +135,7 @@ def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, 
         uvs = pre['uv_scales'] if torch.is_tensor(pre['uv_scales']) else torch.full((v, 1, 1), float(pre['uv_scales'] or 2.0), device=dev)
         sf = pre['scale_factors'] if torch.is_tensor(pre['scale_factors']) else torch.ones((v,), device=dev)
         rec = pack_view_records(local, vis_l, pk_l, uvc, uvs, sf)
-        rec = all_gather_views(rec, view_num, rank, world, group)                  # the one collective
+        rec = all_gather_views(rec, view_num, rank, world, group, force_collective)  # the one collective
         inpainted, vis, per_kernel, uvc_a, uvs_a, sf_a = unpack_view_records(rec, tuple(local.shape[1:]), A, K)
         pre_all = dict(uv_centers=uvc_a, uv_scales=uvs_a, padding=pre['padding'], scale_factors=sf_a, mesh_depths=None)
         atlas = st['after'](pre_all, inpainted, vis, per_kernel, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,

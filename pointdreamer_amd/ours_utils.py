@@ -219,13 +219,16 @@ def linear_fill(img, site_mask, return_triangles=False):
     tri = torch.empty((B, H, W, 3), dtype=torch.int32, device=dev) if return_triangles else None
     check(L.pdhip_linear_fill(ptr(img), ptr(out), B, Cn, H, W, ptr(site_mask), is_f32, H * W, ptr(ws), ptr(tri, allow_none=True),
                               stream()), 'pdhip_linear_fill')
-    if return_triangles:
-        n = C.c_int(0)
-        check(L.pdhip_linear_fill_unresolved(ptr(ws), B, H, W, C.byref(n), stream()), 'pdhip_linear_fill_unresolved')
-        if n.value:
+    # the round-cap counter is read on every path ('linear' is a synchronous, tens-of-milliseconds method: the 4-byte read is free);
+    # such pixels carry the interpolant of a containing, not necessarily Delaunay, triangle -- never a silent NaN
+    n = C.c_int(0)
+    check(L.pdhip_linear_fill_unresolved(ptr(ws), B, H, W, C.byref(n), stream()), 'pdhip_linear_fill_unresolved')
+    if n.value:
+        if return_triangles:
             raise _lib.PdhipError(f"linear_fill: {n.value} pixels hit the round cap")
-        return out, tri
-    return out
+        import warnings
+        warnings.warn(f"linear_fill: {n.value} pixels hit the round cap of the Delaunay search (interpolated in a containing triangle)")
+    return (out, tri) if return_triangles else out
 
 
 def naive_inpainting(img, no_need_inpaint_mask2, method='linear'):

@@ -110,3 +110,29 @@ def test_demo_directory_is_partitioned_over_ranks():
         parts = [demo.files_of_rank(files, r, w) for r in range(w)]
         assert sum(parts, []) == files
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_view_parallel_rejects_more_ranks_than_views():
+    """A rank without views would enter the per-view HIP stages with V = 0 while the others block in the all_gather: the driver
+    refuses world > view_num up front (no process group needed: the check precedes every stage and the collective)."""
+    sys.path.insert(0, ROOT)
+    from pointdreamer_amd import dist as pdist
+    xa = dict(gb_pos=torch.zeros((1, 4, 4, 3)), mask=torch.ones((1, 4, 4, 1), dtype=torch.bool), per_atlas_pixel_face_id=torch.zeros((1, 4, 4), dtype=torch.int64))
+    with pytest.raises(ValueError, match="world size <= view_num"):
+        pdist.colorize_one_mesh_view_parallel(None, None, None, None, None, xa, {}, view_num=2, res=4, cam_res=8, rank=2, world=3,
+                                              texture_gen_method='nearest', stages={})
+
+
+def test_all_gather_views_forced_collective_world1_gloo():
+    """force_collective runs the all_gather at world size 1 too (the GPU suite does the same through RCCL)."""
+    sys.path.insert(0, ROOT)
+    from pointdreamer_amd import dist as pdist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        rec = torch.arange(24, dtype=torch.uint8).view(3, 8)
+        out = pdist.all_gather_views(rec, 3, 0, 1, None, force_collective=True)
+        assert torch.equal(out, rec) and out.data_ptr() != rec.data_ptr()
+    finally:
+        dist.destroy_process_group()

@@ -787,6 +787,12 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case):
     frac = bad[~sites].mean() if (~sites).any() else 0.0
     if case != "ring_only":                                                 # (a bare square ring of sites is co-circular through and through)
         assert frac < 0.35, frac                                           # co-circular ambiguity only; most pixels agree outright
+    if sites[0].all() and sites[-1].all() and sites[:, 0].all() and sites[:, -1].all() and case != "ring_only":
+        # the image diagonals: pixels collinear with the two far-apart support sites phase 0 starts from (round-2 bug: lerp of the
+        # two corner sites).  Each must agree with scipy or sit in a valid Delaunay triangle (checked below for every `bad` pixel);
+        # a corner-to-corner segment can never be the answer when other sites exist
+        seg = (tri[..., 1] == tri[..., 2]) & (tri[..., 0] >= 0) & ~sites
+        assert seg.sum() == 0, int(seg.sum())                              # a full border of sites: no query on the hull boundary
     checked = 0
     for (y, x) in qs:
         t = tri[y, x]
@@ -796,9 +802,16 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case):
         if not bad[y, x] and case != "random64":
             continue                                                       # (random64: check EVERY pixel's triangle)
         assert (t >= 0).all()
-        if t[1] == t[2]:                                                   # on a segment between two sites
-            a, b = P[t[0]], P[t[1]]
-            assert (b[0] - a[0]) * (y - a[1]) == (b[1] - a[1]) * (x - a[0])
+        if t[1] == t[2]:                                                   # on a segment between two sites: only a HULL edge qualifies
+            a, b = P[t[0]].astype(np.int64), P[t[1]].astype(np.int64)
+            qv = np.array([x, y], np.int64)
+            assert (b[0] - a[0]) * (y - a[1]) == (b[1] - a[1]) * (x - a[0])            # q on line ab ...
+            assert ((qv - a) * (b - a)).sum() > 0 and ((qv - b) * (a - b)).sum() > 0   # ... strictly between a and b
+            side = (b[0] - a[0]) * (P[:, 1].astype(np.int64) - a[1]) - (b[1] - a[1]) * (P[:, 0].astype(np.int64) - a[0])
+            assert (side >= 0).all() or (side <= 0).all(), (case, y, x, t)            # ab supports the hull of the sites
+            on = side == 0
+            par = ((P[on].astype(np.int64) - a) * (b - a)).sum(1)
+            assert not ((par > 0) & (par < ((b - a) ** 2).sum())).any(), (case, y, x, t)   # no site strictly between: a hull EDGE
         else:
             assert oinp.delaunay_triangle_is_valid(P, t, (x, y)), (case, y, x, t)
         checked += 1

@@ -131,6 +131,96 @@ def gen_ddnm(name):
                         t=np.array([c['t'] for c in cos]), t_next=np.array([c['t_next'] for c in cos]))
 
 
+def _import_diffusion():
+    rh.install()
+    import importlib
+    cwd = os.getcwd()
+    os.chdir(rh.REF)
+    try:
+        sys.path.insert(0, os.path.join(rh.REF, 'models', 'DDNM'))
+        return importlib.import_module('models.DDNM.guided_diffusion.diffusion')
+    finally:
+        os.chdir(cwd)
+
+
+def ddnm_full_inputs(seed, n_img, steps, S=256):
+    """Inputs of the full-size D1 o U1 fixture, regenerated from the seed by the test (numpy PCG64 streams are stable across
+    numpy versions): masked images, masks, x_T and the per-step noise tape, image-major."""
+    rng = np.random.default_rng(seed)
+    imgs = rng.random((n_img, 3, S, S), dtype=np.float32)
+    masks = (rng.random((n_img, S, S), dtype=np.float32) > 0.6).astype(np.float32)
+    tape = rng.standard_normal((n_img, steps + 1, 3, S, S), dtype=np.float32)      # [:, 0] = x_T, [:, k + 1] = noise of step k
+    return imgs * masks[:, None], masks, tape
+
+
+def gen_ddnm_full(name, steps=10, n_img=2, seed=2024, stride=4):
+    """D1 o U1 at full size: the reference's own simplified_ddnm_inpainting (diffusion.py:459-570) driving the reference's own
+    fp32 UNetModel (552.8 M parameters, seeded weights) for the first `steps` of the 100-step schedule; the loop is cut after
+    `steps` updates by the model wrapper.  Stored: a strided sample of x_k after every update and the full x after the last."""
+    diffusion = _import_diffusion()
+    import yaml
+
+    class NS(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+        __setattr__ = dict.__setitem__
+
+    def to_ns(d):
+        return NS({k: to_ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+    config = to_ns(yaml.safe_load(open(os.path.join(rh.REF, 'models/DDNM/configs/imagenet_256.yml'))))
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, 12)
+    model = ref_unet(FULL, w)
+    masked, masks, tape = ddnm_full_inputs(seed, n_img, steps)
+    xs_all, final_all = [], []
+
+    class Cut(Exception):
+        pass
+    orig_to, orig_randn, orig_randn_like = torch.Tensor.to, torch.randn, torch.randn_like
+    for im in range(n_img):
+        args = NS(sigma_y=0, eta=0.85, seed=1234)
+        runner = diffusion.Diffusion(args, config, device=torch.device('cpu'))
+        pos = {'i': 0}
+        seen = []
+
+        def next_noise(*a, **k):
+            n = torch.from_numpy(tape[im, pos['i']][None].copy())
+            pos['i'] += 1
+            return n
+
+        def wrapped(x, t):
+            seen.append(x.detach().clone())               # the sampler's state entering this step = x after the previous update
+            if len(seen) == steps + 1:
+                raise Cut()
+            assert float(t[0]) == 990.0 - 10.0 * (len(seen) - 1)
+            with torch.no_grad():
+                return model(x, t)
+
+        def to(self, *a, **k):
+            if a and a[0] == 'cuda':
+                return self
+            return orig_to(self, *a, **k)
+        torch.Tensor.to, torch.randn, torch.randn_like = to, next_noise, next_noise
+        try:
+            runner.simplified_ddnm_inpainting(wrapped, torch.from_numpy(masked[im:im + 1]).unsqueeze(0), torch.from_numpy(masks[im:im + 1]))
+            raise AssertionError('the sampler was expected to be cut')
+        except Cut:
+            pass
+        finally:
+            torch.Tensor.to, torch.randn, torch.randn_like = orig_to, orig_randn, orig_randn_like
+        assert pos['i'] == steps + 1 and len(seen) == steps + 1
+        assert torch.equal(seen[0], torch.from_numpy(tape[im, 0][None]))
+        xs = torch.cat(seen[1:], 0).numpy()               # [steps, 3, S, S]: x after update k = 0 .. steps-1
+        print(name, 'image', im, 'x_k std', [round(float(v.std()), 4) for v in xs])
+        xs_all.append(xs[:, :, ::stride, ::stride].copy())
+        final_all.append(xs[-1].copy())
+    np.savez_compressed(os.path.join(OUT, name), seed=seed, steps=steps, n_img=n_img, stride=stride, weight_seed=12,
+                        xs=np.stack(xs_all), x_last=np.stack(final_all))
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -141,6 +231,8 @@ def main():
         gen_unet('unet_small.npz', SMALL, seed=11, batch=2, stride=1)
     if 'full' in which:
         gen_unet('unet_full.npz', FULL, seed=12, batch=1, stride=8)
+    if 'ddnm_full' in which:
+        gen_ddnm_full('ddnm_unet_full.npz')
 
 
 if __name__ == '__main__':
