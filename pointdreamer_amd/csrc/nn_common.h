@@ -36,6 +36,15 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
                const float* apply_table = nullptr,          // input = silu(A x + B) per gn_table (layers the halo kernel takes only)
                int res_up = 0,                              // residual = half-resolution tensor read with nearest x2 (unsplit halo layers only)
                int in_up = 0);                              // X = half-resolution tensor, input = its nearest x2 (halo layers only)
+// ---- small-M convolution with in-launch split-K combine (nn_conv_sk.hip).  ws: [0, 4096) ticket words (zero at allocation,
+// self-resetting), slabs behind them.  conv_sk_plan decides whether / how a layer runs there (bm == 0: not this kernel's layer).
+struct SkPlan { int bm, bn, splits, tile_id; };
+SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, bool two_source, size_t ws_floats);
+int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
+            int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* ws, size_t ws_floats, float* gn_part,
+            int* gn_fused, const half_t* X2, int Cin1);
+extern thread_local int g_sk_mode, g_sk_tile, g_sk_splits, g_sk_stages, g_sk_kg;                         // tuning / test hooks (pdhip_debug_set_conv_sk)
+#define PD_SK_TICKET_FLOATS 4096
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
 // the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).
 int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,

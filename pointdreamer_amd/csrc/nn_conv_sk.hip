@@ -26,19 +26,30 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 namespace {
 
 __device__ __forceinline__ void sk_glds16(const void* gsrc, void* lds_wave_base) {
+#ifndef PD_LAB_SK_NOGLDS                                   // (lab builds only: the loop without its L2 -> LDS traffic)
     __builtin_amdgcn_global_load_lds((sk_gbl_void*)gsrc, (sk_lds_void*)lds_wave_base, 16, 0, 0);
+#endif
 }
 __device__ __forceinline__ int sk_swz(int row) { return (row >> 1) & 7; }       // 128-byte rows: 16-byte slot ^= (row >> 1) & 7
 
+#ifdef PD_LAB_SK_STAMP                                      // (lab builds only: where one wave's loop time goes, s_memtime cycles)
+__device__ unsigned long long g_sk_stamps[8 * 64];
+#define SK_CLK() __builtin_readcyclecounter()
+#endif
 template <int N> __device__ __forceinline__ void sk_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// grid: total_tiles * splits workgroups (1-D).  tickets[tile] must be zero at launch; the last arriver of a tile resets it.
-template <int TAPS, int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
-                                                 const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int W, int Cin,
-                                                 int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
-                                                 float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
-                                                 const half_t* __restrict__ X2, int Cin1) {
+// grid: total_tiles * splits workgroups (1-D) of KG * 256 threads.  tickets[tile] must be zero at launch; the last arriver resets it.
+// KG "K-groups" of 4 waves share one output tile: group g runs K-steps it0 + g, it0 + g + KG, ... of the workgroup's K slice on its
+// own ring of NST LDS stages, the groups' accumulators are summed through LDS (fixed order) after the loop.  One wave's K-step is a
+// serial chain -- LDS-DMA issue (~80 cycles of blocked issue slot per 1 KiB piece: 250-650 cycles), fragment reads, 2-32 MFMAs
+// (tools/lab_sk.sh stamp: 800 cycles per step for the 64x32 tile, 1 600 for 128x128, at one wave per SIMD) -- so a second / fourth
+// wave per SIMD working on ANOTHER K-step is what overlaps it, without a second workgroup's slab traffic.
+template <int TAPS, int BM, int BN, int NST, int KG>
+__global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
+                                                      const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int W, int Cin,
+                                                      int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
+                                                      float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
+                                                      const half_t* __restrict__ X2, int Cin1) {
     constexpr int ROWB = 128, RPI = 8;                 // bytes per tile row (K-step 64), rows per 1 KiB wave-instruction
     constexpr int LPO = BM / 32, LPB = BN / 32;        // LDS-DMA pieces per wave per K-step: activation rows, weight rows
     constexpr int OPS = LPO + LPB;
@@ -46,12 +57,17 @@ __global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, c
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int CS_LD = BN + 8;
     constexpr int D = NST - 1;                         // prefetch distance
-    constexpr int FLAG_OFF = NST * STAGE_BYTES;        // "I drew the last ticket" (ONE __shared__ object: cdna guide section 5 trap 4a)
-    static_assert(NST >= 2 && NST <= 4 && OPS * 2 <= 63, "stage count / vmcnt range");
-    static_assert(BM * CS_LD * 2 <= NST * STAGE_BYTES && 256 * 2 * 4 <= NST * STAGE_BYTES, "epilogue staging must fit the stages");
+    constexpr int NT = KG * 256;
+    constexpr int RING_BYTES = NST * STAGE_BYTES;
+    constexpr int FLAG_OFF = KG * RING_BYTES;          // "I drew the last ticket" (ONE __shared__ object: cdna guide section 5 trap 4a)
+    static_assert(NST >= 2 && NST <= 8 && OPS * (NST - 2) <= 63, "stage count / vmcnt range");
+    static_assert(BM * CS_LD * 2 <= KG * RING_BYTES && NT * 2 * 4 <= KG * RING_BYTES && (KG - 1) * BM * BN * 4 <= KG * RING_BYTES,
+                  "epilogue staging must fit the stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (provably wave-uniform: LDS-DMA bases stay in SGPRs)
+    const int grp = wave >> 2, w4 = wave & 3, t4 = tid & 255;
+    const int wm = w4 >> 1, wn = w4 & 1;
     // XCD-aware work id: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (tile, split) ids, so the K-slices of a
     // tile and the n-tiles sharing an activation tile sit on one L2
     int wid;
@@ -62,77 +78,68 @@ __global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, c
     }
     const int tile = wid / splits, split = wid - tile * splits;
     const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
-    const long long M = (long long)N * H * W;
+    const int M = N * H * W, HWp = H * W;              // (host: M < 2^31)
     const int K = TAPS * Cin;
     const int kc = Cin >> 6;                           // K-steps per tap
     const int KI = TAPS * kc;
 
-    // ---- loader role (as k_conv_igemm): lane stages 16-byte slot (lane % 8) of row (lane / 8) of each of its pieces
+    // ---- loader role: lane stages 16-byte slot (lane % 8) of row (lane / 8) of each of its pieces.  Source addresses are formed
+    // from (tap, channel chunk) at every issue, branch-free: per piece a base pointer and a 9-bit "tap inside the image" mask,
+    // the tap's pixel offset is wave-uniform; out-of-image taps and rows beyond M read the zero page.
+    // Two-source input (1x1 convs over a never-materialised channel concat): channels [0, Cin1) come from X, the rest from X2.
     const int lrow = lane >> 3, lpos = lane & 7;
-    int py[LPO], pxx[LPO];
-    long long pbase[LPO], pbase2[LPO];
-    const half_t* ap[LPO];
-    int astep[LPO];
+    const half_t* abase[LPO];
+    const half_t* abase2[LPO];
+    unsigned amask[LPO];
     const half_t* bp[LPB];
-    const long long zoff = zero_page - X;
 #pragma unroll
     for (int i = 0; i < LPO; ++i) {
-        const int r = wave * (BM / 4) + i * RPI + lrow;
+        const int r = w4 * (BM / 4) + i * RPI + lrow;
         const int c = lpos ^ sk_swz(r);
-        const long long m = (long long)m0 + r;
+        const int m = m0 + r;
         const bool inm = m < M;
-        const long long mm = inm ? m : 0;
-        const int img = (int)(mm / ((long long)H * W));
-        const int rem = (int)(mm - (long long)img * H * W);
-        py[i] = inm ? rem / W : -100000;
-        pxx[i] = rem - (rem / W) * W;
-        pbase[i] = (((long long)img * H + rem / W) * W + pxx[i]) * Cin1 + c * 8;
-        if (TAPS == 1) pbase2[i] = inm ? (((long long)img * H + rem / W) * W + pxx[i]) * (Cin - Cin1) + c * 8 : (long long)(zero_page - X2);
+        const unsigned mm = inm ? (unsigned)m : 0u;
+        const unsigned img = mm / (unsigned)HWp, rem = mm - img * (unsigned)HWp;
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (rem / (unsigned)W) * (unsigned)W);
+        abase[i] = X + (size_t)mm * Cin1 + c * 8;
+        abase2[i] = (TAPS == 1 && X2 != nullptr) ? X2 + (size_t)mm * (Cin - Cin1) + c * 8 : nullptr;
+        unsigned msk = 0;
+        if (TAPS == 1) msk = inm ? 1u : 0u;
+        else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (inm && yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << t;
+            }
+        }
+        amask[i] = msk;
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
-        const int r = wave * (BN / 4) + i * RPI + lrow;
+        const int r = w4 * (BN / 4) + i * RPI + lrow;
         bp[i] = Wt + (size_t)(n0 + r) * K + (lpos ^ sk_swz(r)) * 8;
     }
-    auto set_tap = [&](int tap) {
-        const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
-#pragma unroll
-        for (int i = 0; i < LPO; ++i) {
-            const int yy = py[i] + dy, xx = pxx[i] + dx;
-            const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-            const long long off = pbase[i] + ((long long)dy * W + dx) * Cin1;
-            ap[i] = X + (ok ? off : zoff);
-            astep[i] = ok ? 64 : 0;
-        }
-    };
     const int it0 = (int)((long long)KI * split / splits), it1 = (int)((long long)KI * (split + 1) / splits);
-    int ntap = it0 / kc, nc = it0 - (it0 / kc) * kc;
-    set_tap(ntap);
-    if (TAPS == 1 && X2 != nullptr && nc >= (Cin1 >> 6)) {        // a split that starts inside the concat's second tensor
+    char* const ring = smem + grp * RING_BYTES;
+    char* const wave_dst_a = ring + w4 * ((BM / 4) * ROWB);
+    char* const wave_dst_b = ring + A_BYTES + w4 * ((BN / 4) * ROWB);
+    // (tap, channel chunk) of the group's next K-step to issue: scalars advanced by KG steps per issue (no division in the loop)
+    int is_tap = 0, is_nc = 0;
+    auto issue = [&](int stage, int it) {                 // all pieces of K-step `it` (wave-uniform) into `stage` of this group's ring
+        const int tap = is_tap, nc = is_nc;
+        is_nc += KG;
+        while (TAPS != 1 && is_nc >= kc) { is_nc -= kc; ++is_tap; }
+        const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
+        const bool second = TAPS == 1 && X2 != nullptr && nc * 64 >= Cin1;
+        const long long koff = second ? (long long)nc * 64 - Cin1 : ((long long)dy * W + dx) * Cin1 + (long long)nc * 64;
 #pragma unroll
-        for (int i = 0; i < LPO; ++i) ap[i] = X2 + pbase2[i] + (long long)(nc - (Cin1 >> 6)) * 64;
-    } else {
-#pragma unroll
-        for (int i = 0; i < LPO; ++i) ap[i] += astep[i] * nc;
-    }
-#pragma unroll
-    for (int i = 0; i < LPB; ++i) bp[i] += (size_t)it0 * 64;
-    char* const wave_dst_a = smem + wave * ((BM / 4) * ROWB);
-    char* const wave_dst_b = smem + A_BYTES + wave * ((BN / 4) * ROWB);
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int p = 0; p < LPO; ++p) { sk_glds16(ap[p], wave_dst_a + stage * STAGE_BYTES + p * 1024); ap[p] += astep[p]; }
-#pragma unroll
-        for (int p = 0; p < LPB; ++p) { sk_glds16(bp[p], wave_dst_b + stage * STAGE_BYTES + p * 1024); bp[p] += 64; }
-        if (TAPS == 1) {
-            if (X2 != nullptr && ++nc == (Cin1 >> 6)) {           // the concat's first tensor is exhausted: continue in the second
-#pragma unroll
-                for (int i = 0; i < LPO; ++i) ap[i] = X2 + pbase2[i];
-            }
-        } else if (++nc == kc) {
-            nc = 0;
-            if (++ntap < TAPS) set_tap(ntap);
+        for (int p = 0; p < LPO; ++p) {
+            const half_t* src = (second ? abase2[p] : abase[p]) + koff;
+            if (((amask[p] >> tap) & 1u) == 0u) src = zero_page + ((lpos ^ sk_swz(w4 * (BM / 4) + p * RPI + lrow)) * 8 & 63);
+            sk_glds16(src, wave_dst_a + stage * STAGE_BYTES + p * 1024);
         }
+#pragma unroll
+        for (int p = 0; p < LPB; ++p) sk_glds16(bp[p] + (size_t)it * 64, wave_dst_b + stage * STAGE_BYTES + p * 1024);
     };
 
     // ---- consumer role
@@ -145,48 +152,132 @@ __global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, c
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
+    // this group's K-steps: g0, g0 + KG, ...; `mine` of them.  Every group runs `iters` loop trips (the barrier counts must match).
+    const int g0 = it0 + grp;
+    if (TAPS == 1) is_nc = g0; else { is_tap = g0 / kc; is_nc = g0 - is_tap * kc; }
+    const int mine = g0 < it1 ? (it1 - g0 + KG - 1) / KG : 0;
+    const int iters = (it1 - it0 + KG - 1) / KG;
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (it0 + d < it1) issue(d);
+        if (d < mine) issue(d, g0 + d * KG);
     int cur = 0, nxt = D % NST;
-    for (int it = it0; it < it1; ++it) {
-        const int rem = it1 - it;                          // stages in flight at this point: min(D, rem) (NST 2: this one only)
-        if (D >= 3 && rem >= 3) sk_wait_vm<2 * OPS>();
-        else if (D >= 2 && rem >= 2) sk_wait_vm<OPS>();
+#ifdef PD_LAB_SK_STAMP
+    unsigned long long lab_w = 0, lab_b = 0, lab_i = 0, lab_c = 0, lab_t, lab_u;
+    const unsigned long long lab_start = SK_CLK();
+#endif
+    for (int k = 0; k < iters; ++k) {
+#ifdef PD_LAB_SK_STAMP
+        lab_t = SK_CLK();
+#endif
+        const int infl = min(D, mine - k);                 // this group's stages in flight, the current one included (<= 0: idle trip)
+        if (D >= 7 && infl >= 7) sk_wait_vm<(D >= 7 ? 6 : 0) * OPS>();
+        else if (D >= 6 && infl >= 6) sk_wait_vm<(D >= 6 ? 5 : 0) * OPS>();
+        else if (D >= 5 && infl >= 5) sk_wait_vm<(D >= 5 ? 4 : 0) * OPS>();
+        else if (D >= 4 && infl >= 4) sk_wait_vm<(D >= 4 ? 3 : 0) * OPS>();
+        else if (D >= 3 && infl >= 3) sk_wait_vm<2 * OPS>();
+        else if (D >= 2 && infl >= 2) sk_wait_vm<OPS>();
         else sk_wait_vm<0>();
-        __builtin_amdgcn_s_barrier();                      // stage `cur` landed for every wave; stage `nxt` is free again
+#ifdef PD_LAB_SK_STAMP
+        lab_u = SK_CLK(); lab_w += lab_u - lab_t; lab_t = lab_u;
+#endif
+#ifndef PD_LAB_SK_NOBARRIER
+        __builtin_amdgcn_s_barrier();                      // stage `cur` landed for every wave of the group; stage `nxt` is free again
+#endif
         asm volatile("" ::: "memory");
-        if (it + D < it1) issue(nxt);
-        const char* As = smem + cur * STAGE_BYTES + (wm * (BM / 2)) * ROWB;
-        const char* Bs = smem + cur * STAGE_BYTES + A_BYTES + (wn * (BN / 2)) * ROWB;
+#ifdef PD_LAB_SK_STAMP
+        lab_u = SK_CLK(); lab_b += lab_u - lab_t; lab_t = lab_u;
+#endif
+        // The groups of a SIMD's waves run in OPPOSITE phases: even groups issue their LDS-DMA pieces (the wave's issue slot is
+        // blocked ~80 cycles per piece, the matrix pipe idles) while odd groups run their MFMAs, then the roles swap -- all groups
+        // doing the same thing behind the common barrier just queue at the LDS-DMA port and then at the matrix pipe.
+        // (measured, tools/bench_sk.py: worth 3-7 % on the 128x64 ... 64x32 tiles; the 128x128 tile is 7 % faster in lock-step)
+        const bool issue_first = KG == 1 || (grp & 1) == 0 || (BM == 128 && BN == 128);
+        if (issue_first && k + D < mine) issue(nxt, g0 + (k + D) * KG);
+#ifdef PD_LAB_SK_STAMP
+        lab_u = SK_CLK(); lab_i += lab_u - lab_t; lab_t = lab_u;
+#endif
+        if (k < mine) {
+            const char* As = ring + cur * STAGE_BYTES + (wm * (BM / 2)) * ROWB;
+            const char* Bs = ring + cur * STAGE_BYTES + A_BYTES + (wn * (BN / 2)) * ROWB;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 a[TM], b[TN];
+            for (int kk = 0; kk < 2; ++kk) {
+                half8 a[TM], b[TN];
+#ifdef PD_LAB_SK_NOLDS                                     // (lab builds only: fragments from registers)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * ROWB + frag_off[kk]);
+                for (int j = 0; j < TN; ++j) { b[j] = (half8){(half_t)j, 1, 2, 3, 4, 5, 6, (half_t)lane}; asm volatile("" : "+v"(b[j])); }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
+                for (int i = 0; i < TM; ++i) { a[i] = (half8){(half_t)i, 1, 2, 3, 4, 5, 6, (half_t)kk}; asm volatile("" : "+v"(a[i])); }
+#else
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * ROWB + frag_off[kk]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
+#endif
+#ifndef PD_LAB_SK_NOMFMA
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { acc[i][j][0] += (float)a[i][0] + (float)b[j][0]; }
+#endif
+            }
         }
+#ifdef PD_LAB_SK_STAMP
+        asm volatile("" : "+v"(acc[0][0]));
+        lab_u = SK_CLK(); lab_c += lab_u - lab_t;
+#endif
+        if (!issue_first && k + D < mine) issue(nxt, g0 + (k + D) * KG);
         cur = (cur + 1 == NST) ? 0 : cur + 1;
         nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
+#ifdef PD_LAB_SK_STAMP
+    if (lane == 0 && (blockIdx.x == 8 || blockIdx.x == 100) && wave < 4) {
+        unsigned long long* o = g_sk_stamps + ((blockIdx.x == 8 ? 0 : 4) + wave) * 8;
+        o[0] = lab_w; o[1] = lab_b; o[2] = lab_i; o[3] = lab_c; o[4] = SK_CLK() - lab_start; o[5] = iters; o[6] = lab_start;
+    }
+#endif
     __syncthreads();                                       // all fragment reads done before the stages are reused
 
-    // ---- in-launch split-K combine
+    // ---- the K-groups' accumulators: groups 1 .. KG-1 park theirs in LDS (register order, 16 bytes per lane), group 0 adds them in
+    // group order
+    if (KG > 1) {
+        constexpr int F = TM * TN;
+        float4_t* R = reinterpret_cast<float4_t*>(smem);
+        if (grp > 0) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) R[((grp - 1) * F + f) * 256 + t4] = acc[f / TN][f % TN];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < KG; ++g)
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    const float4_t v = R[((g - 1) * F + f) * 256 + t4];
+                    float4_t& a = acc[f / TN][f % TN];
+                    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- in-launch split-K combine (group 0 holds the workgroup's slice)
     if (splits > 1) {
         constexpr int F = TM * TN;                         // float4 pieces per thread
         constexpr int SLAB_BYTES = BM * BN * 4;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)tile * splits * (BM * BN), 0, splits * SLAB_BYTES, 0x00020000);
+        if (grp == 0) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
-                                                       split * SLAB_BYTES + ((i * TN + j) * 256 + tid) * 16, 0, /*sc1: write-through*/ 16);
+                for (int j = 0; j < TN; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                                           split * SLAB_BYTES + ((i * TN + j) * 256 + t4) * 16, 0, /*sc1: write-through*/ 16);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
         __syncthreads();                                   // ... before ONE lane takes the ticket
         volatile int* flag = reinterpret_cast<volatile int*>(smem + FLAG_OFF);
@@ -200,28 +291,28 @@ __global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, c
         if (*flag == 0) return;
         // the last arriver: sum the slices in slice order (its own included -- the order must not depend on who is last);
         // U slices' loads in flight at a time, clamped index + conditional add (no branch around a load: cdna guide trap 4c)
-        constexpr int U = 32 / F >= 1 ? 32 / F : 1;
+        if (grp == 0) {
+            constexpr int U = 16 / F >= 1 ? 16 / F : 1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        for (int sp0 = 0; sp0 < splits; sp0 += U) {
-            float4_t v[U][F];
+                for (int j = 0; j < TN; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            for (int sp0 = 0; sp0 < splits; sp0 += U) {
+                float4_t v[U][F];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int sp = min(sp0 + u, splits - 1);
+                for (int u = 0; u < U; ++u) {
+                    const int sp = min(sp0 + u, splits - 1);
 #pragma unroll
-                for (int f = 0; f < F; ++f)
-                    v[u][f] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, sp * SLAB_BYTES + (f * 256 + tid) * 16, 0, /*sc1*/ 16));
-            }
+                    for (int f = 0; f < F; ++f)
+                        v[u][f] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, sp * SLAB_BYTES + (f * 256 + t4) * 16, 0, /*sc1*/ 16));
+                }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float keep = sp0 + u < splits ? 1.0f : 0.0f;
+                for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    float4_t& a = acc[f / TN][f % TN];
-                    if (sp0 + u < splits) { a[0] += v[u][f][0]; a[1] += v[u][f][1]; a[2] += v[u][f][2]; a[3] += v[u][f][3]; }
-                    (void)keep;
+                    for (int f = 0; f < F; ++f) {
+                        float4_t& a = acc[f / TN][f % TN];
+                        if (sp0 + u < splits) { a[0] += v[u][f][0]; a[1] += v[u][f][1]; a[2] += v[u][f][2]; a[3] += v[u][f][3]; }
+                    }
                 }
             }
         }
@@ -230,30 +321,33 @@ __global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, c
     // ---- epilogue: acc (+bias) -> f16 -> LDS [BM][CS_LD] -> coalesced 16-byte rows (+residual) + GroupNorm octet partials.
     // Transposed accumulators (weights x activations): lane holds pixel 16 i + (lane & 15), channels 16 j + 4 (lane >> 4) + 0..3
     half_t* Cs = reinterpret_cast<half_t*>(smem);
+    if (grp == 0) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nl = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-        float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (bias != nullptr && n0 + nl < Cout) bv = *reinterpret_cast<const float4_t*>(bias + n0 + nl);
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && n0 + nl < Cout) bv = *reinterpret_cast<const float4_t*>(bias + n0 + nl);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ml = wm * (BM / 2) + i * 16 + (lane & 15);
-            half4 h;
+            for (int i = 0; i < TM; ++i) {
+                const int ml = wm * (BM / 2) + i * 16 + (lane & 15);
+                half4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
-            *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
+                *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
+            }
         }
     }
     __syncthreads();
     constexpr int CT = BN / 8;                             // column threads (one channel octet each)
-    constexpr int RPP = 256 / CT;                          // rows per pass
+    constexpr int RPP = NT / CT;                           // rows per pass
+    constexpr int PASSES = (BM + RPP - 1) / RPP;
     const int col8 = (tid % CT) * 8;
     float gs = 0.f, gq = 0.f;
 #pragma unroll
-    for (int p = 0; p < BM / RPP; ++p) {
+    for (int p = 0; p < PASSES; ++p) {
         const int row = p * RPP + tid / CT;
-        const long long m = (long long)m0 + row;
-        if (m < M && n0 + col8 < Cout) {
+        const int m = m0 + row;
+        if (row < BM && m < M && n0 + col8 < Cout) {
             half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
             const size_t o = (size_t)m * Cout + n0 + col8;
             if (residual != nullptr) {
@@ -274,57 +368,84 @@ __global__ __launch_bounds__(256) void k_conv_sk(const half_t* __restrict__ X, c
         if (tid < CT && n0 + tid * 8 < Cout) {
             float s1 = 0.f, q1 = 0.f;
             for (int r = 0; r < RPP; ++r) { s1 += red[(r * CT + tid) * 2]; q1 += red[(r * CT + tid) * 2 + 1]; }
-            const int hw = H * W, chunks = hw / BM;
-            const int img = m0 / hw, chunk = (m0 - img * hw) / BM;
+            const int chunks = HWp / BM;
+            const int img = m0 / HWp, chunk = (m0 - img * HWp) / BM;
             float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + tid) * 2;
             dst[0] = s1; dst[1] = q1;
         }
     }
 }
 
-template <int TAPS, int BM, int BN, int NST>
+template <int TAPS, int BM, int BN, int NST, int KG>
 int launch_sk(int grid, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
               int W, int Cin, int Cout, int n_tiles, int total, const half_t* zero_page, int splits, float* slabs, unsigned* tickets,
               float* gnp, const half_t* X2, int Cin1) {
-    auto kern = k_conv_sk<TAPS, BM, BN, NST>;
-    const size_t smem = (size_t)NST * (BM + BN) * 128 + 16;
+    auto kern = k_conv_sk<TAPS, BM, BN, NST, KG>;
+    constexpr size_t smem = (size_t)KG * NST * (BM + BN) * 128 + 16;
+    static_assert(smem <= 160 * 1024, "LDS budget");
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1);
+    kern<<<grid, KG * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
 
 }  // namespace
 
+#ifdef PD_LAB_SK_STAMP
+extern "C" int pdhip_lab_sk_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sk_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 thread_local int g_sk_mode = 1;        // tuning / test hook: 0 = never route to k_conv_sk, 1 = automatic, 2 = every eligible layer
 thread_local int g_sk_tile = 0;        // tuning hook: 0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x32
 thread_local int g_sk_splits = 0;      // tuning hook: >= 1 forces the split factor
+thread_local int g_sk_stages = 0;      // lab hook: LDS stages per K-group (2, 3, 4 where the tile allows); 0 = default
+thread_local int g_sk_kg = 0;          // lab hook: K-groups per workgroup (1, 2, 4); 0 = default
 
-// the plan for one layer; bm == 0: not a layer for this kernel
+// the plan for one layer; bm == 0: not a layer for this kernel.  Rules read off tools/bench_sk.py tables (profiles/r03_sk_bench.txt):
+//   * a tile shape whose tiles alone fill the chip (>= 224) runs unsplit -- the largest such shape (fewest L2 -> LDS bytes);
+//   * otherwise 3x3 layers are split along K to ~256 workgroups: the largest tile that needs <= 4 slices, else the 64x32 tile with
+//     up to 8 (a tile's slabs are re-read by ONE workgroup: 16 x 8 KB slices cost more than the K loop they shorten);
+//   * 1x1 layers (K loops of 4-32 steps) never split: the combine costs more than their whole loop.
 SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, bool two_source, size_t ws_floats) {
     SkPlan p{0, 0, 0, 0};
     if (g_sk_mode == 0 || Cin % 64 != 0 || Cout % 8 != 0 || Cout_pad % 128 != 0) return p;
     const long long M = (long long)N * H * W, hw = (long long)H * W;
+    if (M >= (1LL << 31) / 2) return p;
     const int KI = taps * (Cin / 64);
     static const int BMs[4] = {128, 128, 64, 64}, BNs[4] = {128, 64, 64, 32};
-    static const int SMAX[4] = {2, 4, 8, 16};          // slices whose slabs one workgroup re-reads: <= 128 KB per tile
-    int pick = -1, ps = 1;
+    long long tiles[4];
+    bool ok[4];
     for (int t = 0; t < 4; ++t) {
-        if (g_sk_tile != 0 && g_sk_tile != t + 1) continue;
-        const int bm = BMs[t], bn = BNs[t];
-        if (hw % bm != 0) continue;                        // a tile never straddles two images (fused GroupNorm partials)
-        const long long tiles = ((M + bm - 1) / bm) * (Cout_pad / bn);
-        if (tiles > 640 && g_sk_tile == 0 && g_sk_mode != 2) return p;   // enough tiles already: the big-tile kernels own that regime
-        int s = (int)std::min<long long>(std::min<long long>(511 / std::max<long long>(tiles, 1), SMAX[t]), std::max(KI / 2, 1));
-        if (ws_floats == 0) s = 1;
-        if (s < 1) s = 1;
-        while (s > 1 && (size_t)tiles * s * bm * bn + 4096 > ws_floats) --s;
-        if (g_sk_splits >= 1) s = (int)std::min<long long>(std::min(g_sk_splits, std::max(KI, 1)), s > 1 || ws_floats ? 64 : 1);
-        if (g_sk_splits >= 1) while (s > 1 && (size_t)tiles * s * bm * bn + 4096 > ws_floats) --s;
-        pick = t; ps = s;
-        if (tiles * s >= 200 || g_sk_tile != 0) break;     // fills the chip: take the largest such tile
+        tiles[t] = ((M + BMs[t] - 1) / BMs[t]) * (Cout_pad / BNs[t]);
+        ok[t] = hw % BMs[t] == 0;                          // a tile never straddles two images (fused GroupNorm partials)
     }
-    if (pick < 0) return p;
+    int pick = -1, ps = 1;
+    if (g_sk_tile != 0) {
+        pick = g_sk_tile - 1;
+        if (pick < 0 || pick > 3 || !ok[pick]) return p;
+        ps = g_sk_splits >= 1 ? g_sk_splits : 1;
+    } else {
+        if (g_sk_mode != 2 && ok[0] && tiles[0] > 640) return p;   // enough 128x128 tiles: the big-tile kernels own that regime
+        for (int t = 0; t < 4 && pick < 0; ++t)
+            if (ok[t] && tiles[t] >= 224) { pick = t; ps = 1; }
+        if (pick < 0 && taps == 9) {
+            for (int t = 0; t < 4 && pick < 0; ++t) {
+                const int s = (int)((256 + tiles[t] / 2) / std::max<long long>(tiles[t], 1));
+                if (ok[t] && s <= 4) { pick = t; ps = std::max(s, 1); }
+            }
+            if (pick < 0 && ok[3]) { pick = 3; ps = (int)std::min<long long>(8, (256 + tiles[3] / 2) / std::max<long long>(tiles[3], 1)); }
+        }
+        if (pick < 0) {                                    // 1x1: unsplit, the smallest tile the images allow
+            for (int t = 3; t >= 0 && pick < 0; --t) if (ok[t]) pick = t;
+            ps = 1;
+        }
+        if (pick < 0) return p;
+        if (g_sk_splits >= 1) ps = g_sk_splits;
+    }
+    ps = std::max(1, std::min(std::min(ps, std::max(KI / 2, 1)), 64));
+    if (ws_floats == 0 || tiles[pick] > 4096) ps = 1;
+    while (ps > 1 && (size_t)tiles[pick] * ps * BMs[pick] * BNs[pick] + PD_SK_TICKET_FLOATS > ws_floats) --ps;
     (void)two_source;
     p.bm = BMs[pick]; p.bn = BNs[pick]; p.splits = ps; p.tile_id = pick + 1;
     return p;
@@ -338,18 +459,30 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     PD_REQUIRE(X2 == nullptr || (taps == 1 && Cin1 % 64 == 0 && (Cin - Cin1) % 64 == 0 && Cin1 > 0 && Cin1 < Cin), "conv_sk: bad two-source split");
     const long long M = (long long)N * H * W;
     const int m_tiles = (int)((M + pl.bm - 1) / pl.bm), n_tiles = Cout_pad / pl.bn, total = m_tiles * n_tiles;
-    PD_REQUIRE(pl.splits == 1 || (ws != nullptr && (size_t)total * pl.splits * pl.bm * pl.bn + 4096 <= ws_floats && total <= 4096),
+    PD_REQUIRE(pl.splits == 1 || (ws != nullptr && (size_t)total * pl.splits * pl.bm * pl.bn + PD_SK_TICKET_FLOATS <= ws_floats && total <= 4096),
                "conv_sk: split-K workspace too small");
     // workspace: [0, 4096) ticket words (zeroed at allocation, self-resetting), then the slabs
     unsigned* tickets = reinterpret_cast<unsigned*>(ws);
-    float* slabs = ws ? ws + 4096 : nullptr;
+    float* slabs = ws ? ws + PD_SK_TICKET_FLOATS : nullptr;
     if (gn_fused) *gn_fused = gn_part ? (int)(((long long)H * W) / pl.bm) : 0;
     const int grid = total * pl.splits;
 #define SK_ARGS grid, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, X2, Cin1
-#define SK_TILE(T) (pl.tile_id == 1 ? launch_sk<T, 128, 128, 2>(SK_ARGS) : pl.tile_id == 2 ? launch_sk<T, 128, 64, 3>(SK_ARGS) \
-                    : pl.tile_id == 3 ? launch_sk<T, 64, 64, 4>(SK_ARGS) : launch_sk<T, 64, 32, 4>(SK_ARGS))
+    // (lab hooks: K-groups g_sk_kg, stages g_sk_stages; 0 = the tile's default)
+    int kg = g_sk_kg;
+    const int st = g_sk_stages;
+    if (kg == 0) kg = (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
+#define SK_L(T, BM_, BN_, NST_, KG_) launch_sk<T, BM_, BN_, NST_, KG_>(SK_ARGS)
+#define SK_TILE(T)                                                                                                                   \
+    (pl.tile_id == 1 ? (kg == 1 ? (st == 3 ? SK_L(T, 128, 128, 3, 1) : st == 4 ? SK_L(T, 128, 128, 4, 1) : SK_L(T, 128, 128, 2, 1)) : SK_L(T, 128, 128, 2, 2))        \
+     : pl.tile_id == 2 ? (kg == 1 ? (st == 2 ? SK_L(T, 128, 64, 2, 1) : st == 4 ? SK_L(T, 128, 64, 4, 1) : SK_L(T, 128, 64, 3, 1))                                   \
+                          : (st == 2 ? SK_L(T, 128, 64, 2, 2) : SK_L(T, 128, 64, 3, 2)))                                                                          \
+     : pl.tile_id == 3 ? (kg == 1 ? (st == 2 ? SK_L(T, 64, 64, 2, 1) : SK_L(T, 64, 64, 4, 1)) : kg == 4 ? SK_L(T, 64, 64, 2, 4)                                       \
+                          : (st == 2 ? SK_L(T, 64, 64, 2, 2) : st == 3 ? SK_L(T, 64, 64, 3, 2) : SK_L(T, 64, 64, 4, 2)))                                             \
+                       : (kg == 1 ? (st == 2 ? SK_L(T, 64, 32, 2, 1) : SK_L(T, 64, 32, 4, 1)) : kg == 4 ? (st == 2 ? SK_L(T, 64, 32, 2, 4) : SK_L(T, 64, 32, 3, 4))    \
+                          : (st == 2 ? SK_L(T, 64, 32, 2, 2) : st == 3 ? SK_L(T, 64, 32, 3, 2) : SK_L(T, 64, 32, 4, 2))))
     return taps == 9 ? SK_TILE(9) : SK_TILE(1);
 #undef SK_TILE
+#undef SK_L
 #undef SK_ARGS
 }
 

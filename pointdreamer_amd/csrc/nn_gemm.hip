@@ -593,6 +593,20 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0))
         return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused, splitk_ws,
                             splitk_ws_floats, apply_table, res_up, in_up);
+    // small-M layers (output tiles do not fill the chip): small tiles, deep staging, split-K combined inside the launch
+    if (in_up == 0 && res_up == 0 && apply_table == nullptr && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
+        const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, X2 != nullptr, splitk_ws ? splitk_ws_floats : 0);
+        if (pl.bm > 0) {
+            float* gnp = (gn_part != nullptr && ((long long)H * W) % pl.bm == 0) ? gn_part : nullptr;
+            return conv_sk(pl, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, taps, zero_page, s, splitk_ws, splitk_ws_floats, gnp,
+                           gn_fused, X2, Cin1);
+        }
+    }
+    // (the first PD_SK_TICKET_FLOATS words of the split-K workspace are k_conv_sk's ticket counters)
+    if (splitk_ws != nullptr) {
+        if (splitk_ws_floats > PD_SK_TICKET_FLOATS) { splitk_ws += PD_SK_TICKET_FLOATS; splitk_ws_floats -= PD_SK_TICKET_FLOATS; }
+        else { splitk_ws = nullptr; splitk_ws_floats = 0; }
+    }
     PD_REQUIRE(in_up == 0, "conv_igemm: an up-sampled input needs a layer the halo-resident kernel takes");
     PD_REQUIRE(res_up == 0, "conv_igemm: an up-sampled residual needs a layer the halo-resident kernel takes unsplit");
     PD_REQUIRE(apply_table == nullptr, "conv_igemm: an input transform needs a layer the halo-resident kernel takes");

@@ -494,6 +494,7 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     chk(dalloc(u, &u->t_dev, (size_t)max_batch));
     u->splitk_floats = (size_t)16 * 384 * 128 * 128;               // 16 splits x (< 384 tiles of 128x128) f32
     chk(dalloc(u, &u->splitk_ws, u->splitk_floats));
+    if (rc == PDHIP_OK && hipMemset(u->splitk_ws, 0, PD_SK_TICKET_FLOATS * sizeof(float)) != hipSuccess) rc = PDHIP_E_HIP;   // k_conv_sk's tickets
     chk(dalloc(u, &u->sx, (size_t)max_batch * 3 * S2)); chk(dalloc(u, &u->sy, (size_t)max_batch * 3 * S2));
     chk(dalloc(u, &u->set_, (size_t)max_batch * out_channels * S2)); chk(dalloc(u, &u->smask, (size_t)max_batch * S2));
     if (rc) return fail(rc);
@@ -778,8 +779,18 @@ extern "C" int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed, const 
 extern "C" int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int splits) {
     int old = pdnn::g_force_splits;
     pdnn::g_dbg_splitk_ws = (float*)ws; pdnn::g_dbg_splitk_floats = ws ? (size_t)ws_floats : 0; pdnn::g_force_splits = splits;
+    if (ws != nullptr && ws_floats >= PD_SK_TICKET_FLOATS) (void)hipMemset(ws, 0, PD_SK_TICKET_FLOATS * sizeof(float));   // k_conv_sk's tickets start at zero
     return old;
 }
+/* tuning / test hook of the small-M conv kernel (nn_conv_sk.hip): mode 0 = never, 1 = automatic (default), 2 = every eligible layer;
+ * tile 0 = automatic, 1..4 = 128x128 / 128x64 / 64x64 / 64x32; splits 0 = automatic.  Returns the previous mode. */
+extern "C" int pdhip_debug_set_conv_sk(int mode, int tile, int splits) {
+    int old = pdnn::g_sk_mode;
+    pdnn::g_sk_mode = mode; pdnn::g_sk_tile = tile; pdnn::g_sk_splits = splits;
+    return old;
+}
+extern "C" int pdhip_debug_set_conv_sk_stages(int stages) { int old = pdnn::g_sk_stages; pdnn::g_sk_stages = stages; return old; }
+extern "C" int pdhip_debug_set_conv_sk_kgroups(int kg) { int old = pdnn::g_sk_kg; pdnn::g_sk_kg = kg; return old; }
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }

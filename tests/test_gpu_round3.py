@@ -109,17 +109,60 @@ def test_unet_small_batch_routing_variants(nn, full_model):
     for N in (1, 2):
         x, t = x1.repeat(N, 1, 1, 1).contiguous(), t1.repeat(N).contiguous()
         outs = {}
-        for fin in (4, 0):
-            old = L.pdhip_debug_set_fold_finalize(fin)
+        for fin, sk in ((4, 1), (0, 1), (4, 0), (0, 0)):
+            old, olds = L.pdhip_debug_set_fold_finalize(fin), L.pdhip_debug_set_conv_sk(sk, 0, 0)
             try:
-                outs[fin] = full_model(x, t).cpu()
+                outs[(fin, sk)] = full_model(x, t).cpu()
+                again = full_model(x, t).cpu()
             finally:
-                L.pdhip_debug_set_fold_finalize(old)
+                L.pdhip_debug_set_fold_finalize(old); L.pdhip_debug_set_conv_sk(olds, 0, 0)
+            assert torch.equal(outs[(fin, sk)], again), "a forward is deterministic (fixed-order in-launch split-K combine)"
             for b in range(N):
-                linf, l2 = _rel(outs[fin][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))
-                assert linf <= 2e-2 and l2 <= 5e-3, (N, fin, b, linf, l2)
-        linf, l2 = _rel(outs[4], outs[0])
-        assert linf <= 2e-3 and l2 <= 1e-3, (N, linf, l2)       # (f64 sums in a different order: equal up to an f32 rounding of mean / rstd)
+                linf, l2 = _rel(outs[(fin, sk)][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+                assert linf <= 2e-2 and l2 <= 5e-3, (N, fin, sk, b, linf, l2)
+        for key in ((0, 1), (4, 0), (0, 0)):
+            linf, l2 = _rel(outs[(4, 1)], outs[key])
+            assert linf <= 4e-3 and l2 <= 2.5e-3, (N, key, linf, l2)   # (two f16 routings of the same net: both inside the U1 budget, and this close to each other)
+
+
+@pytest.mark.parametrize("tile,splits", [(1, 1), (1, 2), (2, 1), (2, 3), (3, 1), (3, 5), (4, 1), (4, 8), (4, 16), (0, 0)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,res", [
+    (1, 8, 8, 128, 256, 3, True),          # one 64-pixel image: the 8^2 level (weight stream)
+    (3, 8, 8, 192, 136, 3, False),         # M = 192 (not a multiple of 128), Cout not a multiple of the tile
+    (1, 16, 16, 256, 128, 3, True),
+    (2, 32, 32, 64, 64, 3, False),
+    (1, 16, 16, 320, 384, 1, True),        # 1x1 (qkv / proj / skip shapes), K-steps 5: uneven slices
+    (2, 8, 8, 1024, 256, 1, False),
+])
+def test_conv_sk_small_m_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, k, res, tile, splits):
+    """k_conv_sk (nn_conv_sk.hip): every tile shape, split factors incl. uneven K slices, in-launch combine; vs F.conv2d in fp32 on
+    the same f16-rounded operands, and bit-identical when repeated (the combine order does not depend on the arrival order)."""
+    from test_gpu_nn import hip_conv
+    import torch.nn.functional as F
+    L = nn['L']
+    if tile in (1, 2) and (H * W) % 128 != 0:
+        pytest.skip("128-row tiles need H * W % 128 == 0")
+    g = torch.Generator().manual_seed(1000 * tile + splits + Cin)
+    x = torch.randn((N, Cin, H, W), generator=g).half().float()
+    w = (torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)).half().float()
+    b = torch.randn((Cout,), generator=g).half().float()
+    r = torch.randn((N, Cout, H, W), generator=g).half().float() if res else None
+    ws = torch.empty((4096 + 64 * 4096 * 16,), dtype=torch.float32, device=DEV)
+    L.pdhip_debug_set_conv_splitk(_ptr(ws), ws.numel(), 0)
+    old = L.pdhip_debug_set_conv_sk(2 if tile else 1, tile, splits)
+    ref = F.conv2d(x, w, b, padding=k // 2) + (r if res else 0)
+    try:
+        for kg in (0, 1, 2, 4):                     # K-groups per workgroup (4-wave groups on alternate K-steps of one tile)
+            L.pdhip_debug_set_conv_sk_kgroups(kg)
+            y1 = hip_conv(nn, x, w, b, r)
+            y2 = hip_conv(nn, x, w, b, r)
+            err = (y1 - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 2e-3, (kg, err)
+            assert torch.equal(y1, y2), kg
+    finally:
+        L.pdhip_debug_set_conv_sk_kgroups(0)
+        L.pdhip_debug_set_conv_sk(old, 0, 0)
+        L.pdhip_debug_set_conv_splitk(None, 0, 0)
 
 
 def _free_port():
