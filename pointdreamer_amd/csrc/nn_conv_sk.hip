@@ -61,7 +61,7 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     constexpr int RING_BYTES = NST * STAGE_BYTES;
     constexpr int FLAG_OFF = KG * RING_BYTES;          // "I drew the last ticket" (ONE __shared__ object: cdna guide section 5 trap 4a)
     static_assert(NST >= 2 && NST <= 8 && OPS * (NST - 2) <= 63, "stage count / vmcnt range");
-    static_assert(BM * CS_LD * 2 <= KG * RING_BYTES && NT * 2 * 4 <= KG * RING_BYTES && (KG - 1) * BM * BN * 4 <= KG * RING_BYTES,
+    static_assert(BM * CS_LD * 2 <= KG * RING_BYTES && NT * 4 * 4 <= KG * RING_BYTES && (KG - 1) * BM * BN * 4 <= KG * RING_BYTES,
                   "epilogue staging must fit the stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -342,7 +342,10 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     constexpr int RPP = NT / CT;                           // rows per pass
     constexpr int PASSES = (BM + RPP - 1) / RPP;
     const int col8 = (tid % CT) * 8;
-    float gs = 0.f, gq = 0.f;
+    // GroupNorm octet partials per image segment of the tile: a 128-row tile of an 8x8 level covers TWO images (host: H * W % BM == 0
+    // or BM % (H * W) == 0 with at most two images per tile)
+    const int seg_rows = min(BM, HWp);
+    float gs[2] = {0.f, 0.f}, gq[2] = {0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int row = p * RPP + tid / CT;
@@ -356,22 +359,32 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
             *reinterpret_cast<half8*>(Y + o) = v;
+            float s8 = 0.f, q8 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
+            for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s8 += f; q8 += f * f; }
+            const bool hi = row >= seg_rows;
+            gs[0] += hi ? 0.f : s8; gq[0] += hi ? 0.f : q8;
+            gs[1] += hi ? s8 : 0.f; gq[1] += hi ? q8 : 0.f;
         }
     }
-    if (gn_part != nullptr) {                              // host guarantees the tile lies inside one image (H * W % BM == 0)
+    if (gn_part != nullptr) {
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        red[tid * 2] = gs; red[tid * 2 + 1] = gq;
+        float* red = reinterpret_cast<float*>(smem);       // [segment][thread][2]
+        red[tid * 2] = gs[0]; red[tid * 2 + 1] = gq[0];
+        red[(NT + tid) * 2] = gs[1]; red[(NT + tid) * 2 + 1] = gq[1];
         __syncthreads();
-        if (tid < CT && n0 + tid * 8 < Cout) {
-            float s1 = 0.f, q1 = 0.f;
-            for (int r = 0; r < RPP; ++r) { s1 += red[(r * CT + tid) * 2]; q1 += red[(r * CT + tid) * 2 + 1]; }
-            const int chunks = HWp / BM;
-            const int img = m0 / HWp, chunk = (m0 - img * HWp) / BM;
-            float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + tid) * 2;
-            dst[0] = s1; dst[1] = q1;
+        const int nseg = BM / seg_rows;
+        if (tid < CT * nseg) {
+            const int seg = tid / CT, c = tid - seg * CT;
+            const int img = m0 / HWp + seg;
+            if (n0 + c * 8 < Cout && img < N) {
+                float s1 = 0.f, q1 = 0.f;
+                for (int r = 0; r < RPP; ++r) { s1 += red[(seg * NT + r * CT + c) * 2]; q1 += red[(seg * NT + r * CT + c) * 2 + 1]; }
+                const int chunks = HWp >= BM ? HWp / BM : 1;
+                const int chunk = HWp >= BM ? (m0 - (m0 / HWp) * HWp) / BM : 0;
+                float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + c) * 2;
+                dst[0] = s1; dst[1] = q1;
+            }
         }
     }
 }
@@ -418,7 +431,7 @@ SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
     bool ok[4];
     for (int t = 0; t < 4; ++t) {
         tiles[t] = ((M + BMs[t] - 1) / BMs[t]) * (Cout_pad / BNs[t]);
-        ok[t] = hw % BMs[t] == 0;                          // a tile never straddles two images (fused GroupNorm partials)
+        ok[t] = hw % BMs[t] == 0 || BMs[t] == 2 * hw;      // a tile is part of one image, or exactly two whole images (fused GroupNorm partials)
     }
     int pick = -1, ps = 1;
     if (g_sk_tile != 0) {
@@ -464,13 +477,16 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     // workspace: [0, 4096) ticket words (zeroed at allocation, self-resetting), then the slabs
     unsigned* tickets = reinterpret_cast<unsigned*>(ws);
     float* slabs = ws ? ws + PD_SK_TICKET_FLOATS : nullptr;
-    if (gn_fused) *gn_fused = gn_part ? (int)(((long long)H * W) / pl.bm) : 0;
+    if (gn_fused) *gn_fused = gn_part ? std::max((int)(((long long)H * W) / pl.bm), 1) : 0;
     const int grid = total * pl.splits;
 #define SK_ARGS grid, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, X2, Cin1
     // (lab hooks: K-groups g_sk_kg, stages g_sk_stages; 0 = the tile's default)
     int kg = g_sk_kg;
     const int st = g_sk_stages;
-    if (kg == 0) kg = (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
+    // K-groups: two (four for long unsplit loops of the 64x32 tile) when the launch is ONE round of workgroups -- they are what puts a
+    // second wave on every SIMD; with >= 1.5 rounds co-resident workgroups do that already and the lock-step of the groups only
+    // costs (tools/bench_sk.py, 512 tiles of 128x128: 148 us with one group, 184 with two)
+    if (kg == 0) kg = grid >= 384 ? 1 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
 #define SK_L(T, BM_, BN_, NST_, KG_) launch_sk<T, BM_, BN_, NST_, KG_>(SK_ARGS)
 #define SK_TILE(T)                                                                                                                   \
     (pl.tile_id == 1 ? (kg == 1 ? (st == 3 ? SK_L(T, 128, 128, 3, 1) : st == 4 ? SK_L(T, 128, 128, 4, 1) : SK_L(T, 128, 128, 2, 1)) : SK_L(T, 128, 128, 2, 2))        \

@@ -597,7 +597,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     if (in_up == 0 && res_up == 0 && apply_table == nullptr && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
         const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, X2 != nullptr, splitk_ws ? splitk_ws_floats : 0);
         if (pl.bm > 0) {
-            float* gnp = (gn_part != nullptr && ((long long)H * W) % pl.bm == 0) ? gn_part : nullptr;
+            float* gnp = (gn_part != nullptr && (((long long)H * W) % pl.bm == 0 || pl.bm == 2 * H * W)) ? gn_part : nullptr;
             return conv_sk(pl, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, taps, zero_page, s, splitk_ws, splitk_ws_floats, gnp,
                            gn_fused, X2, Cin1);
         }

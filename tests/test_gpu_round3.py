@@ -140,8 +140,8 @@ def test_conv_sk_small_m_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, k, res, ti
     from test_gpu_nn import hip_conv
     import torch.nn.functional as F
     L = nn['L']
-    if tile in (1, 2) and (H * W) % 128 != 0:
-        pytest.skip("128-row tiles need H * W % 128 == 0")
+    if tile in (1, 2) and (H * W) % 128 != 0 and H * W != 64:
+        pytest.skip("128-row tiles need H * W % 128 == 0 (or two whole 64-pixel images per tile)")
     g = torch.Generator().manual_seed(1000 * tile + splits + Cin)
     x = torch.randn((N, Cin, H, W), generator=g).half().float()
     w = (torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)).half().float()

@@ -11,7 +11,8 @@ P = lambda t: C.c_void_p(t.data_ptr())
 SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (1, 8, 8, 1024, 1024, 9), (1, 16, 16, 1024, 1024, 9), (1, 32, 32, 512, 512, 9), (1, 64, 64, 512, 512, 9), (1, 128, 128, 256, 256, 9),
     (1, 8, 8, 1024, 3072, 1), (1, 8, 8, 1024, 1024, 1), (1, 32, 32, 512, 1536, 1), (1, 16, 16, 2048, 1024, 1),
-    (8, 8, 8, 1024, 1024, 9), (8, 16, 16, 1024, 1024, 9), (8, 32, 32, 512, 512, 9)]
+    (8, 8, 8, 1024, 1024, 9), (8, 16, 16, 1024, 1024, 9), (8, 32, 32, 512, 512, 9),
+    (32, 8, 8, 1024, 1024, 9), (32, 16, 16, 1024, 1024, 9), (8, 8, 8, 2048, 1024, 9), (8, 16, 16, 2048, 1024, 9)]
 ap = argparse.ArgumentParser()
 ap.add_argument('--shapes', type=int, nargs='*', default=None)
 ap.add_argument('--tiles', type=int, nargs='*', default=[1, 2, 3, 4])
@@ -62,7 +63,7 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
         for tile in a.tiles:
             row = []
             for sp in a.splits:
-                if (tile in (1, 2) and (H * W) % 128 != 0):
+                if (tile in (1, 2) and (H * W) % 128 != 0 and H * W != 64):
                     continue
                 L.pdhip_debug_set_conv_sk(2 if tile else 1, tile, sp)
                 row.append(f"s{sp}:{timed():6.1f}")
