@@ -78,19 +78,26 @@ def _cpu_worker(args):
     return wall, stages, off
 
 
-def cpu_baseline(timed=3, max_workers=32):
+def cpu_baseline(timed=2, max_workers=None):
     """Reference CPU 'nearest' path next to the GPU number.  kind = "port": the reference has no runnable
     CPU pipeline (demo.py:12,19 hard-code CUDA; kaolin / nvdiffrast are CUDA-only), so this is the oracle's CPU restatement of
     it -- project, raster, depth test + hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF
     unproject, atlas dilate -- at BASELINE sizes.  Host cores are used the way a CPU deployment of this throughput metric would
-    use them: one independent shape stream per core (the per-shape code is serial numpy / scipy, as the reference's is), on
-    min(`max_workers`, host cores) cores -- bounded so that the default bench run stays within minutes and ~1 GB per worker fits
-    any box of the pool; `cores`, `host_cores` and the per-core rate are reported, so the all-core figure can be read off.
-    Every worker runs 1 warm-up + `timed` shapes (about 40 s of wall time), the aggregate rate is shapes / slowest worker's
-    wall time."""
+    use them: one independent shape stream per core (the per-shape code is serial numpy / scipy, as the reference's is), on ALL
+    host cores (capped only by memory at ~1.5 GB per worker, or by `max_workers`); `cores`, `host_cores` and the
+    per-core rate are reported.  Every worker runs 1 warm-up + `timed` shapes with hidden-point removal and one without (the bounded
+    sample of the task statement: ~30 s of CPU work per core), the aggregate rate is shapes / slowest worker's wall time; the
+    median seconds per shape over all workers x shapes is reported next to it."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
-    workers = max(1, min(cores, max_workers))
+    workers = cores if max_workers is None else max(1, min(cores, max_workers))
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable'):
+                workers = max(1, min(workers, int(int(line.split()[1]) / (1.5 * 1024 * 1024))))
+                break
+    except OSError:
+        pass
     model = 'unknown'
     try:
         for line in open('/proc/cpuinfo'):
@@ -221,15 +228,19 @@ def main():
         ams, aflops, alaunches = inpainter.model.profile_read(attention=True)
         inpainter.model.profile(False)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_conv.json')))
         pmc = cands[-1] if cands else ''
         if pmc:          # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command (tools/pmc_bench.sh)
             pj = json.load(open(pmc))                 # per-launch bytes depend on the UNet batch: only quoted for the batch it was measured at
             traffic = pj.get('hbm_bytes_per_launch') if pj.get('shapes_per_step', 1) == SPS else None
+            if traffic is not None:                   # NOT measured by this run: PMC counters need their own rocprofv3 passes
+                traffic_source = (f"{os.path.relpath(pmc, ROOT)} (rocprofv3 --pmc passes of this command, recorded earlier; FETCH_SIZE "
+                                  f"doubled per the gfx950 correction + WRITE_SIZE)")
         roofline = dict(bound="mfma", kernel="k_conv3x3_halo (3x3 conv of the 64^2/128^2/256^2 levels, LDS-resident activation halo, f16 in / f32 acc)", achieved=achieved,
-                        peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=traffic,
+                        peak=PEAK_FP16_TFLOPS, unit="TFLOP/s", frac=achieved / PEAK_FP16_TFLOPS, traffic=traffic, traffic_source=traffic_source,
+                        whole_unet_frac=(UNET_FLOP_PER_FORWARD * views_here * args.ddnm_steps * args.steps) / dt / 1e12 / PEAK_FP16_TFLOPS,
                         launches=int(launches), avg_launch_ms=ms / max(launches, 1),
                         flops_per_launch=flops / max(launches, 1),
                         unet_forward_tflops_effective=(UNET_FLOP_PER_FORWARD * views_here * args.ddnm_steps * args.steps) / dt / 1e12,
@@ -259,7 +270,11 @@ def main():
             sync(); dno = (time.perf_counter() - t1) / 50
             extras['nearest'] = dict(metric="shapes/hour (configs[1]: 30k-pt cloud, 8x256^2 views, texture_gen_method='nearest' + NBF [21], "
                                             "hidden-point removal on, one shape per step)", value=3600.0 / dn, ms_per_shape=dn * 1e3,
-                                     ms_per_shape_hpr_off=dno * 1e3, value_hpr_off=3600.0 / dno)
+                                     ms_per_shape_hpr_off=dno * 1e3, value_hpr_off=3600.0 / dno,
+                                     # rows P1-Uq5 without P3b move 254 MB of algorithmic bytes per shape
+                                     roofline=dict(bound="hbm", achieved=254e6 / dno / 1e9, peak=8000.0, unit="GB/s",
+                                                   frac=254e6 / dno / 1e9 / 8000.0, traffic=None,
+                                                   note="aggregate over the ~21 launches of one shape, hidden-point removal off"))
             one(cfg)
             sync(); t1 = time.perf_counter()
             one(cfg)

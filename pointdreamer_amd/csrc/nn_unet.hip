@@ -40,7 +40,7 @@ namespace pdnn { thread_local int g_fuse_gn = 0; }
 namespace pdnn { thread_local int g_fold_resample = 1; }
 // tuning / test hook (pdhip_debug_set_fold_finalize): largest batch at which GroupNorm-apply reduces the conv epilogues' octet
 // partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never)
-namespace pdnn { thread_local int g_fold_finalize = 4; }
+namespace pdnn { thread_local int g_fold_finalize = 8; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 

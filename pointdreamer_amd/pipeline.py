@@ -1,9 +1,11 @@
 """The texturing hot path as one call: project -> inpaint -> unproject (-> dilate).
 
 `colorize_one_mesh` keeps the keyword surface of the reference's demo.colorize_one_mesh
-(/root/reference/demo.py:38-253) for the stages this build covers.  Stages outside SURVEY 8 rows (a)-(e)
-(`complete_unseen_by='optimize'`, `texture_gen_method='linear'`) raise NotImplementedError instead of silently doing
-something else; `complete_unseen_by='unproject'`, `optimize_from=None` is the measured path.
+(/root/reference/demo.py:38-253).  Built: texture_gen_method 'nearest' / 'linear' / 'DDNM_inpaint', complete_unseen_by
+'unproject' / 'neighbor', optimize_from None / 'scratch' / 'naive' / 'ours'.  Not built, and refused with NotImplementedError instead
+of silently doing something else: `complete_unseen_by='optimize'` (a per-shape TextureField training loop, outside SURVEY 8) and
+`refine_point_validation_by_remove_abnormal_depth` (cv2 blob heuristics, off in every shipped config).  The measured path of
+bench.py is `complete_unseen_by='unproject'`, `optimize_from=None`.
 """
 import torch
 
