@@ -155,7 +155,14 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
     const int r16 = lane & 15, g4 = lane >> 4;
     const int heads = C / D;
     const float scale2l = scale2 * 1.4426950408889634f;            // softmax in the log2 domain: exp(x) = 2^(x log2 e)
-    const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8 (private L2).  All T / 128 query blocks of one (image, head) read the same
+    // K / V^T, so they are given CONSECUTIVE slots of ONE XCD -- with the query block as the fastest grid index the 8 query blocks
+    // of a head at 32x32 landed on 8 different XCDs and every L2 fetched the same K / V^T (3.2x the algorithmic HBM reads,
+    // profiles/r02_pmc_kernels.json).  N * heads is a multiple of 8 (8 or 16 heads).
+    const int nqb = T >> 7;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qb = slot % nqb, grp = (slot / nqb) * 8 + xcd;           // grp = n * heads + h
+    const int n = grp / heads, h = grp - n * heads;
     const size_t row_stride = (size_t)3 * C;
     const half_t* base = qkv + (size_t)n * T * row_stride + (size_t)h * 3 * D;
     const half_t* vbase = vt + (((size_t)n * heads + h) * D) * T;
@@ -279,9 +286,10 @@ int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStr
     PD_REQUIRE(D == 64 || D == 32, "attention: head dim must be 32 or 64 (got %d)", D);
     PD_REQUIRE(C % D == 0 && T % QT == 0, "attention: need C %% D == 0 and T %% 64 == 0 (T=%d C=%d)", T, C);
     const float scale2 = 1.0f / sqrtf((float)D);
-    if (vt_ws != nullptr && D == 64 && T % 128 == 0) {
+    if (vt_ws != nullptr && D == 64 && T % 128 == 0 && (N * (C / D)) % 8 == 0) {
         k_transpose_v<<<dim3(T / 64, C / D, N), 256, 0, s>>>(qkv, vt_ws, T, C, D);
-        k_attention_t64<<<dim3(T / 128, C / D, N), 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
+        PD_REQUIRE((N * (C / D)) % 8 == 0, "attention: N * heads must be a multiple of 8");
+        k_attention_t64<<<(T / 128) * (C / D) * N, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
         PD_LAUNCH_CHECK();
         return PDHIP_OK;
     }
