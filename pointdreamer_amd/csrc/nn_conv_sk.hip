@@ -36,6 +36,22 @@ __device__ __forceinline__ int sk_swz(int row) { return (row >> 1) & 7; }       
 __device__ unsigned long long g_sk_stamps[8 * 64];
 #define SK_CLK() __builtin_readcyclecounter()
 #endif
+// s_waitcnt lgkmcnt(n) for a compile-time-unrolled n in [0, 15], tying the A fragment and the B fragments of the group to the wait
+// ("+v": the MFMAs that read them cannot be scheduled above it -- cdna guide section 5.7, form (ii))
+template <int TN_>
+__device__ __forceinline__ void sk_wait_lgkm_tied(int n, half8& a, half8 (&b)[TN_]) {
+#define SK_W(NN)                                                                                                  \
+    case NN:                                                                                                      \
+        if constexpr (TN_ == 4) asm volatile("s_waitcnt lgkmcnt(" #NN ")" : "+v"(a), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3 % TN_])); \
+        else if constexpr (TN_ == 2) asm volatile("s_waitcnt lgkmcnt(" #NN ")" : "+v"(a), "+v"(b[0]), "+v"(b[1 % TN_]));                     \
+        else asm volatile("s_waitcnt lgkmcnt(" #NN ")" : "+v"(a), "+v"(b[0]));                                   \
+        break;
+    switch (n) {
+        SK_W(0) SK_W(1) SK_W(2) SK_W(3) SK_W(4) SK_W(5) SK_W(6) SK_W(7) SK_W(8) SK_W(9) SK_W(10) SK_W(11) SK_W(12) SK_W(13) SK_W(14) SK_W(15)
+        default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b[0])); break;
+    }
+#undef SK_W
+}
 template <int N> __device__ __forceinline__ void sk_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // grid: total_tiles * splits workgroups (1-D) of KG * 256 threads.  tickets[tile] must be zero at launch; the last arriver resets it.
@@ -44,8 +60,12 @@ template <int N> __device__ __forceinline__ void sk_wait_vm() { asm volatile("s_
 // serial chain -- LDS-DMA issue (~80 cycles of blocked issue slot per 1 KiB piece: 250-650 cycles), fragment reads, 2-32 MFMAs
 // (tools/lab_sk.sh stamp: 800 cycles per step for the 64x32 tile, 1 600 for 128x128, at one wave per SIMD) -- so a second / fourth
 // wave per SIMD working on ANOTHER K-step is what overlaps it, without a second workgroup's slab traffic.
-template <int TAPS, int BM, int BN, int NST, int KG>
-__global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
+// LS ("loader-specialised", KG == 1): the workgroup has EIGHT waves -- waves 0-3 only run the fragment reads + MFMAs of the tile
+// (2x2 as before), waves 4-7 only issue the LDS-DMA pieces (wave 4 + w stages what wave w staged): a SIMD then holds one compute
+// wave and one loader wave, and the ~80 cycles a wave's issue slot is blocked per LDS-DMA piece (640 of a 128x128 step's 1 600
+// cycles) run beside the MFMAs of the partner instead of in front of them.
+template <int TAPS, int BM, int BN, int NST, int KG, bool LS>
+__global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
                                                       const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int W, int Cin,
                                                       int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
@@ -57,7 +77,8 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int CS_LD = BN + 8;
     constexpr int D = NST - 1;                         // prefetch distance
-    constexpr int NT = KG * 256;
+    static_assert(!LS || KG == 1, "loader specialisation replaces the K-groups");
+    constexpr int NT = (LS ? 2 : KG) * 256;
     constexpr int RING_BYTES = NST * STAGE_BYTES;
     constexpr int FLAG_OFF = KG * RING_BYTES;          // "I drew the last ticket" (ONE __shared__ object: cdna guide section 5 trap 4a)
     static_assert(NST >= 2 && NST <= 8 && OPS * (NST - 2) <= 63, "stage count / vmcnt range");
@@ -66,7 +87,8 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (provably wave-uniform: LDS-DMA bases stay in SGPRs)
-    const int grp = wave >> 2, w4 = wave & 3, t4 = tid & 255;
+    const int grp = LS ? 0 : wave >> 2, w4 = wave & 3, t4 = tid & 255;
+    const bool loader = !LS || wave >= 4, consumer = !LS || wave < 4;      // LS: the role of this wave
     const int wm = w4 >> 1, wn = w4 & 1;
     // XCD-aware work id: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (tile, split) ids, so the K-slices of a
     // tile and the n-tiles sharing an activation tile sit on one L2
@@ -157,9 +179,11 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     if (TAPS == 1) is_nc = g0; else { is_tap = g0 / kc; is_nc = g0 - is_tap * kc; }
     const int mine = g0 < it1 ? (it1 - g0 + KG - 1) / KG : 0;
     const int iters = (it1 - it0 + KG - 1) / KG;
+    if (loader) {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < mine) issue(d, g0 + d * KG);
+        for (int d = 0; d < D; ++d)
+            if (d < mine) issue(d, g0 + d * KG);
+    }
     int cur = 0, nxt = D % NST;
 #ifdef PD_LAB_SK_STAMP
     unsigned long long lab_w = 0, lab_b = 0, lab_i = 0, lab_c = 0, lab_t, lab_u;
@@ -192,51 +216,52 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
         // doing the same thing behind the common barrier just queue at the LDS-DMA port and then at the matrix pipe.
         // (measured, tools/bench_sk.py: worth 3-7 % on the 128x64 ... 64x32 tiles; the 128x128 tile is 7 % faster in lock-step)
         const bool issue_first = KG == 1 || (grp & 1) == 0 || (BM == 128 && BN == 128);
-        if (issue_first && k + D < mine) issue(nxt, g0 + (k + D) * KG);
+        if (loader && issue_first && k + D < mine) issue(nxt, g0 + (k + D) * KG);
 #ifdef PD_LAB_SK_STAMP
         lab_u = SK_CLK(); lab_i += lab_u - lab_t; lab_t = lab_u;
 #endif
-        if (k < mine) {
-            const char* As = ring + cur * STAGE_BYTES + (wm * (BM / 2)) * ROWB;
-            const char* Bs = ring + cur * STAGE_BYTES + A_BYTES + (wn * (BN / 2)) * ROWB;
+        if (consumer && k < mine) {
+            // All 2 (TM + TN) fragment reads of the K-step are issued at once (inline asm: hipcc waits lgkmcnt(0) in front of every
+            // batch of MFMAs, which left one compute wave per SIMD exposed to four LDS round trips per step -- 1 017 cycles for the
+            // 544 cycles of a 128x128 step's MFMAs, tools/lab_sk.sh stamp); the MFMA groups then follow the reads with counted waits
+            // (LDS returns in issue order: group (kk, i) may leave the reads issued after its own A fragment in flight).
+            const uint32_t a_ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + cur * STAGE_BYTES + (wm * (BM / 2)) * ROWB);
+            const uint32_t b_ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + cur * STAGE_BYTES + A_BYTES + (wn * (BN / 2)) * ROWB);
+            half8 fa[2][TM], fb[2][TN];
+            constexpr int RPK = TM + TN, RTOT = 2 * RPK;
+#define SK_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                half8 a[TM], b[TN];
-#ifdef PD_LAB_SK_NOLDS                                     // (lab builds only: fragments from registers)
+                const uint32_t ba = b_ad + frag_off[kk], aa = a_ad + frag_off[kk];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) { b[j] = (half8){(half_t)j, 1, 2, 3, 4, 5, 6, (half_t)lane}; asm volatile("" : "+v"(b[j])); }
+                for (int j = 0; j < TN; ++j) SK_DSR(fb[kk][j], ba, j * 16 * ROWB);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) { a[i] = (half8){(half_t)i, 1, 2, 3, 4, 5, 6, (half_t)kk}; asm volatile("" : "+v"(a[i])); }
-#else
+                for (int i = 0; i < TM; ++i) SK_DSR(fa[kk][i], aa, i * 16 * ROWB);
+            }
+#undef SK_DSR
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const half8*>(Bs + j * 16 * ROWB + frag_off[kk]);
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const half8*>(As + i * 16 * ROWB + frag_off[kk]);
-#endif
-#ifndef PD_LAB_SK_NOMFMA
+                for (int i = 0; i < TM; ++i) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int idx = kk * RPK + TN + i;                      // issue index of this group's A fragment
+                    sk_wait_lgkm_tied<TN>(RTOT - 1 - idx, fa[kk][i], fb[kk]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
-#else
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) { acc[i][j][0] += (float)a[i][0] + (float)b[j][0]; }
-#endif
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                }
             }
         }
 #ifdef PD_LAB_SK_STAMP
         asm volatile("" : "+v"(acc[0][0]));
         lab_u = SK_CLK(); lab_c += lab_u - lab_t;
 #endif
-        if (!issue_first && k + D < mine) issue(nxt, g0 + (k + D) * KG);
+        if (loader && !issue_first && k + D < mine) issue(nxt, g0 + (k + D) * KG);
         cur = (cur + 1 == NST) ? 0 : cur + 1;
         nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
     }
 #ifdef PD_LAB_SK_STAMP
-    if (lane == 0 && (blockIdx.x == 8 || blockIdx.x == 100) && wave < 4) {
-        unsigned long long* o = g_sk_stamps + ((blockIdx.x == 8 ? 0 : 4) + wave) * 8;
+    if (lane == 0 && blockIdx.x == 8 && wave < 8) {
+        unsigned long long* o = g_sk_stamps + wave * 8;
         o[0] = lab_w; o[1] = lab_b; o[2] = lab_i; o[3] = lab_c; o[4] = SK_CLK() - lab_start; o[5] = iters; o[6] = lab_start;
     }
 #endif
@@ -270,7 +295,7 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
         constexpr int F = TM * TN;                         // float4 pieces per thread
         constexpr int SLAB_BYTES = BM * BN * 4;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)tile * splits * (BM * BN), 0, splits * SLAB_BYTES, 0x00020000);
-        if (grp == 0) {
+        if (grp == 0 && consumer) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -291,7 +316,7 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
         if (*flag == 0) return;
         // the last arriver: sum the slices in slice order (its own included -- the order must not depend on who is last);
         // U slices' loads in flight at a time, clamped index + conditional add (no branch around a load: cdna guide trap 4c)
-        if (grp == 0) {
+        if (grp == 0 && consumer) {
             constexpr int U = 16 / F >= 1 ? 16 / F : 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     // ---- epilogue: acc (+bias) -> f16 -> LDS [BM][CS_LD] -> coalesced 16-byte rows (+residual) + GroupNorm octet partials.
     // Transposed accumulators (weights x activations): lane holds pixel 16 i + (lane & 15), channels 16 j + 4 (lane >> 4) + 0..3
     half_t* Cs = reinterpret_cast<half_t*>(smem);
-    if (grp == 0) {
+    if (grp == 0 && consumer) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
@@ -389,15 +414,15 @@ __global__ __launch_bounds__(KG * 256) void k_conv_sk(const half_t* __restrict__
     }
 }
 
-template <int TAPS, int BM, int BN, int NST, int KG>
+template <int TAPS, int BM, int BN, int NST, int KG, bool LS = false>
 int launch_sk(int grid, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
               int W, int Cin, int Cout, int n_tiles, int total, const half_t* zero_page, int splits, float* slabs, unsigned* tickets,
               float* gnp, const half_t* X2, int Cin1) {
-    auto kern = k_conv_sk<TAPS, BM, BN, NST, KG>;
+    auto kern = k_conv_sk<TAPS, BM, BN, NST, KG, LS>;
     constexpr size_t smem = (size_t)KG * NST * (BM + BN) * 128 + 16;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, KG * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1);
+    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -440,6 +465,9 @@ SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
         ps = g_sk_splits >= 1 ? g_sk_splits : 1;
     } else {
         if (g_sk_mode != 2 && ok[0] && tiles[0] > 640) return p;   // enough 128x128 tiles: the big-tile kernels own that regime
+        // (long K loops amortise a two-slice combine: 128 tiles of 128x128 x 2 slices beat 256 unsplit 128x64 tiles at K = 9216 --
+        // 50 vs 55 us at 16^2 batch 8 -- and lose at K = 4608, 31 vs 29 us at 64^2 batch 1)
+        if (taps == 9 && KI >= 128 && ok[0] && tiles[0] >= 112 && tiles[0] < 224) { pick = 0; ps = 2; }
         for (int t = 0; t < 4 && pick < 0; ++t)
             if (ok[t] && tiles[t] >= 224) { pick = t; ps = 1; }
         if (pick < 0 && taps == 9) {
@@ -486,8 +514,20 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     // K-groups: two (four for long unsplit loops of the 64x32 tile) when the launch is ONE round of workgroups -- they are what puts a
     // second wave on every SIMD; with >= 1.5 rounds co-resident workgroups do that already and the lock-step of the groups only
     // costs (tools/bench_sk.py, 512 tiles of 128x128: 148 us with one group, 184 with two)
-    if (kg == 0) kg = grid >= 384 ? 1 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
+    // The 128x128 tile takes the loader-specialised form instead (8): 26.2 vs 26.8 us at 128^2 batch 1, 42.4 vs 44.3 at 32^2 batch 8.
+    if (kg == 0) kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 8 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
 #define SK_L(T, BM_, BN_, NST_, KG_) launch_sk<T, BM_, BN_, NST_, KG_>(SK_ARGS)
+#define SK_LS(T, BM_, BN_, NST_) launch_sk<T, BM_, BN_, NST_, 1, true>(SK_ARGS)
+    if (kg == 8) {                                         // loader-specialised form (hook value 8)
+        if (taps == 9) return pl.tile_id == 1 ? (st == 2 ? SK_LS(9, 128, 128, 2) : st == 4 ? SK_LS(9, 128, 128, 4) : SK_LS(9, 128, 128, 3))
+                            : pl.tile_id == 2 ? (st == 2 ? SK_LS(9, 128, 64, 2) : st == 3 ? SK_LS(9, 128, 64, 3) : SK_LS(9, 128, 64, 4))
+                            : pl.tile_id == 3 ? (st == 2 ? SK_LS(9, 64, 64, 2) : st == 6 ? SK_LS(9, 64, 64, 6) : SK_LS(9, 64, 64, 4))
+                                              : (st == 2 ? SK_LS(9, 64, 32, 2) : st == 6 ? SK_LS(9, 64, 32, 6) : SK_LS(9, 64, 32, 4));
+        return pl.tile_id == 1 ? (st == 2 ? SK_LS(1, 128, 128, 2) : st == 4 ? SK_LS(1, 128, 128, 4) : SK_LS(1, 128, 128, 3))
+             : pl.tile_id == 2 ? (st == 2 ? SK_LS(1, 128, 64, 2) : st == 3 ? SK_LS(1, 128, 64, 3) : SK_LS(1, 128, 64, 4))
+             : pl.tile_id == 3 ? (st == 2 ? SK_LS(1, 64, 64, 2) : st == 6 ? SK_LS(1, 64, 64, 6) : SK_LS(1, 64, 64, 4))
+                               : (st == 2 ? SK_LS(1, 64, 32, 2) : st == 6 ? SK_LS(1, 64, 32, 6) : SK_LS(1, 64, 32, 4));
+    }
 #define SK_TILE(T)                                                                                                                   \
     (pl.tile_id == 1 ? (kg == 1 ? (st == 3 ? SK_L(T, 128, 128, 3, 1) : st == 4 ? SK_L(T, 128, 128, 4, 1) : SK_L(T, 128, 128, 2, 1)) : SK_L(T, 128, 128, 2, 2))        \
      : pl.tile_id == 2 ? (kg == 1 ? (st == 2 ? SK_L(T, 128, 64, 2, 1) : st == 4 ? SK_L(T, 128, 64, 4, 1) : SK_L(T, 128, 64, 3, 1))                                   \
@@ -499,6 +539,7 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     return taps == 9 ? SK_TILE(9) : SK_TILE(1);
 #undef SK_TILE
 #undef SK_L
+#undef SK_LS
 #undef SK_ARGS
 }
 
