@@ -135,7 +135,7 @@ def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, 
         uvs = pre['uv_scales'] if torch.is_tensor(pre['uv_scales']) else torch.full((v, 1, 1), float(pre['uv_scales'] or 2.0), device=dev)
         sf = pre['scale_factors'] if torch.is_tensor(pre['scale_factors']) else torch.ones((v,), device=dev)
         rec = pack_view_records(local, vis_l, pk_l, uvc, uvs, sf)
-        rec = all_gather_views(rec, view_num, rank, world, group, force_collective)  # the one collective
+        rec = all_gather_views(rec, view_num, rank, world, group, **({'force_collective': True} if force_collective else {}))  # the one collective
         inpainted, vis, per_kernel, uvc_a, uvs_a, sf_a = unpack_view_records(rec, tuple(local.shape[1:]), A, K)
         pre_all = dict(uv_centers=uvc_a, uv_scales=uvs_a, padding=pre['padding'], scale_factors=sf_a, mesh_depths=None)
         atlas = st['after'](pre_all, inpainted, vis, per_kernel, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,
