@@ -43,7 +43,7 @@ SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
 int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
             int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* ws, size_t ws_floats, float* gn_part,
             int* gn_fused, const half_t* X2, int Cin1);
-extern thread_local int g_sk_mode, g_sk_tile, g_sk_splits, g_sk_stages, g_sk_kg;                         // tuning / test hooks (pdhip_debug_set_conv_sk)
+extern thread_local int g_sk_mode, g_sk_tile, g_sk_splits, g_sk_stages, g_sk_kg, g_sk_order;                         // tuning / test hooks (pdhip_debug_set_conv_sk)
 #define PD_SK_TICKET_FLOATS 4096
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
 // the two tensors of a channel concat (A: Ca channels, B: Cb channels), into GroupNorm(32) stats [N][32][2] (mean, rstd).

@@ -69,7 +69,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
                                                       const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int W, int Cin,
                                                       int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
-                                                      const half_t* __restrict__ X2, int Cin1) {
+                                                      const half_t* __restrict__ X2, int Cin1, int m_fast) {
     constexpr int ROWB = 128, RPI = 8;                 // bytes per tile row (K-step 64), rows per 1 KiB wave-instruction
     constexpr int LPO = BM / 32, LPB = BN / 32;        // LDS-DMA pieces per wave per K-step: activation rows, weight rows
     constexpr int OPS = LPO + LPB;
@@ -99,7 +99,11 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
         wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
     const int tile = wid / splits, split = wid - tile * splits;
-    const int m0 = (tile / n_tiles) * BM, n0 = (tile % n_tiles) * BN;
+    // tile order inside an XCD's run: n-tiles of one pixel tile back-to-back (they share the activation tile), or -- m_fast, the
+    // weight-heavy layers of the 16^2 / 8^2 levels, 19-38 MB of weights against <= 4 MB of activations -- the pixel tiles of one
+    // n-tile back-to-back, so that a weight slice is fetched from HBM once and its other readers hit the XCD's L2
+    const int m_tiles = total_tiles / n_tiles;
+    const int m0 = (m_fast ? tile % m_tiles : tile / n_tiles) * BM, n0 = (m_fast ? tile / m_tiles : tile % n_tiles) * BN;
     const int M = N * H * W, HWp = H * W;              // (host: M < 2^31)
     const int K = TAPS * Cin;
     const int kc = Cin >> 6;                           // K-steps per tap
@@ -417,12 +421,12 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
 template <int TAPS, int BM, int BN, int NST, int KG, bool LS = false>
 int launch_sk(int grid, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
               int W, int Cin, int Cout, int n_tiles, int total, const half_t* zero_page, int splits, float* slabs, unsigned* tickets,
-              float* gnp, const half_t* X2, int Cin1) {
+              float* gnp, const half_t* X2, int Cin1, int m_fast) {
     auto kern = k_conv_sk<TAPS, BM, BN, NST, KG, LS>;
     constexpr size_t smem = (size_t)KG * NST * (BM + BN) * 128 + 16;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1);
+    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -438,7 +442,8 @@ thread_local int g_sk_mode = 1;        // tuning / test hook: 0 = never route to
 thread_local int g_sk_tile = 0;        // tuning hook: 0 = automatic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x32
 thread_local int g_sk_splits = 0;      // tuning hook: >= 1 forces the split factor
 thread_local int g_sk_stages = 0;      // lab hook: LDS stages per K-group (2, 3, 4 where the tile allows); 0 = default
-thread_local int g_sk_kg = 0;          // lab hook: K-groups per workgroup (1, 2, 4); 0 = default
+thread_local int g_sk_kg = 0;          // lab hook: K-groups per workgroup (1, 2, 4; 8 = loader-specialised); 0 = default
+thread_local int g_sk_order = 0;       // lab hook: tile order inside an XCD's run: 0 automatic, 1 pixel tiles fastest, 2 n-tiles fastest
 
 // the plan for one layer; bm == 0: not a layer for this kernel.  Rules read off tools/bench_sk.py tables (profiles/r03_sk_bench.txt):
 //   * a tile shape whose tiles alone fill the chip (>= 224) runs unsplit -- the largest such shape (fewest L2 -> LDS bytes);
@@ -468,8 +473,11 @@ SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
         // (long K loops amortise a two-slice combine: 128 tiles of 128x128 x 2 slices beat 256 unsplit 128x64 tiles at K = 9216 --
         // 50 vs 55 us at 16^2 batch 8 -- and lose at K = 4608, 31 vs 29 us at 64^2 batch 1)
         if (taps == 9 && KI >= 128 && ok[0] && tiles[0] >= 112 && tiles[0] < 224) { pick = 0; ps = 2; }
+        // (a weight-heavy layer re-reads its 19-38 MB of weights once per PIXEL tile: 64-row tiles double that traffic -- 39 us unsplit
+        // on 64x32 tiles against 24 us on 128x64 tiles x 4 slices at the 8^2 level, batch 8)
+        const bool heavy = (size_t)Cout_pad * taps * Cin * 2 >= ((size_t)8 << 20) && M >= 256;
         for (int t = 0; t < 4 && pick < 0; ++t)
-            if (ok[t] && tiles[t] >= 224) { pick = t; ps = 1; }
+            if (ok[t] && tiles[t] >= 224 && !(heavy && BMs[t] == 64 && (ok[0] || ok[1]))) { pick = t; ps = 1; }
         if (pick < 0 && taps == 9) {
             for (int t = 0; t < 4 && pick < 0; ++t) {
                 const int s = (int)((256 + tiles[t] / 2) / std::max<long long>(tiles[t], 1));
@@ -507,7 +515,10 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     float* slabs = ws ? ws + PD_SK_TICKET_FLOATS : nullptr;
     if (gn_fused) *gn_fused = gn_part ? std::max((int)(((long long)H * W) / pl.bm), 1) : 0;
     const int grid = total * pl.splits;
-#define SK_ARGS grid, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, X2, Cin1
+    // (lab hook only: sharing the weight slices of the weight-heavy 16^2 / 8^2 layers through one L2 measured no better than the
+    // default order -- the 256 MB Infinity Cache already absorbs the re-reads -- and 18 % worse at 512 tiles; profiles/r03_sk_bench.txt)
+    const int m_fast = g_sk_order == 1 && m_tiles > 1 ? 1 : 0;
+#define SK_ARGS grid, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, X2, Cin1, m_fast
     // (lab hooks: K-groups g_sk_kg, stages g_sk_stages; 0 = the tile's default)
     int kg = g_sk_kg;
     const int st = g_sk_stages;

@@ -791,6 +791,7 @@ extern "C" int pdhip_debug_set_conv_sk(int mode, int tile, int splits) {
 }
 extern "C" int pdhip_debug_set_conv_sk_stages(int stages) { int old = pdnn::g_sk_stages; pdnn::g_sk_stages = stages; return old; }
 extern "C" int pdhip_debug_set_conv_sk_kgroups(int kg) { int old = pdnn::g_sk_kg; pdnn::g_sk_kg = kg; return old; }
+extern "C" int pdhip_debug_set_conv_sk_order(int order) { int old = pdnn::g_sk_order; pdnn::g_sk_order = order; return old; }
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }

@@ -19,6 +19,7 @@ ap.add_argument('--tiles', type=int, nargs='*', default=[1, 2, 3, 4])
 ap.add_argument('--splits', type=int, nargs='*', default=[0, 1, 2, 4, 8, 16, 32])
 ap.add_argument('--stages', type=int, nargs='*', default=[0])
 ap.add_argument('--kg', type=int, nargs='*', default=[0])
+ap.add_argument('--order', type=int, default=0, help='tile order hook: 0 auto, 1 pixel tiles fastest, 2 n-tiles fastest')
 ap.add_argument('--iters', type=int, default=30)
 ap.add_argument('--fixed', action='store_true')
 ap.add_argument('--stamps', action='store_true', help='lab stamp build: print the per-wave loop time split of the last launch')
@@ -27,6 +28,7 @@ a = ap.parse_args()
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 L = _lib.lib()
+L.pdhip_debug_set_conv_sk_order(a.order)
 dev = 'cuda:0'
 zp = torch.zeros(128, dtype=torch.float16, device=dev)
 ws = torch.zeros((4096 + 64 * 1024 * 1024,), dtype=torch.float32, device=dev)
