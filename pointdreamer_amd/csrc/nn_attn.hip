@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const half8*>(base + (size_t)q * row_stride + ks * 32 + g4 * 8);
     }
+    (void)scale2l;
     float4_t o[2][4];
     float mrun[2], lrun[2];
 #pragma unroll
@@ -230,7 +231,6 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mnew = fmaxf(mrun[qt], mx);
-            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -238,12 +238,19 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
                 for (int r = 0; r < 4; ++r) { st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - mnew); sum += st[kt][r]; }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
-            lrun[qt] = lrun[qt] * alpha + sum;
+            // lazy rescale: the running maximum of a query stops moving after its first few key chunks -- when no lane's maximum grew
+            // (wave-uniform test) alpha is exactly 1 for every lane and the 16 multiplies of O and the exp2 are skipped
+            if (__builtin_amdgcn_ballot_w64(mnew > mrun[qt]) != 0ull) {
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+                lrun[qt] = lrun[qt] * alpha + sum;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
+            } else {
+                lrun[qt] += sum;
+            }
             mrun[qt] = mnew;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
