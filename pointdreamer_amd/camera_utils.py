@@ -62,19 +62,43 @@ def stack_params(cams):
     return _lib.memo([c.params for c in cams], 'stack_params', lambda ps: torch.stack(list(ps), 0).contiguous())
 
 
+def _dodecahedron():
+    phi = (1 + math.sqrt(5)) / 2.
+    return np.array([[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1, 1], [1, 1, 1], [-1, 1, 1],
+                     [0, -phi, -1 / phi], [0, -phi, 1 / phi], [0, phi, -1 / phi], [0, phi, 1 / phi],
+                     [-1 / phi, 0, -phi], [-1 / phi, 0, phi], [1 / phi, 0, -phi], [1 / phi, 0, phi],
+                     [-phi, -1 / phi, 0], [-phi, 1 / phi, 0], [phi, -1 / phi, 0], [phi, 1 / phi, 0]]).astype(float)
+
+
 def create_cameras(num_views=8, distance=1.6, res=512, distribution='fibonacci_sphere',
                    device=torch.device('cuda'), vis=False):
     """Same return contract as the reference: cams, base_dirs[V,3], eye_positions (numpy), up_dirs[V,3]."""
-    if distribution != 'fibonacci_sphere':
-        raise NotImplementedError("only camera_distribution='fibonacci_sphere' (every shipped config) is built")
-    eyes = fibonacci_sphere(num_views, distance)
+    if distribution not in ('fibonacci_sphere', 'self_defined', 'blender', 'exact_blender'):
+        raise ValueError(f"camera distribution {distribution!r} (camera_utils.py:129: fibonacci_sphere, self_defined, blender, exact_blender)")
+    fov = math.pi * 45 / 180
+    if distribution == 'fibonacci_sphere':
+        eyes = fibonacci_sphere(num_views, distance)
+    elif distribution in ('blender', 'exact_blender'):
+        # camera_utils.py:132-164: the 20 vertices of a dodecahedron, 1.2 x its circumradius away, y-up -> z-up; always 20 views
+        num_views = 20
+        eyes = (_dodecahedron() * 1.2).dot(np.array([[1, 0, 0], [0, 0, 1], [0, -1, 0.0]]).T)
+        if distribution == 'exact_blender':
+            fov = 0.8575560450553894
+    else:
+        # camera_utils.py:165-201: six axis views at `distance`, or the raw dodecahedron vertices
+        if num_views == 6:
+            eyes = distance * np.array([[0, 0, -1.0], [0, 0, 1.0], [0, -1.0, 0], [0, 1.0, 0], [-1.0, 0, 0], [1.0, 0, 0]])
+        elif num_views == 20:
+            eyes = _dodecahedron()
+        else:
+            raise ValueError("camera distribution 'self_defined' knows 6 or 20 views (camera_utils.py:165-201)")
     cams = []
     base_dirs = torch.zeros((num_views, 3), dtype=torch.float32)
     up_dirs = torch.zeros((num_views, 3), dtype=torch.float32)
     at = np.array([0, 0, 0])
     for i, eye in enumerate(eyes):
         up = calculate_up_vector(eye, at)
-        cams.append(Camera(look_at_params(eye, at, up), res, device))
+        cams.append(Camera(look_at_params(eye, at, up, fov=fov), res, device))
         base_dirs[i] = torch.tensor(eye - at).float()
         up_dirs[i] = torch.tensor(up).float()
     return cams, base_dirs.to(device), eyes, up_dirs.to(device)
