@@ -150,6 +150,7 @@ size_t pdhip_linear_fill_ws_bytes(int B, int H, int W);
 int pdhip_linear_fill(const float* img, float* out, int B, int C, int H, int W, const void* mask, int mask_is_f32,
                       int64_t mask_batch_stride, void* ws, int32_t* tri, void* stream);
 int pdhip_linear_fill_unresolved(const void* ws, int B, int H, int W, int* out, void* stream);
+int pdhip_debug_set_linear_local(int on);   /* tuning / test hook: 1 (default) = local 16x16-tile window pass first, global scans only for what it cannot certify; 0 = global scans only */
 
 /* ---- Uq1+Uq2: unproject.unproject texel transform + depth visibility (unproject.py:219-284).
  *      visibility[V,A,A] u8 (0 outside the chart mask). */

@@ -29,7 +29,8 @@ __device__ __forceinline__ double orient(i2 a, i2 b, i2 c) { return (b.x - a.x) 
 // per image: sites (x, y, x^2 + y^2 as f32 -- exact below 2^24) in row-major order, queries (pixel index) likewise
 __global__ __launch_bounds__(1024) void k_linear_collect(const void* __restrict__ mask, int mask_is_f32, int64_t mask_bstride, int H,
                                                          int W, float* __restrict__ sites /*[B][3][H*W]*/, int* __restrict__ qlist /*[B][H*W]*/,
-                                                         int* __restrict__ counts /*[B][2]*/) {
+                                                         int* __restrict__ counts /*[B][2]*/, int* __restrict__ rowstart /*[B][H+1] or null*/,
+                                                         int* __restrict__ fbcount /*[B][2] or null*/, int make_qlist) {
     __shared__ int s_s[16], s_q[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = H * W;
@@ -52,11 +53,16 @@ __global__ __launch_bounds__(1024) void k_linear_collect(const void* __restrict_
             const int y = i / W, x = i - y * W;
             sx[pos] = (float)x; sx[n + pos] = (float)y; sx[2 * (size_t)n + pos] = (float)(x * x + y * y);
         }
-        if (qry) qlist[(size_t)b * n + pq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
+        if (qry && make_qlist) qlist[(size_t)b * n + pq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
+        if (rowstart != nullptr && i < n && i % W == 0) rowstart[(size_t)b * (H + 1) + i / W] = ps + __popcll(bs & ((1ull << lane) - 1ull));
         base_s += ts; base_q += tq;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { counts[2 * b] = base_s; counts[2 * b + 1] = base_q; }
+    if (threadIdx.x == 0) {
+        counts[2 * b] = base_s; counts[2 * b + 1] = base_q;
+        if (rowstart != nullptr) rowstart[(size_t)b * (H + 1) + H] = base_s;
+        if (fbcount != nullptr) { fbcount[2 * b] = base_s; fbcount[2 * b + 1] = 0; }
+    }
 }
 
 // sites copy themselves
@@ -226,6 +232,192 @@ __global__ __launch_bounds__(256, 2) void k_linear_tri(const float* __restrict__
     }
 }
 
+// ---- local first pass (round 3).  The reference's images are dense in sites (background + splatted points), so the Delaunay triangle
+// of an unknown pixel is a LOCAL object; the global kernel above streams all ~50 k sites of an image ~20 times per query batch
+// (58 ms for 8 views).  Here one wavefront owns a 16 x 16 pixel tile: it gathers the sites of the tile's window (tile +- LW pixels,
+// row-major order preserved: the tie rules stay those of the global scan) into LDS once, and runs the same two phases for the
+// tile's queries against the window only.  A triangle found this way is accepted iff its circumcircle stays clear of every pixel
+// column / row OUTSIDE the window (conservative f64 test, or the window side is the image border): then "no window site inside
+// the circumcircle" is "no site inside" and the triangle is a Delaunay triangle of the whole image.  Everything else -- circle
+// leaving the window, query outside / on the hull of the window's sites, window overflow -- goes to the global kernel through a
+// fallback list.  Same exact integer predicates in f64.
+#define LW 16                          // window margin (pixels)
+#define LT 16                          // tile edge
+#define LCAP ((LT + 2 * LW) * (LT + 2 * LW))
+__global__ __launch_bounds__(256) void k_linear_local(const float* __restrict__ img, float* __restrict__ out, int C, int H, int W,
+                                                      const void* __restrict__ mask, int mask_is_f32, int64_t mask_bstride,
+                                                      const int* __restrict__ rowstart /*[B][H+1]*/, int32_t* __restrict__ tri,
+                                                      int* __restrict__ fbq /*[B][H*W]*/, int* __restrict__ fbcount /*[B][2]: NS copy, count*/) {
+    __shared__ unsigned int s_site[4][LCAP];             // x | y << 16, window sites in row-major order
+    __shared__ unsigned short s_q[4][LT * LT];            // tile queries (x - tx0 | (y - ty0) << 8)
+    __shared__ double s_co[4][LQ][3];
+    const int b = blockIdx.y, n = H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (W + LT - 1) / LT, tiles_y = (H + LT - 1) / LT;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tiles_x * tiles_y) return;
+    const int tx0 = (tile % tiles_x) * LT, ty0 = (tile / tiles_x) * LT;
+    auto is_site = [&](int y, int x) -> bool {
+        const size_t i = (size_t)b * mask_bstride + (size_t)y * W + x;
+        return mask_is_f32 ? reinterpret_cast<const float*>(mask)[i] != 0.0f : reinterpret_cast<const uint8_t*>(mask)[i] != 0;
+    };
+    // ---- the tile's queries
+    int NQ = 0;
+    for (int i0 = 0; i0 < LT * LT; i0 += 64) {
+        const int i = i0 + lane, ly = i / LT, lx = i - ly * LT;
+        const bool qry = ty0 + ly < H && tx0 + lx < W && !is_site(ty0 + ly, tx0 + lx);
+        const unsigned long long bq = __ballot(qry);
+        if (qry) s_q[wave][NQ + __popcll(bq & ((1ull << lane) - 1ull))] = (unsigned short)(lx | (ly << 8));
+        NQ += __popcll(bq);
+    }
+    if (NQ == 0) return;
+    // ---- the window's sites (row-major)
+    const int wx0 = max(tx0 - LW, 0), wx1 = min(tx0 + LT + LW, W) - 1, wy0 = max(ty0 - LW, 0), wy1 = min(ty0 + LT + LW, H) - 1;
+    const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+    int NS = 0;
+    for (int i0 = 0; i0 < ww * wh; i0 += 64) {
+        const int i = i0 + lane, ly = i / ww, lx = i - ly * ww;
+        const bool st = i < ww * wh && is_site(wy0 + ly, wx0 + lx);
+        const unsigned long long bs = __ballot(st);
+        if (st) s_site[wave][NS + __popcll(bs & ((1ull << lane) - 1ull))] = (unsigned)(wx0 + lx) | ((unsigned)(wy0 + ly) << 16);
+        NS += __popcll(bs);
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int ST = 64 / LQ;
+    const int kq = lane / ST;
+    const bool slot = (lane % ST) == 0;
+    for (int q0 = 0; q0 < NQ; q0 += LQ) {
+        const bool owner = slot && q0 + kq < NQ;
+        const unsigned qp = owner ? s_q[wave][q0 + kq] : 0;
+        const int qxi = tx0 + (int)(qp & 255), qyi = ty0 + (int)(qp >> 8);
+        const int qi = qyi * W + qxi;
+        const i2 q = {(double)qxi, (double)qyi};
+        int phase = 0, dim = 0;
+        int state = owner ? (NS > 0 ? 0 : 2) : 3;        // 0 running, 1 done, 2 outside the window's hull, 3 idle, 4 on its boundary
+        i2 pa = {0, 0}, pb = {0, 0}, pc = {0, 0};
+        double A = 1.0, B = 0.0, Cc = 0.0, K = 0.0;
+        for (int round = 0; round < LIN_MAX_ROUNDS; ++round) {
+            if (__ballot(state == 0) == 0ull) break;
+            if (slot) { s_co[wave][kq][0] = A; s_co[wave][kq][1] = B; s_co[wave][kq][2] = Cc; }
+            __builtin_amdgcn_wave_barrier();
+            double ca[LQ], cb[LQ], cc[LQ], best[LQ];
+            int bi[LQ];
+#pragma unroll
+            for (int k = 0; k < LQ; ++k) { ca[k] = s_co[wave][k][0]; cb[k] = s_co[wave][k][1]; cc[k] = s_co[wave][k][2]; best[k] = -1.0e300; bi[k] = 0x7fffffff; }
+            for (int j = lane; j < NS; j += 64) {
+                const unsigned sp = s_site[wave][j];
+                const double x = (double)(sp & 0xffffu), y = (double)(sp >> 16), r2 = x * x + y * y;
+#pragma unroll
+                for (int k = 0; k < LQ; ++k) {
+                    const double val = (ca[k] * x + cb[k] * y) + cc[k] * r2;
+                    if (val > best[k]) { best[k] = val; bi[k] = j; }
+                }
+            }
+#define LIN_HALVE(I)                                                                                                  \
+            if constexpr ((LQ >> (I)) > 1) {                                                                          \
+                constexpr int off = 32 >> (I), nn = LQ >> (I);                                                        \
+                const bool hi = (lane & off) != 0;                                                                    \
+                _Pragma("unroll") for (int k = 0; k < nn / 2; ++k) {                                                  \
+                    const double send = hi ? best[k] : best[k + nn / 2], keep = hi ? best[k + nn / 2] : best[k];      \
+                    const int sendi = hi ? bi[k] : bi[k + nn / 2], keepi = hi ? bi[k + nn / 2] : bi[k];               \
+                    const double ob = __shfl_xor(send, off);                                                          \
+                    const int oi = __shfl_xor(sendi, off);                                                            \
+                    const bool take = ob > keep || (ob == keep && oi < keepi);                                        \
+                    best[k] = take ? ob : keep; bi[k] = take ? oi : keepi;                                            \
+                }                                                                                                     \
+            }
+            LIN_HALVE(0) LIN_HALVE(1) LIN_HALVE(2) LIN_HALVE(3)
+#undef LIN_HALVE
+#pragma unroll
+            for (int off = ST / 2; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best[0], off);
+                const int oi = __shfl_xor(bi[0], off);
+                if (ob > best[0] || (ob == best[0] && oi < bi[0])) { best[0] = ob; bi[0] = oi; }
+            }
+            if (state != 0) continue;
+            const unsigned sp = s_site[wave][bi[0]];
+            const i2 p = {(double)(sp & 0xffffu), (double)(sp >> 16)};
+            if (phase == 0) {
+                const double sv = best[0] - (A * q.x + B * q.y);
+                if (sv < 0.0) { state = 2; continue; }
+                if (sv == 0.0 && !(dim == 1 && (pa.x - q.x) * B == (pa.y - q.y) * A)) { state = 4; continue; }
+                if (dim == 0) { pa = p; A = -(p.x - q.x); B = -(p.y - q.y); dim = 1; continue; }
+                if (dim == 1) {
+                    pb = p;
+                    const double abx = pa.x - pb.x, aby = pa.y - pb.y;
+                    double px = -aby, py = abx;
+                    const double t = px * (q.x - pb.x) + py * (q.y - pb.y);
+                    if (t < 0.0) { px = -px; py = -py; }
+                    A = px; B = py; dim = 2; continue;
+                }
+                pc = p;
+                const double cbx = pb.x - pc.x, cby = pb.y - pc.y, cax = pa.x - pc.x, cay = pa.y - pc.y;
+                const double cox = q.x - pc.x, coy = q.y - pc.y;
+                double nbx = -cby, nby = cbx;
+                if (nbx * cax + nby * cay > 0.0) { nbx = -nbx; nby = -nby; }
+                double nax = -cay, nay = cax;
+                if (nax * cbx + nay * cby > 0.0) { nax = -nax; nay = -nay; }
+                if (nbx * cox + nby * coy > 0.0) { pa = pb; pb = pc; A = nbx; B = nby; continue; }
+                if (nax * cox + nay * coy > 0.0) { pb = pc; A = nax; B = nay; continue; }
+                if (orient(pa, pb, pc) == 0.0) { state = 2; continue; }
+                if (orient(pa, pb, pc) < 0.0) { const i2 tp = pb; pb = pc; pc = tp; }
+                phase = 1;
+            } else {
+                if (best[0] + K <= 0.0) { state = 1; continue; }
+                const i2 t0[3] = {p, pa, pa}, t1[3] = {pb, p, pb}, t2[3] = {pc, pc, p};
+                int pick = -1;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (pick >= 0) continue;
+                    if (orient(t0[k], t1[k], t2[k]) > 0.0 && orient(t0[k], t1[k], q) >= 0.0 && orient(t1[k], t2[k], q) >= 0.0 &&
+                        orient(t2[k], t0[k], q) >= 0.0) pick = k;
+                }
+                if (pick < 0) { state = 2; continue; }                                   // (cannot happen; the global kernel decides)
+                pa = t0[pick]; pb = t1[pick]; pc = t2[pick];
+            }
+            const double ar = pa.x * pa.x + pa.y * pa.y, br = pb.x * pb.x + pb.y * pb.y, cr = pc.x * pc.x + pc.y * pc.y;
+            const double ux = pb.x - pa.x, uy = pb.y - pa.y, uz = br - ar, vx = pc.x - pa.x, vy = pc.y - pa.y, vz = cr - ar;
+            const double Nx = uy * vz - uz * vy, Ny = uz * vx - ux * vz, Nz = ux * vy - uy * vx;
+            A = -Nx; B = -Ny; Cc = -Nz; K = (Nx * pa.x + Ny * pa.y) + Nz * ar;
+        }
+        if (!owner) continue;
+        bool accept = state == 1;
+        if (accept) {
+            // circumcircle of (a, b, c) against the window: centre = -(Nx, Ny) / (2 Nz) of the lifted plane, conservative margins
+            const double ar = pa.x * pa.x + pa.y * pa.y, br = pb.x * pb.x + pb.y * pb.y, cr = pc.x * pc.x + pc.y * pc.y;
+            const double d = 2.0 * orient(pa, pb, pc);
+            const double cx = (ar * (pb.y - pc.y) + br * (pc.y - pa.y) + cr * (pa.y - pb.y)) / d;
+            const double cy = (ar * (pc.x - pb.x) + br * (pa.x - pc.x) + cr * (pb.x - pa.x)) / d;
+            const double r = sqrt((pa.x - cx) * (pa.x - cx) + (pa.y - cy) * (pa.y - cy)) * (1.0 + 1e-9) + 1e-3;
+            accept = (wx0 == 0 || cx - r > (double)(wx0 - 1)) && (wx1 == W - 1 || cx + r < (double)(wx1 + 1)) &&
+                     (wy0 == 0 || cy - r > (double)(wy0 - 1)) && (wy1 == H - 1 || cy + r < (double)(wy1 + 1));
+        }
+        if (!accept) {
+            const int k = atomicAdd(fbcount + 2 * b + 1, 1);
+            fbq[(size_t)b * n + k] = qi;
+            continue;
+        }
+        float* o = out + (size_t)b * C * n + qi;
+        const float* im = img + (size_t)b * C * n;
+        if (tri) {
+            // site-list index (row-major rank) of a vertex: sites before its row + sites before it in the row (debug / test path)
+            auto rank = [&](i2 v) -> int {
+                int r = rowstart[(size_t)b * (H + 1) + (int)v.y];
+                for (int x = 0; x < (int)v.x; ++x) r += is_site((int)v.y, x) ? 1 : 0;
+                return r;
+            };
+            int32_t* t = tri + ((size_t)b * n + qi) * 3;
+            t[0] = rank(pa); t[1] = rank(pb); t[2] = rank(pc);
+        }
+        const int xa = (int)pa.y * W + (int)pa.x, xb = (int)pb.y * W + (int)pb.x, xc = (int)pc.y * W + (int)pc.x;
+        const double wa = orient(q, pb, pc), wb = orient(pa, q, pc), wc = orient(pa, pb, q), Wt = orient(pa, pb, pc);
+        for (int c = 0; c < C; ++c) {
+            const double v = (wa * (double)im[(size_t)c * n + xa] + wb * (double)im[(size_t)c * n + xb]) + wc * (double)im[(size_t)c * n + xc];
+            o[(size_t)c * n] = (float)(v / Wt);
+        }
+    }
+}
+
 // q on the boundary of the sites' hull, supporting direction d (every site has d . (p - q) <= 0): the Delaunay triangulation
 // has the hull edge between the two sites ON that line nearest to q on either side; q beyond the last one is outside (NaN).
 // One wavefront per query (rare: the reference's images carry a full border of sites).
@@ -273,8 +465,10 @@ __global__ __launch_bounds__(64) void k_linear_boundary(const float* __restrict_
 
 extern "C" size_t pdhip_linear_fill_ws_bytes(int B, int H, int W) {
     return (size_t)B * 3 * H * W * sizeof(float) + (size_t)B * H * W * sizeof(int) + (size_t)(2 * B + 64) * sizeof(int) +
-           (size_t)B * H * W * 3 * sizeof(int);
+           (size_t)B * H * W * 3 * sizeof(int) + (size_t)B * (H + 1) * sizeof(int) + (size_t)2 * B * sizeof(int);
 }
+static thread_local int g_linear_local = 1;             // tuning / test hook: 0 = global scans only (the round-2 path)
+extern "C" int pdhip_debug_set_linear_local(int on) { int old = g_linear_local; g_linear_local = on; return old; }
 
 /* tri (may be NULL): per pixel the three site indices (in the image's row-major site order) of the triangle used, -1 at
  * sites, -2 outside the hull -- for tests.  unresolved: device int, incremented for queries that hit the round cap. */
@@ -290,9 +484,19 @@ extern "C" int pdhip_linear_fill(const float* img, float* out, int B, int C, int
     int* unresolved = counts + 2 * B;
     int* bcount = unresolved + 1;
     int* blist = counts + 2 * B + 64;
+    int* rowstart = blist + (size_t)B * n * 3;
+    int* fbcount = rowstart + (size_t)B * (H + 1);
+    const bool local = g_linear_local != 0 && W < 65536 && H < 65536;
     PD_HIP(hipMemsetAsync(unresolved, 0, 2 * sizeof(int), s));
-    k_linear_collect<<<B, 1024, 0, s>>>(mask, mask_is_f32, mask_batch_stride, H, W, sites, qlist, counts);
+    k_linear_collect<<<B, 1024, 0, s>>>(mask, mask_is_f32, mask_batch_stride, H, W, sites, qlist, counts, rowstart, fbcount, local ? 0 : 1);
     k_linear_copy_sites<<<dim3(min(cdiv(n, 256), 1024), B), 256, 0, s>>>(img, out, mask, mask_is_f32, mask_batch_stride, C, n, tri);
+    if (local) {
+        // local pass over 16 x 16 tiles (window sites in LDS); what it cannot certify lands in the fallback list (written over the unused
+        // query list), which the global kernel then finishes with (NS, count) = fbcount
+        const int tiles = cdiv(W, LT) * cdiv(H, LT);
+        k_linear_local<<<dim3(cdiv(tiles, 4), B), 256, 0, s>>>(img, out, C, H, W, mask, mask_is_f32, mask_batch_stride, rowstart, tri, qlist, fbcount);
+        k_linear_tri<<<dim3(cdiv(n, 4 * LQ), B), 256, 0, s>>>(img, out, C, H, W, sites, qlist, fbcount, tri, unresolved, bcount, blist);
+    } else
     k_linear_tri<<<dim3(cdiv(n, 4 * LQ), B), 256, 0, s>>>(img, out, C, H, W, sites, qlist, counts, tri, unresolved, bcount, blist);
     k_linear_boundary<<<256, 64, 0, s>>>(img, out, C, H, W, sites, counts, bcount, blist, tri);
     PD_LAUNCH_CHECK();

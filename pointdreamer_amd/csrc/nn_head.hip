@@ -20,7 +20,7 @@ namespace pdnn {
 #define HD_IH (HD_TH + 2)
 #define HD_NPIX (HD_IW * HD_IH)              // 340 input pixels per tile
 #define HD_NCH ((HD_NPIX + 15) / 16)         // 22 chunks of 16 pixels (one MFMA M-tile each)
-#define HD_ZS 60                              // z row stride (floats): 4*60 mod 64 = 48 -> the 4 row groups of a C tile hit disjoint banks
+#define HD_ZS_OF(NO) ((NO) == 6 ? 60 : 28)   // z row stride (floats): 4*60 mod 64 = 4*28 mod 64 = 48 -> the 4 row groups of a C tile hit disjoint banks
 
 // packed head weights: [2 (hi, lo)][64 rows n = tap*NO + o (zero above 9*NO)][C] f16, 16-byte chunk index XOR-swizzled by n
 // so that the ds_read_b128 B-fragment reads (16 rows x one chunk column) spread over all banks
@@ -56,15 +56,19 @@ __global__ __launch_bounds__(512) void k_head(const half_t* __restrict__ X, cons
                                               float* __restrict__ y, int H, int W) {
     constexpr int KK = C / 32;                       // MFMA k-steps over the channels
     constexpr int NT = (9 * NO + 15) / 16;           // 16-column tiles of z actually needed
+    constexpr int NR = NT * 16;                      // weight rows staged (of the 64 packed ones)
+    constexpr int HD_ZS = HD_ZS_OF(NO);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* Bs = reinterpret_cast<half_t*>(smem);                               // [2][64][C]
-    float* zs = reinterpret_cast<float*>(smem + (size_t)2 * 64 * C * 2);        // [HD_NCH*16][HD_ZS]
+    half_t* Bs = reinterpret_cast<half_t*>(smem);                               // [2][NR][C]
+    float* zs = reinterpret_cast<float*>(smem + (size_t)2 * NR * C * 2);        // [HD_NCH*16][HD_ZS]
     float* gab = zs + HD_NCH * 16 * HD_ZS;                                      // [2][C]: GN scale, shift of this image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.z, x0 = blockIdx.x * HD_TW;
 
-    for (int i = tid; i < 2 * 64 * C / 8; i += 512)
-        reinterpret_cast<half8*>(Bs)[i] = reinterpret_cast<const half8*>(wz)[i];
+    for (int i = tid; i < 2 * NR * C / 8; i += 512) {    // rows [0, NR) of the hi and of the lo plane
+        const int pl = i / (NR * C / 8), r = i - pl * (NR * C / 8);
+        reinterpret_cast<half8*>(Bs)[i] = reinterpret_cast<const half8*>(wz)[pl * (64 * C / 8) + r];
+    }
     for (int c = tid; c < C; c += 512) {
         const int grp = c / (C / 32);
         const float mean = stats[((size_t)n * 32 + grp) * 2], rstd = stats[((size_t)n * 32 + grp) * 2 + 1];
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(512) void k_head(const half_t* __restrict__ X, cons
                 const int nrow = t * 16 + r16;
                 const int off = nrow * C + (((kk * 4 + q4) ^ hd_swz(nrow, C)) << 3);
                 const half8 bh = *reinterpret_cast<const half8*>(Bs + off);
-                const half8 bl = *reinterpret_cast<const half8*>(Bs + 64 * C + off);
+                const half8 bl = *reinterpret_cast<const half8*>(Bs + NR * C + off);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t], 0, 0, 0);
@@ -162,13 +166,16 @@ __global__ __launch_bounds__(512) void k_head(const half_t* __restrict__ X, cons
     }
 }
 
-size_t head_smem_bytes(int C) { return (size_t)2 * 64 * C * 2 + (size_t)HD_NCH * 16 * HD_ZS * 4 + (size_t)2 * C * 4; }
+size_t head_smem_bytes(int C, int NO) {
+    const int NR = ((9 * NO + 15) / 16) * 16;
+    return (size_t)2 * NR * C * 2 + (size_t)HD_NCH * 16 * HD_ZS_OF(NO) * 4 + (size_t)2 * C * 4;
+}
 
 template <int NO, int C>
 static int head_launch(const half_t* X, const float* stats, const float* gamma, const float* beta, const half_t* wz,
                        const float* bias, float* y, int N, int H, int W, hipStream_t s) {
     auto kern = k_head<NO, C>;
-    const size_t smem = head_smem_bytes(C);
+    const size_t smem = head_smem_bytes(C, NO);
     PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     dim3 grid(cdiv(W, HD_TW), cdiv(cdiv(H, HD_TH), HD_TPW), N);
     kern<<<grid, 512, smem, s>>>(X, stats, gamma, beta, wz, bias, y, H, W);

@@ -69,6 +69,8 @@ struct pdhip_unet {
     // and kept until the weights change (every image of a sampling step shares t, so the per-step forward reads one row)
     float *steps_t = nullptr, *steps_silu = nullptr, *steps_tmp = nullptr, *steps_emb = nullptr; int steps_cached = 0;
     half_t* head_wz = nullptr;                   // output-head weights as f16 hi/lo pairs (nn_head.hip)
+    half_t* head_wz3 = nullptr;                  // the same for output channels 0..2 only: the DDNM sampler discards the variance
+                                                 // channels of a learn_sigma net (diffusion.py:527-528: et = et[:, :3]) -- half the head
     float *t_dev = nullptr;
     float* splitk_ws = nullptr; size_t splitk_floats = 0;
     // sampler state
@@ -323,7 +325,7 @@ int run_blocks(Ctx& c, std::vector<Block>& blocks, Act* h, const float* x_nchw) 
 // the whole forward; dry = sizing pass (no launches)
 // shared_emb: one precomputed row of ResBlock embeddings [emb_rows] used by every image (t is then ignored), or nullptr
 int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* out, hipStream_t s, bool dry,
-                 const float* shared_emb = nullptr) {
+                 const float* shared_emb = nullptr, int head_ch = 0) {   // head_ch 3: only eps (out [N,3,H,W]); 0 = all out_ch
     Ctx c{u, N, s, dry, shared_emb ? shared_emb : u->emb_all, shared_emb ? 0 : u->emb_rows};
     u->arena_off = 0;
     u->arena_overflow = false;
@@ -364,8 +366,9 @@ int forward_impl(pdhip_unet* u, const float* x, const float* t, int N, float* ou
         PD_REQUIRE(!u->arena_overflow, "unet: activation arena too small for this routing (sized at create())");
         PD_REQUIRE(u->out_norm.have_g && u->out_norm.have_b && u->have_ow && u->have_ob, "unet: output head not loaded");
         PD_TRY(run_gn_stats(c, h));
-        PD_TRY(head_gn_silu_conv3x3(h.p, u->stats, u->out_norm.g, u->out_norm.b, u->head_wz, u->out_b, out, N, h.H, h.W, h.C,
-                                    u->out_ch, s));
+        const bool eps_only = head_ch == 3 && u->out_ch == 6;
+        PD_TRY(head_gn_silu_conv3x3(h.p, u->stats, u->out_norm.g, u->out_norm.b, eps_only ? u->head_wz3 : u->head_wz, u->out_b, out, N,
+                                    h.H, h.W, h.C, eps_only ? 3 : u->out_ch, s));
     }
     return PDHIP_OK;
 }
@@ -491,6 +494,7 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     chk(dalloc(u, &u->steps_t, 128)); chk(dalloc(u, &u->steps_silu, (size_t)100 * u->ted));
     chk(dalloc(u, &u->steps_tmp, (size_t)100 * (u->mc + u->ted))); chk(dalloc(u, &u->steps_emb, (size_t)100 * emb_rows));
     { float* wz = nullptr; chk(dalloc(u, &wz, (size_t)64 * u->final_ch)); u->head_wz = reinterpret_cast<half_t*>(wz); }
+    { float* wz = nullptr; chk(dalloc(u, &wz, (size_t)64 * u->final_ch)); u->head_wz3 = reinterpret_cast<half_t*>(wz); }
     chk(dalloc(u, &u->t_dev, (size_t)max_batch));
     u->splitk_floats = (size_t)16 * 384 * 128 * 128;               // 16 splits x (< 384 tiles of 128x128) f32
     chk(dalloc(u, &u->splitk_ws, u->splitk_floats));
@@ -598,6 +602,7 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
         k_pack_conv_f32<<<grid_for(numel), 256, 0, s>>>(data, is_f16, u->out_ch, u->final_ch, 9, u->out_w);
         PD_LAUNCH_CHECK();
         PD_TRY(head_pack(u->out_w, u->out_ch, u->final_ch, u->head_wz, s));
+        PD_TRY(head_pack(u->out_w, 3, u->final_ch, u->head_wz3, s));            // rows 0..2 of [out_ch][9 C]
         u->have_ow = true;
         return PDHIP_OK;
     }
@@ -756,8 +761,8 @@ extern "C" int pdhip_ddnm_sample_keyed(pdhip_unet* u, const float* masked_imgs, 
         u->steps_cached = n_steps;
     }
     for (int k = 0; k < n_steps; ++k) {
-        PD_TRY(forward_impl(u, u->sx, nullptr, N, u->set_, s, false, u->steps_emb + (size_t)k * u->emb_rows));
-        PD_TRY(ddnm_update(u->sx, u->set_, u->out_ch, u->sy, masks, eps_tape ? eps_tape + (size_t)k * n3 : nullptr, seed,
+        PD_TRY(forward_impl(u, u->sx, nullptr, N, u->set_, s, false, u->steps_emb + (size_t)k * u->emb_rows, 3));
+        PD_TRY(ddnm_update(u->sx, u->set_, 3, u->sy, masks, eps_tape ? eps_tape + (size_t)k * n3 : nullptr, seed,
                            (unsigned long long)k + 1, sched.co[k], N, HW, s, quad0));
     }
     return ddnm_finish(u->sx, out, n3, s);

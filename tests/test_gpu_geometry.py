@@ -22,7 +22,7 @@ def pd():
     import pointdreamer_amd.camera_utils as cu
     from pointdreamer_amd import synthetic, _lib
     _lib.lib()                                    # fails loudly if libpdhip.so is missing
-    return dict(ou=ou, up=up, cu=cu, syn=synthetic)
+    return dict(ou=ou, up=up, cu=cu, syn=synthetic, lib=_lib)
 
 
 DEV = 'cuda:0'
@@ -754,8 +754,9 @@ def _site_list(mask):
     return np.stack([xs, ys], 1)
 
 
+@pytest.mark.parametrize("local", [1, 0])
 @pytest.mark.parametrize("case", ["random64", "ring_only", "no_corners", "golden_view"])
-def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case):
+def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case, local):
     """texture_gen_method='linear' (ours_utils.py:610-643 -> scipy griddata linear = qhull Delaunay + barycentric interpolation).
     The device finds, per unknown pixel, its Delaunay triangle exactly (integer predicates).  Equality with scipy is required
     wherever the values agree to 1e-5; every other pixel must sit in a co-circular configuration where the device's triangle is
@@ -775,7 +776,12 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case):
         m2 = np.repeat(m[None].astype(np.float32), 3, 0)
     sites = m2[0] != 0
     want = oinp.reference_linear_inpaint_scipy(img, m2)
-    got, tri = pd['ou'].linear_fill(T(img[None]), T(sites[None]), return_triangles=True)
+    # local = 1: the 16x16-tile window pass first (round 3), the global scans only for what it cannot certify; 0: global scans only
+    old_local = pd['lib'].lib().pdhip_debug_set_linear_local(local)
+    try:
+        got, tri = pd['ou'].linear_fill(T(img[None]), T(sites[None]), return_triangles=True)
+    finally:
+        pd['lib'].lib().pdhip_debug_set_linear_local(old_local)
     got, tri = N_(got)[0], N_(tri)[0]
     assert np.array_equal(got[:, sites], img[:, sites])                     # sites keep their values
     nan_w, nan_g = np.isnan(want).any(0), np.isnan(got).any(0)
@@ -819,8 +825,13 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case):
             break
     if case == "no_corners":
         assert nan_g.any() and (nan_g & ~nan_w).sum() <= 8                  # NaN set == scipy's up to hull-boundary pixels
-    # through the reference-signature entry points
-    one = pd['ou'].naive_inpainting(T(img), T(m2), method='linear')
+    # through the reference-signature entry points (same pass configuration: at co-circular pixels the two routes may pick
+    # different valid triangles)
+    old_local = pd['lib'].lib().pdhip_debug_set_linear_local(local)
+    try:
+        one = pd['ou'].naive_inpainting(T(img), T(m2), method='linear')
+        views = pd['ou'].get_inpainted_images(T(img[None]), T(m2[None]), T(m2[None]), None, None, 1, method='linear')
+    finally:
+        pd['lib'].lib().pdhip_debug_set_linear_local(old_local)
     assert np.array_equal(np.nan_to_num(N_(one), nan=-1), np.nan_to_num(got, nan=-1))
-    views = pd['ou'].get_inpainted_images(T(img[None]), T(m2[None]), T(m2[None]), None, None, 1, method='linear')
     assert np.array_equal(np.nan_to_num(N_(views)[0], nan=-1), np.nan_to_num(got, nan=-1))
