@@ -84,13 +84,33 @@ def cpu_baseline(timed=2, max_workers=None):
     it -- project, raster, depth test + hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF
     unproject, atlas dilate -- at BASELINE sizes.  Host cores are used the way a CPU deployment of this throughput metric would
     use them: one independent shape stream per core (the per-shape code is serial numpy / scipy, as the reference's is), on ALL
-    host cores (capped only by memory at ~1.5 GB per worker, or by `max_workers`); `cores`, `host_cores` and the
+    cores the process may use (scheduler affinity and cgroup CPU quota; capped by memory at ~1.5 GB per worker, or by `max_workers`); `cores`, `host_cores` and the
     per-core rate are reported.  Every worker runs 1 warm-up + `timed` shapes with hidden-point removal and one without (the bounded
     sample of the task statement: ~30 s of CPU work per core), the aggregate rate is shapes / slowest worker's wall time; the
     median seconds per shape over all workers x shapes is reported next to it."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
-    workers = cores if max_workers is None else max(1, min(cores, max_workers))
+    # cores this process may actually use: scheduler affinity and the cgroup CPU quota (the GPU boxes of the pool show 256 logical
+    # CPUs but run the container under cpu.max = 16 CPUs: 256 workers there time-slice 16 cores and thrash -- 178 s per shape)
+    usable = cores
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', ):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != 'max':
+                usable = max(1, min(usable, int(int(q) / int(per) + 0.5)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            usable = max(1, min(usable, int(q / per + 0.5)))
+    except (OSError, ValueError):
+        pass
+    workers = usable if max_workers is None else max(1, min(usable, max_workers))
     try:
         for line in open('/proc/meminfo'):
             if line.startswith('MemAvailable'):
@@ -117,12 +137,12 @@ def cpu_baseline(timed=2, max_workers=None):
     med = {k: float(np.median([st[k] for st in flat])) for k in flat[0]}
     per_shape = float(np.median([sum(st.values()) for st in flat]))
     off = float(np.median([sum(r[2].values()) for r in res]))
-    return dict(value=value, unit="shapes/hour", cores=workers, kind="port", cpu_model=model, host_cores=cores,
+    return dict(value=value, unit="shapes/hour", cores=workers, kind="port", cpu_model=model, host_cores=cores, usable_cores=usable,
                 seconds_per_shape_one_core=per_shape, shapes_per_hour_one_core=3600.0 / per_shape,
                 seconds_per_shape_hpr_off=off, value_hpr_off=value * per_shape / off,
                 stage_seconds=med,
                 sample=f"oracle CPU restatement of the reference's texture_gen_method='nearest' path (scipy griddata / qhull) on "
-                       f"{workers} of {cores} host cores ({model}): one independent 30k-point 8-view shape stream per core at A=1024, "
+                       f"{workers} cores = every core the container may use (cgroup quota / affinity; the host shows {cores} logical CPUs; {model}): one independent 30k-point 8-view shape stream per core at A=1024, "
                        f"1 warm-up + {timed} timed shapes each = {workers * timed} shapes in {slowest:.1f} s (pool wall {total_wall:.1f} s); "
                        f"median {per_shape:.2f} s/shape/core with hidden-point removal, {off:.2f} s without; no diffusion on the CPU "
                        f"(a CPU fp32 UNet forward is ~8 s, x800 per DDNM shape)")

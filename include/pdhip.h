@@ -55,6 +55,11 @@ int pdhip_project_points(const float* cam_params, int V, const float* vertices, 
 int pdhip_raster_mesh(const float* pos /*[V,Vn,4]*/, int V, int Vn, const int32_t* faces /*[F,3]*/, int F,
                       int R, uint64_t* zkey_ws, uint8_t* hard_masks, int64_t* face_idxs, float* depths,
                       void* stream);
+/* the same with an explicit workspace: pdhip_raster_mesh_ws_bytes(V, F, R) bytes keep meshes up to 65 536 faces on the LDS-tiled path
+ * (with the historical V*R*R*8 bytes it is taken up to R*R/17 faces only: 15.4 k at R = 512) */
+size_t pdhip_raster_mesh_ws_bytes(int V, int F, int R);
+int pdhip_raster_mesh_ws(const float* pos, int V, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws, size_t ws_bytes,
+                         uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream);
 /* tuning / test hook: 0 = automatic (LDS-tiled rasteriser up to 65 536 faces), 1 = force the global 64-bit atomicMin path;
  * both produce identical images.  Returns the previous value. */
 int pdhip_debug_set_raster_path(int path);

@@ -21,6 +21,8 @@ _SIGS = {
     'pdhip_last_error': (C.c_char_p, []),
     'pdhip_project_points': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp]),
     'pdhip_raster_mesh': (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
+    'pdhip_raster_mesh_ws_bytes': (sz, [i32, i32, i32]),
+    'pdhip_raster_mesh_ws': (C.c_int, [vp, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, vp]),
     'pdhip_debug_set_raster_path': (C.c_int, [i32]),
     'pdhip_raster_barycentrics': (C.c_int, [vp, i32, i32, vp, i32, vp, vp, vp]),
     'pdhip_interpolate': (C.c_int, [vp, i32, vp, vp, vp, C.c_longlong, vp, vp]),

@@ -311,15 +311,29 @@ __global__ void k_raster_resolve(const uint64_t* __restrict__ zkey, long long n,
 static thread_local int g_raster_path = 0;                    // 0 automatic, 1 force the global-atomic fallback
 extern "C" int pdhip_debug_set_raster_path(int path) { int old = g_raster_path; g_raster_path = path; return old; }
 
+/* workspace of the LDS-tiled path for a mesh of F faces: the face setups (128 B) + clipped boxes (8 B) of every view, or the z keys
+ * of the atomic fallback, whichever is larger.  pdhip_raster_mesh() assumes the historical V*R*R*8 bytes, i.e. takes the tiled path
+ * up to F <= R*R / 17 faces (15.4 k at R = 512); pdhip_raster_mesh_ws() with a workspace of this size takes it up to 65 536 faces. */
+extern "C" size_t pdhip_raster_mesh_ws_bytes(int V, int F, int R) {
+    const size_t zk = (size_t)V * R * R * sizeof(uint64_t), fs = (size_t)V * (size_t)std::min(F, 65536) * (sizeof(FaceSetup) + sizeof(short4));
+    return std::max(zk, fs);
+}
+extern "C" int pdhip_raster_mesh_ws(const float* pos, int V, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws, size_t ws_bytes,
+                                    uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream);
 extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t* faces, int F, int R,
                                  uint64_t* zkey_ws, uint8_t* hard_masks, int64_t* face_idxs, float* depths,
                                  void* stream) {
+    return pdhip_raster_mesh_ws(pos, V, Vn, faces, F, R, zkey_ws, (size_t)V * R * R * sizeof(uint64_t), hard_masks, face_idxs, depths, stream);
+}
+extern "C" int pdhip_raster_mesh_ws(const float* pos, int V, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws, size_t ws_bytes,
+                                    uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream) {
     PD_REQUIRE(V > 0 && Vn > 0 && F >= 0 && R > 0 && R <= 16384, "pdhip_raster_mesh: bad sizes V=%d Vn=%d F=%d R=%d", V, Vn, F, R);
     PD_REQUIRE(pos && (F == 0 || faces) && zkey_ws && hard_masks && face_idxs && depths, "pdhip_raster_mesh: null pointer");
     hipStream_t s = as_stream(stream);
     long long n = (long long)V * R * R;
-    // LDS-tiled path: the face setups live in the z-key workspace (V*R*R*8 bytes >= V*F*80 bytes)
-    if (g_raster_path != 1 && F > 0 && F <= 65536 && R <= 32767 && (size_t)V * F * (sizeof(FaceSetup) + sizeof(short4)) <= (size_t)n * sizeof(uint64_t)) {
+    PD_REQUIRE(ws_bytes >= (size_t)n * sizeof(uint64_t), "pdhip_raster_mesh: workspace smaller than V*R*R*8 bytes");
+    // LDS-tiled path: the face setups (128 B + 8 B box per face and view) live in the workspace
+    if (g_raster_path != 1 && F > 0 && F <= 65536 && R <= 32767 && (size_t)V * F * (sizeof(FaceSetup) + sizeof(short4)) <= ws_bytes) {
         FaceSetup* setup = reinterpret_cast<FaceSetup*>(zkey_ws);
         short4* bbox = reinterpret_cast<short4*>(setup + (size_t)V * F);
         k_raster_setup<<<dim3(cdiv(F, 256), V), 256, 0, s>>>(pos, Vn, faces, F, R, setup, bbox);

@@ -16,12 +16,12 @@ def rasterize(pos, tri, resolution):
     V, Vn = pos.shape[:2]
     R = int(resolution)
     dev = pos.device
-    zkey = torch.empty((V, R, R), dtype=torch.int64, device=dev)
+    zkey = torch.empty(((L.pdhip_raster_mesh_ws_bytes(V, tri32.shape[0], R) + 7) // 8,), dtype=torch.int64, device=dev)
     hard = torch.empty((V, R, R), dtype=torch.bool, device=dev)
     fidx = torch.empty((V, R, R), dtype=torch.int64, device=dev)
     depth = torch.empty((V, R, R), device=dev)
-    check(L.pdhip_raster_mesh(ptr(pos), V, Vn, ptr(tri32), tri32.shape[0], R, ptr(zkey), ptr(as_u8(hard)), ptr(fidx), ptr(depth),
-                              stream()), 'pdhip_raster_mesh')
+    check(L.pdhip_raster_mesh_ws(ptr(pos), V, Vn, ptr(tri32), tri32.shape[0], R, ptr(zkey), zkey.numel() * 8, ptr(as_u8(hard)), ptr(fidx),
+                                 ptr(depth), stream()), 'pdhip_raster_mesh')
     bary = torch.empty((V, R, R, 2), device=dev)
     check(L.pdhip_raster_barycentrics(ptr(pos), V, Vn, ptr(tri32), R, ptr(fidx), ptr(bary), stream()), 'pdhip_raster_barycentrics')
     return fidx, bary, depth, hard

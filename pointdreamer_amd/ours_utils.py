@@ -77,12 +77,13 @@ def get_rendered_hard_mask_and_face_idx_batch(cams, vertices, faces, points, glc
     check(L.pdhip_project_points(ptr(cp), V, ptr(vertices), Vn, ptr(points), N, 1 if rescale else 0, float(padding),
                                  ptr(pos), ptr(vuv), ptr(uvc), ptr(uvs), ptr(puv), ptr(pdep), ptr(ws), stream()),
           'pdhip_project_points')
-    zkey = torch.empty((V, R, R), dtype=torch.int64, device=dev)
+    ws_bytes = L.pdhip_raster_mesh_ws_bytes(V, F, R)          # face setups of the LDS-tiled path (meshes up to 65 536 faces) or z keys
+    zkey = torch.empty(((ws_bytes + 7) // 8,), dtype=torch.int64, device=dev)
     hard = torch.empty((V, R, R), dtype=torch.bool, device=dev)
     fidx = torch.empty((V, R, R), dtype=torch.int64, device=dev)
     depth = torch.empty((V, R, R), device=dev)
-    check(L.pdhip_raster_mesh(ptr(pos), V, Vn, ptr(faces32), F, R, ptr(zkey), ptr(as_u8(hard)), ptr(fidx), ptr(depth),
-                              stream()), 'pdhip_raster_mesh')
+    check(L.pdhip_raster_mesh_ws(ptr(pos), V, Vn, ptr(faces32), F, R, ptr(zkey), zkey.numel() * 8, ptr(as_u8(hard)), ptr(fidx), ptr(depth),
+                                 stream()), 'pdhip_raster_mesh')
     if rescale:
         return hard, fidx, depth, vuv, uvc, uvs, padding, puv, pdep
     return hard, fidx, depth, vuv, 0, 2, 0, puv, pdep

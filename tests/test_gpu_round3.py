@@ -205,3 +205,29 @@ def test_rccl_all_gather_views_world1(nn):
         assert torch.equal(a_par, a_one)
     finally:
         dist.destroy_process_group()
+
+
+def test_p2_raster_large_mesh_stays_on_tiled_path(nn):
+    """A 39 600-face mesh at R = 512 (more faces than the V*R*R*8-byte z-key workspace holds setups for: 15.4 k): the wrappers size
+    the workspace with pdhip_raster_mesh_ws_bytes so that the LDS-tiled path still runs; it must equal the global-atomic path bit
+    for bit, and the historical entry point (which falls back for such a mesh) too."""
+    from pointdreamer_amd import synthetic, extract_texture_map as etm
+    import pointdreamer_amd.camera_utils as cu
+    import pointdreamer_amd.ours_utils as ou
+    L = nn['L']
+    V, R = 3, 512
+    verts, faces, _ = synthetic.uv_sphere(100, 200)
+    assert faces.shape[0] > 30000 and L.pdhip_raster_mesh_ws_bytes(V, faces.shape[0], R) > V * R * R * 8
+    xyz, _ = synthetic.sphere_points(2000, seed=3)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    cams, _, _, _ = cu.create_cameras(V, 1.6, R, device=DEV)
+    outs = []
+    for path in (0, 1):
+        old = L.pdhip_debug_set_raster_path(path)
+        try:
+            outs.append([t.cpu() for t in ou.get_rendered_hard_mask_and_face_idx_batch(cams, T(verts), T(faces), T(xyz), None, True, 0.05)[:3]])
+        finally:
+            L.pdhip_debug_set_raster_path(old)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][0].any() and (outs[0][1] >= 0).sum() > 10000
