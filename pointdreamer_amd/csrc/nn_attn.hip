@@ -147,9 +147,12 @@ typedef __attribute__((address_space(3))) void lds_void_a;
 typedef const __attribute__((address_space(1))) void gbl_void_a;
 __device__ __forceinline__ void glds16a(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_void_a*)g, (lds_void_a*)l, 16, 0, 0); }
 
+// QTN: 16-query tiles per wave (2: 128 queries per workgroup; 1: 64 -- twice the workgroups for the small grids of batch 1-2, where
+// 8 heads x 8 query blocks are 64 workgroups on 256 CUs)
+template <int QTN>
 __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict__ qkv, const half_t* __restrict__ vt,
                                                        half_t* __restrict__ out, int T, int C, float scale2) {
-    constexpr int D = 64, KCH = 64;
+    constexpr int D = 64, KCH = 64, QPW = 16 * QTN, QPB = 4 * QPW;
     __shared__ __attribute__((aligned(16))) char lds[2][2][KCH * 128];      // [buffer][K | Vt][64 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g4 = lane >> 4;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
     // K / V^T, so they are given CONSECUTIVE slots of ONE XCD -- with the query block as the fastest grid index the 8 query blocks
     // of a head at 32x32 landed on 8 different XCDs and every L2 fetched the same K / V^T (3.2x the algorithmic HBM reads,
     // profiles/r02_pmc_kernels.json).  N * heads is a multiple of 8 (8 or 16 heads).
-    const int nqb = T >> 7;
+    const int nqb = T / QPB;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int qb = slot % nqb, grp = (slot / nqb) * 8 + xcd;           // grp = n * heads + h
     const int n = grp / heads, h = grp - n * heads;
@@ -167,18 +170,18 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
     const half_t* base = qkv + (size_t)n * T * row_stride + (size_t)h * 3 * D;
     const half_t* vbase = vt + (((size_t)n * heads + h) * D) * T;
     // Q fragments (B operand): column = query r16 of tile qt, k = d chunk ks*32 + 8 g4
-    half8 qf[2][2];
+    half8 qf[QTN][2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = qb * 128 + wave * 32 + qt * 16 + r16;
+    for (int qt = 0; qt < QTN; ++qt) {
+        const int q = qb * QPB + wave * QPW + qt * 16 + r16;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qt][ks] = *reinterpret_cast<const half8*>(base + (size_t)q * row_stride + ks * 32 + g4 * 8);
     }
     (void)scale2l;
-    float4_t o[2][4];
-    float mrun[2], lrun[2];
+    float4_t o[QTN][4];
+    float mrun[QTN], lrun[QTN];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QTN; ++qt) {
         mrun[qt] = -INFINITY; lrun[qt] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -212,9 +215,9 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
             for (int ks = 0; ks < 2; ++ks)
                 kf[kt][ks] = *reinterpret_cast<const half8*>(Kb + row * 128 + (((ks * 4 + g4) ^ ((row >> 1) & 7)) << 4));
         }
-        half8 pf[2][2];                                            // [query tile][k-step of 32 keys]
+        half8 pf[QTN][2];                                          // [query tile][k-step of 32 keys]
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QTN; ++qt) {
             float4_t st[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
@@ -269,14 +272,14 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
+                for (int qt = 0; qt < QTN; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
             }
         }
     }
     // normalise and store: lane = query r16 of each tile, d = 16 dt + 4 g4 + r (8-byte packed stores)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = qb * 128 + wave * 32 + qt * 16 + r16;
+    for (int qt = 0; qt < QTN; ++qt) {
+        const int q = qb * QPB + wave * QPW + qt * 16 + r16;
         const float inv = 1.0f / lrun[qt];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -296,7 +299,8 @@ int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStr
     if (vt_ws != nullptr && D == 64 && T % 128 == 0 && (N * (C / D)) % 8 == 0) {
         k_transpose_v<<<dim3(T / 64, C / D, N), 256, 0, s>>>(qkv, vt_ws, T, C, D);
         PD_REQUIRE((N * (C / D)) % 8 == 0, "attention: N * heads must be a multiple of 8");
-        k_attention_t64<<<(T / 128) * (C / D) * N, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
+        if ((T / 128) * (C / D) * N < 256) k_attention_t64<1><<<(T / 64) * (C / D) * N, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
+        else k_attention_t64<2><<<(T / 128) * (C / D) * N, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
         PD_LAUNCH_CHECK();
         return PDHIP_OK;
     }
