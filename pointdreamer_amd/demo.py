@@ -268,10 +268,11 @@ def main(argv=None):
     p.add_argument("--allow_random_weights", action='store_true', help="run DDNM with random-init weights if the checkpoint is absent")
     p.add_argument("--set", nargs='*', default=[], help="YAML overrides key=value (e.g. complete_unseen_by=unproject optimize_from=None)")
     p.add_argument("--batch_shapes", type=int, default=4, help="directory runs: clouds textured together, their views in one "
-                   "inpainter batch (1 = one at a time, as the reference; 4 is ~16 %% more shapes/hour on one MI355X)")
+                   "inpainter batch (1 = one at a time, as the reference -- the only route that re-uses existing {k}_inpainted.png "
+                   "files of a resumed output directory, demo.py:138-147; 4 is ~16 %% more shapes/hour on one MI355X)")
     p.add_argument("--parallel", choices=['shapes', 'views'], default='shapes', help="under torch.distributed.run: 'shapes' = every "
                    "rank textures its own block of the clouds (no collective); 'views' = the views of each shape are split over the "
-                   "ranks and assembled with one all_gather (lowest latency per shape)")
+                   "ranks and assembled with one all_gather (lowest latency per shape; needs world size <= view_num)")
     args = p.parse_args(argv)
     # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pointdreamer_amd.demo ...`): every rank textures its
     # own contiguous block of the directory's clouds -- independent shapes, no collective on the data path

@@ -12,7 +12,8 @@ SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (1, 8, 8, 1024, 1024, 9), (1, 16, 16, 1024, 1024, 9), (1, 32, 32, 512, 512, 9), (1, 64, 64, 512, 512, 9), (1, 128, 128, 256, 256, 9),
     (1, 8, 8, 1024, 3072, 1), (1, 8, 8, 1024, 1024, 1), (1, 32, 32, 512, 1536, 1), (1, 16, 16, 2048, 1024, 1),
     (8, 8, 8, 1024, 1024, 9), (8, 16, 16, 1024, 1024, 9), (8, 32, 32, 512, 512, 9),
-    (32, 8, 8, 1024, 1024, 9), (32, 16, 16, 1024, 1024, 9), (8, 8, 8, 2048, 1024, 9), (8, 16, 16, 2048, 1024, 9)]
+    (32, 8, 8, 1024, 1024, 9), (32, 16, 16, 1024, 1024, 9), (8, 8, 8, 2048, 1024, 9), (8, 16, 16, 2048, 1024, 9),
+    (8, 256, 256, 512, 256, 1), (8, 128, 128, 512, 256, 1), (32, 32, 32, 512, 1536, 1)]
 ap = argparse.ArgumentParser()
 ap.add_argument('--shapes', type=int, nargs='*', default=None)
 ap.add_argument('--tiles', type=int, nargs='*', default=[1, 2, 3, 4])
