@@ -188,3 +188,65 @@ def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpaint
             outs.append((sh['vertices'], xat.get('uvs'), sh['faces'], xat.get('mesh_tex_idx'), atlas, xat['mask']) if return_full
                         else atlas)
     return outs
+
+
+class ShapeGraphs:
+    """The texturing path of one shape captured into HIP graphs (`torch.cuda.CUDAGraph`), `n_slots` of them on streams of their own:
+    a shape's ~45 launches (0.26 ms of host enqueue, more than half of its 0.54 ms) become one graph launch, and the latency-bound
+    kernels of different shapes overlap on the GPU -- 0.31 ms per shape at 8 slots against 0.45 ms for eager launches on streams
+    (30k-point clouds, 8 x 256^2 views, hidden-point removal on).  Results equal the eager path bit for bit (tested).
+
+    Only sync-free configurations can be captured: texture_gen_method='nearest', complete_unseen_by='unproject', optimize_from=None,
+    no per-view files.  The cloud size, the mesh, the atlas and the cameras are fixed at capture; `run` takes the clouds."""
+
+    def __init__(self, n_slots, n_points, vertices, faces, f_normals, xatlas_dict, camera_info, view_num, res, cam_res, **cfg):
+        if cfg.get('texture_gen_method', 'nearest') != 'nearest' or cfg.get('complete_unseen_by', 'unproject') != 'unproject' or \
+                cfg.get('optimize_from') not in (None, 'None') or cfg.get('save_img_path') is not None:
+            raise ValueError("ShapeGraphs captures the sync-free configuration only: texture_gen_method='nearest', "
+                             "complete_unseen_by='unproject', optimize_from=None, save_img_path=None")
+        cfg = dict(cfg, texture_gen_method='nearest', complete_unseen_by='unproject', optimize_from=None, inpainter=None,
+                   save_img_path=None)
+        dev = vertices.device
+        self.n_points = int(n_points)
+        self._slots = []
+        run_one = lambda p, c: colorize_one_mesh(p, c, vertices, faces, f_normals, xatlas_dict, camera_info, view_num, res, cam_res,
+                                                 **cfg)[4]
+        for _ in range(int(n_slots)):
+            st = torch.cuda.Stream(device=dev)
+            pts = torch.zeros((self.n_points, 3), device=dev)
+            col = torch.zeros((self.n_points, 3), device=dev)
+            pts[:, 2] = 1.0                                                   # (any cloud: the warm-up runs fill the host-side caches)
+            gr = torch.cuda.CUDAGraph()
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                for _ in range(2):
+                    run_one(pts, col)
+                st.synchronize()
+                with torch.cuda.graph(gr, stream=st):
+                    out = run_one(pts, col)
+            self._slots.append((st, gr, pts, col, out))
+        torch.cuda.current_stream(dev).wait_stream(self._slots[-1][0])
+
+    def __len__(self):
+        return len(self._slots)
+
+    def run(self, clouds, clone=True):
+        """clouds: up to n_slots pairs (coords [n_points,3], colors [n_points,3]) -> their atlases [A,A,3] (in slot order).
+        clone=False returns the slots' own output tensors, valid until the slot runs again."""
+        if len(clouds) > len(self._slots):
+            raise ValueError(f"{len(clouds)} clouds for {len(self._slots)} graph slots")
+        main = torch.cuda.current_stream(self._slots[0][2].device)
+        outs = []
+        for (st, gr, pts, col, out), (p, c) in zip(self._slots, clouds):
+            if tuple(p.shape) != (self.n_points, 3):
+                raise ValueError(f"the graphs were captured for clouds of {self.n_points} points, got {tuple(p.shape)}")
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                pts.copy_(p, non_blocking=True); col.copy_(c, non_blocking=True)
+                gr.replay()
+                outs.append(out.clone() if clone else out)
+        for st, *_ in self._slots[:len(clouds)]:
+            main.wait_stream(st)
+        for o in outs:
+            o.record_stream(main)
+        return outs

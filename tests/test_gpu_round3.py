@@ -231,3 +231,34 @@ def test_p2_raster_large_mesh_stays_on_tiled_path(nn):
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert outs[0][0].any() and (outs[0][1] >= 0).sum() > 10000
+
+
+def test_shape_graphs_replay_equals_eager(nn):
+    """pipeline.ShapeGraphs: the 'nearest' path of a shape captured into HIP graphs (three slots on three streams); replays on fresh
+    clouds -- fed in a different order than at capture -- give the eager colorize_one_mesh atlases bit for bit."""
+    from pointdreamer_amd import synthetic, pipeline
+    import pointdreamer_amd.camera_utils as cu
+    V, RES, CAM, A, NP = 4, 128, 256, 256, 5000
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    sh = synthetic.make_shape(NP, A, seed=0)
+    g = {k: T(v) for k, v in sh.items()}
+    cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, CAM, device=DEV)
+    ci = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    xa = dict(gb_pos=g['gb_pos'], mask=g['mask'], per_atlas_pixel_face_id=g['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
+    cfg = dict(point_validation_by_o3d=True, texture_gen_method='nearest', point_size=1, edge_point_size=1, crop_img=True,
+               crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None, edge_dilate_kernels=[21], complete_unseen_by='unproject')
+    clouds = []
+    for i in range(5):
+        c = synthetic.make_shape(NP, A, seed=40 + i)
+        clouds.append((T(c['points']), T(c['colors'])))
+    eager = [pipeline.colorize_one_mesh(p, c, g['vertices'], g['faces'], g['f_normals'], xa, ci, view_num=V, res=RES, cam_res=CAM,
+                                        inpainter=None, **cfg)[4].clone() for p, c in clouds]
+    sg = pipeline.ShapeGraphs(3, NP, g['vertices'], g['faces'], g['f_normals'], xa, ci, V, RES, CAM, **cfg)
+    got = sg.run(clouds[:3]) + sg.run(clouds[3:]) + sg.run([clouds[4], clouds[0]])
+    torch.cuda.synchronize()
+    for a, b in zip(got, eager + [eager[4], eager[0]]):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        pipeline.ShapeGraphs(1, NP, g['vertices'], g['faces'], g['f_normals'], xa, ci, V, RES, CAM, **dict(cfg, optimize_from='ours'))
+    with pytest.raises(ValueError):
+        sg.run([(clouds[0][0][:100], clouds[0][1][:100])])
