@@ -143,17 +143,29 @@ __global__ __launch_bounds__(256) void k_transpose_v(const half_t* __restrict__ 
     }
 }
 
+thread_local int g_attn_nbuf = 0;      // tuning hook: 2 / 3 LDS chunk buffers of k_attention_t64, 0 = automatic
+thread_local int g_attn_qtn = 0;       // tuning hook: 1 / 2 = 64 / 128 queries per workgroup, 0 = automatic
+thread_local int g_attn_vt = 0;        // tuning hook: 1 = transposed-V workspace form (k_transpose_v + plain reads), 0 = LDS transpose reads
+#define PD_ATT_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define PD_ATT_DSR64T(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define PD_ATT_DSR64(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 typedef __attribute__((address_space(3))) void lds_void_a;
 typedef const __attribute__((address_space(1))) void gbl_void_a;
 __device__ __forceinline__ void glds16a(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_void_a*)g, (lds_void_a*)l, 16, 0, 0); }
 
 // QTN: 16-query tiles per wave (2: 128 queries per workgroup; 1: 64 -- twice the workgroups for the small grids of batch 1-2, where
 // 8 heads x 8 query blocks are 64 workgroups on 256 CUs)
-template <int QTN>
+// NBUF: LDS chunk buffers; 3 = K / V^T chunks requested TWO iterations ahead (the one-workgroup-per-CU grids of batch 1-2 have no
+// other wave to cover an L2 round trip with)
+// TR: V is staged ROW-major straight from the qkv tensor (like K) and its fragments are read with ds_read_b64_tr_b16, the gfx950 LDS
+// transpose read: inside a 16-lane group lane i supplies the 8-byte address of (row i >> 2, columns 4 (i & 3) ..+3) of a 4 x 16 block
+// and receives column i of it (tools/ub/ub_tr.py prints the mapping) -- exactly "keys 4 g4 .. 4 g4 + 3 of d = r16", the A operand of
+// O^T = V^T P^T.  No k_transpose_v pass, no V^T workspace.  TR = false: the transposed-V workspace form (lab hook).
+template <int QTN, int NBUF, bool TR>
 __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict__ qkv, const half_t* __restrict__ vt,
                                                        half_t* __restrict__ out, int T, int C, float scale2) {
     constexpr int D = 64, KCH = 64, QPW = 16 * QTN, QPB = 4 * QPW;
-    __shared__ __attribute__((aligned(16))) char lds[2][2][KCH * 128];      // [buffer][K | Vt][64 rows x 128 B]
+    __shared__ __attribute__((aligned(16))) char lds[NBUF][2][KCH * 128];   // [buffer][K | Vt][64 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g4 = lane >> 4;
     const int heads = C / D;
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
     const int n = grp / heads, h = grp - n * heads;
     const size_t row_stride = (size_t)3 * C;
     const half_t* base = qkv + (size_t)n * T * row_stride + (size_t)h * 3 * D;
-    const half_t* vbase = vt + (((size_t)n * heads + h) * D) * T;
+    const half_t* vbase = TR ? nullptr : vt + (((size_t)n * heads + h) * D) * T;
     // Q fragments (B operand): column = query r16 of tile qt, k = d chunk ks*32 + 8 g4
     half8 qf[QTN][2];
 #pragma unroll
@@ -194,27 +206,76 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
             const int row = wave * 16 + p * 8 + lrow;                                   // key (K) / d (V^T)
             const int sl = lslot ^ ((row >> 1) & 7);                                    // source slot landing in physical slot lslot
             glds16a(base + (size_t)(k0 + row) * row_stride + D + sl * 8, &lds[buf][0][(wave * 16 + p * 8) * 128]);
-            glds16a(vbase + (size_t)row * T + k0 + sl * 8, &lds[buf][1][(wave * 16 + p * 8) * 128]);
+            if (TR) {
+                // V row = key, 128 B = 64 d.  Slot swizzle 2 ((key >> 1) & 3): the 8 keys x 32 B a 32-lane half reads tile one bank row
+                const int sv = lslot ^ (2 * ((row >> 1) & 3));
+                glds16a(base + (size_t)(k0 + row) * row_stride + 2 * D + sv * 8, &lds[buf][1][(wave * 16 + p * 8) * 128]);
+            } else {
+                glds16a(vbase + (size_t)row * T + k0 + sl * 8, &lds[buf][1][(wave * 16 + p * 8) * 128]);
+            }
         }
     };
-    stage(0, 0);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
+    uint32_t koff[2], voff[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) koff[ks] = r16 * 128 + (((ks * 4 + g4) ^ (r16 >> 1)) << 4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) voff[u][j] = r16 * 128 + (((4 * u + 2 * j + (g4 >> 1)) ^ (r16 >> 1)) << 4) + (g4 & 1) * 8;
+    // TR: this lane supplies key 4 g4 + (r16 >> 2) (+ 32 u + 16 j: immediate), d = 16 dt + 4 (r16 & 3); the swizzle term of the key
+    // is (2 g4 + (r16 >> 3)) & 3 for every (u, j), so one address per dt serves all four reads of that dt
+    uint32_t vtr[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        vtr[dt] = (4 * g4 + (r16 >> 2)) * 128 + ((2 * (dt ^ ((2 * g4 + (r16 >> 3)) & 3)) + ((r16 & 3) >> 1)) << 4) + (r16 & 1) * 8;
+    // the Q fragments are complete BEFORE the first chunk is requested: left to the compiler, their s_waitcnt vmcnt(0) lands at
+    // the first MFMA -- inside the loop, behind the prefetch, draining it in every iteration
+#pragma unroll
+    for (int qt = 0; qt < QTN; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[qt][ks]));
     const int nch = T / KCH;
+    stage(0, 0);
+    if (NBUF == 3 && nch > 1) stage(1, KCH);
+    int buf = 0;
     for (int ch = 0; ch < nch; ++ch) {
-        const int buf = ch & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                           // chunk `ch` landed for every wave; chunk ch-1 is fully consumed
-        if (ch + 1 < nch) stage(buf ^ 1, (ch + 1) * KCH);         // restage the buffer read in iteration ch-1 (one barrier per chunk)
-        const char* Kb = lds[buf][0];
-        const char* Vb = lds[buf][1];
-        // K fragments (A operand of S^T): row = key 16 kt + r16, slot ks*4 + g4
+        if (NBUF == 3 && ch + 1 < nch) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // chunk ch+1 (4 pieces per lane) stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // chunk `ch` landed for every wave; chunk ch-1 is fully consumed (its fragments fed MFMAs this wave has already issued).
+        // Raw barrier: __syncthreads() would drain the LDS-DMA queue and with it the chunk that is meant to stay in flight.
+        if (NBUF == 3) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        else __syncthreads();
+        // restage the buffer read in iteration ch-1 (one barrier per chunk)
+        if (NBUF == 3) { if (ch + 2 < nch) stage(buf == 0 ? 2 : buf - 1, (ch + 2) * KCH); }
+        else if (ch + 1 < nch) stage(buf ^ 1, (ch + 1) * KCH);
+        // Fragment reads are inline-asm ds_reads: behind a plain C++ read of `lds` the compiler drains the LDS-DMA queue first
+        // (s_waitcnt vmcnt(0) -- it cannot tell the chunk being prefetched from the one being read), which turned every chunk
+        // into a synchronous L2 round trip.  LDS returns in issue order; the waits below are counted by hand.
+        const uint32_t kb = lds0 + buf * (2 * KCH * 128), vb = kb + KCH * 128;
+        // K fragments (A operand of S^T): row = key 16 kt + r16, slot ks*4 + g4 (swizzle (row >> 1) & 7 = r16 >> 1 for every kt)
         half8 kf[4][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            const int row = kt * 16 + r16;
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                kf[kt][ks] = *reinterpret_cast<const half8*>(Kb + row * 128 + (((ks * 4 + g4) ^ ((row >> 1) & 7)) << 4));
-        }
+            for (int ks = 0; ks < 2; ++ks) PD_ATT_DSR128(kf[kt][ks], kb + koff[ks], kt * 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[2][0]), "+v"(kf[2][1]),
+                     "+v"(kf[3][0]), "+v"(kf[3][1]));
+        // V^T fragments (A operand of O^T): row d = 16 dt + r16; k-slots = keys 32u + 4 g4 + {0..3} and 32u + 16 + 4 g4 + {0..3}.
+        // Requested now, needed after the softmax: their LDS latency sits under the QK^T MFMAs and the exponentials.
+        half4 vlo[4][2], vhi[4][2];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)                             // (12 requests now, the last 4 below: the counter has 4 bits)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (TR) {
+                    PD_ATT_DSR64T(vlo[dt][u], vb + vtr[dt], u * 4096);
+                    PD_ATT_DSR64T(vhi[dt][u], vb + vtr[dt], u * 4096 + 2048);
+                } else {
+                    PD_ATT_DSR64(vlo[dt][u], vb + voff[u][0], dt * 2048);
+                    PD_ATT_DSR64(vhi[dt][u], vb + voff[u][1], dt * 2048);
+                }
+            }
         half8 pf[QTN][2];                                          // [query tile][k-step of 32 keys]
 #pragma unroll
         for (int qt = 0; qt < QTN; ++qt) {
@@ -230,15 +291,15 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[kt][r] *= scale2l; mx = fmaxf(mx, st[kt][r]); }   // log2 domain
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qt], mx);
+            const float mnew = fmaxf(mrun[qt], mx * scale2l);              // log2 domain; the scale is positive: max commutes with it
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[kt][r] = __builtin_amdgcn_exp2f(st[kt][r] - mnew); sum += st[kt][r]; }
+                for (int r = 0; r < 4; ++r) { st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], scale2l, -mnew)); sum += st[kt][r]; }   // scale and shift in one FMA
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             // lazy rescale: the running maximum of a query stops moving after its first few key chunks -- when no lane's maximum grew
@@ -259,22 +320,35 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pf[qt][u][r] = (half_t)st[2 * u][r]; pf[qt][u][4 + r] = (half_t)st[2 * u + 1][r]; }
         }
-        // O^T += V^T P^T: A = V^T fragment (row d = 16 dt + r16; k-slots = keys 32u + 4 g4 + {0..3} and 32u + 16 + 4 g4 + {0..3})
+        // O^T += V^T P^T
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            const int row = dt * 16 + r16;
-            const int sw = (row >> 1) & 7;
+            if (dt == 0) {
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (TR) {
+                        PD_ATT_DSR64T(vlo[3][u], vb + vtr[3], u * 4096);
+                        PD_ATT_DSR64T(vhi[3][u], vb + vtr[3], u * 4096 + 2048);
+                    } else {
+                        PD_ATT_DSR64(vlo[3][u], vb + voff[u][0], 3 * 2048);
+                        PD_ATT_DSR64(vhi[3][u], vb + voff[u][1], 3 * 2048);
+                    }
+                }
+            }
+            if (dt == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]));
+            if (dt == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]));
+            if (dt == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]));
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const half4 v0 = *reinterpret_cast<const half4*>(Vb + row * 128 + (((4 * u + (g4 >> 1)) ^ sw) << 4) + (g4 & 1) * 8);
-                const half4 v1 = *reinterpret_cast<const half4*>(Vb + row * 128 + (((4 * u + 2 + (g4 >> 1)) ^ sw) << 4) + (g4 & 1) * 8);
                 half8 vf;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                for (int e = 0; e < 4; ++e) { vf[e] = vlo[dt][u][e]; vf[4 + e] = vhi[dt][u][e]; }
 #pragma unroll
                 for (int qt = 0; qt < QTN; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][u], o[qt][dt], 0, 0, 0);
             }
         }
+        buf = (buf + 1 == NBUF) ? 0 : buf + 1;
     }
     // normalise and store: lane = query r16 of each tile, d = 16 dt + 4 g4 + r (8-byte packed stores)
 #pragma unroll
@@ -297,10 +371,20 @@ int attention(const half_t* qkv, half_t* out, int N, int T, int C, int D, hipStr
     PD_REQUIRE(C % D == 0 && T % QT == 0, "attention: need C %% D == 0 and T %% 64 == 0 (T=%d C=%d)", T, C);
     const float scale2 = 1.0f / sqrtf((float)D);
     if (vt_ws != nullptr && D == 64 && T % 128 == 0 && (N * (C / D)) % 8 == 0) {
-        k_transpose_v<<<dim3(T / 64, C / D, N), 256, 0, s>>>(qkv, vt_ws, T, C, D);
         PD_REQUIRE((N * (C / D)) % 8 == 0, "attention: N * heads must be a multiple of 8");
-        if ((T / 128) * (C / D) * N < 256) k_attention_t64<1><<<(T / 64) * (C / D) * N, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
-        else k_attention_t64<2><<<(T / 128) * (C / D) * N, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2);
+        const bool small = g_attn_qtn == 1 || (g_attn_qtn != 2 && (T / 128) * (C / D) * N < 256);
+        const int nbuf = g_attn_nbuf == 2 || g_attn_nbuf == 3 ? g_attn_nbuf : 3;
+        const int gs = (small ? T / 64 : T / 128) * (C / D) * N;
+#define ATT_LAUNCH(Q, B, R) k_attention_t64<Q, B, R><<<gs, 256, 0, s>>>(qkv, vt_ws, out, T, C, scale2)
+#define ATT_BY_BUF(Q, R) do { if (nbuf == 3) ATT_LAUNCH(Q, 3, R); else ATT_LAUNCH(Q, 2, R); } while (0)
+        if (g_attn_vt != 0) {
+            k_transpose_v<<<dim3(T / 64, C / D, N), 256, 0, s>>>(qkv, vt_ws, T, C, D);
+            if (small) ATT_BY_BUF(1, false); else ATT_BY_BUF(2, false);
+        } else {
+            if (small) ATT_BY_BUF(1, true); else ATT_BY_BUF(2, true);
+        }
+#undef ATT_BY_BUF
+#undef ATT_LAUNCH
         PD_LAUNCH_CHECK();
         return PDHIP_OK;
     }

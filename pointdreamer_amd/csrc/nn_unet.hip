@@ -796,6 +796,12 @@ extern "C" int pdhip_debug_set_conv_sk(int mode, int tile, int splits) {
 }
 extern "C" int pdhip_debug_set_conv_sk_stages(int stages) { int old = pdnn::g_sk_stages; pdnn::g_sk_stages = stages; return old; }
 extern "C" int pdhip_debug_set_conv_sk_kgroups(int kg) { int old = pdnn::g_sk_kg; pdnn::g_sk_kg = kg; return old; }
+namespace pdnn { extern thread_local int g_attn_nbuf, g_attn_vt, g_attn_qtn; }
+extern "C" int pdhip_debug_set_attn(int nbuf, int vt_form, int qtiles) {
+    int old = pdnn::g_attn_nbuf | (pdnn::g_attn_vt << 8) | (pdnn::g_attn_qtn << 16);
+    pdnn::g_attn_nbuf = nbuf; pdnn::g_attn_vt = vt_form; pdnn::g_attn_qtn = qtiles;
+    return old;
+}
 extern "C" int pdhip_debug_set_conv_sk_order(int order) { int old = pdnn::g_sk_order; pdnn::g_sk_order = order; return old; }
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */

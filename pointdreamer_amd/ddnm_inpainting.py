@@ -53,6 +53,7 @@ _reg('pdhip_debug_set_conv_sk', C.c_int, [i32, i32, i32])
 _reg('pdhip_debug_set_conv_sk_stages', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk_kgroups', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk_order', C.c_int, [i32])
+_reg('pdhip_debug_set_attn', C.c_int, [i32, i32, i32])
 _reg('pdhip_debug_conv3x3_apply', C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_attention_f16', C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_philox_normal', C.c_int, [vp, C.c_longlong, u64, u64, vp])

@@ -155,7 +155,16 @@ def test_attention_vs_torch(nn, N, T, Cc, D):
     assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, None, _stream()) == 0, L.pdhip_last_error()
     out2 = torch.empty_like(out)                          # transposed-V kernel (T % 128 == 0, D == 64), same reference
     vt = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
-    assert L.pdhip_attention_f16(_ptr(qd), _ptr(out2), N, T, Cc, D, _ptr(vt), _stream()) == 0, L.pdhip_last_error()
+    outs = []
+    # K / V chunks requested one or two iterations ahead; V read with the LDS transpose read or from a transposed workspace:
+    # the same operands in the same order -> the same bits
+    for nbuf, vt_form, qt in ((2, 0, 0), (3, 0, 1), (2, 1, 2), (3, 1, 0), (3, 0, 2), (0, 0, 0)):
+        L.pdhip_debug_set_attn(nbuf, vt_form, qt)
+        out2.zero_()
+        assert L.pdhip_attention_f16(_ptr(qd), _ptr(out2), N, T, Cc, D, _ptr(vt), _stream()) == 0, L.pdhip_last_error()
+        outs.append(out2.clone())
+    for o_ in outs[1:]:
+        assert torch.equal(outs[0], o_)
     o = out.float().cpu().permute(0, 2, 1)
     assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
     o2 = out2.float().cpu().permute(0, 2, 1)

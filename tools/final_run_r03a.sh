@@ -3,7 +3,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03
 mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/tests.log
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|Error|FAILED" | tail -8 > $O/tests.log
 python bench.py 2> $O/bench.err | tail -1 > $O/bench_full_100steps.json
 python bench.py --shapes-per-step 1 --no-cpu-baseline --no-extras 2> $O/bench1.err | tail -1 > $O/bench_full_100steps_1shape.json
 python bench.py --workload nearest --steps 20 --warmup 3 --no-cpu-baseline --no-extras 2> $O/benchn.err | tail -1 > $O/bench_nearest.json
