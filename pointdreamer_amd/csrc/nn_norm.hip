@@ -363,7 +363,10 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     // pixels per thread: 32 on the big tensors (constants amortised), fewer on the small ones so that the grid still fills
     // the chip (a 64-pixel 8x8 level with 32 pixels per thread is 8 workgroups walking a serial latency chain)
     int iters = GNA_ITERS;
-    while (iters > 1 && (long long)cdiv((long long)Ho * Wo, pps * iters) * N < 2048) iters >>= 1;
+    // (with the in-kernel statistics every workgroup pays the re-reduction of its image's partials first: fewer, longer workgroups --
+    // 512 against 2 048 is -2.3 % on the batch-1 forward, -1 % at batch 8; tools/time_unet.py)
+    const int tgt_blocks = parts != nullptr ? 512 : 2048;
+    while (iters > 1 && (long long)cdiv((long long)Ho * Wo, pps * iters) * N < tgt_blocks) iters >>= 1;
     dim3 grid(cdiv((long long)Ho * Wo, pps * iters), N);
 #define GNA_ARGS X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw, gp
 #define GNA_LAUNCH(R, O, F) do { if (parts) k_gn_apply<R, O, F, true><<<grid, 256, 0, s>>>(GNA_ARGS); else k_gn_apply<R, O, F, false><<<grid, 256, 0, s>>>(GNA_ARGS); } while (0)
