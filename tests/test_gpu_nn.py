@@ -139,7 +139,7 @@ def test_output_head_f32_equivalent_vs_torch(nn, N, H, W, Cc, Cout):
     assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
 
 
-@pytest.mark.parametrize("N,T,Cc,D", [(1, 64, 128, 64), (2, 256, 128, 32), (1, 1024, 512, 64), (4, 1024, 512, 64), (1, 256, 1024, 64), (2, 64, 1024, 64), (2, 256, 128, 64), (3, 128, 64, 64)])
+@pytest.mark.parametrize("N,T,Cc,D", [(1, 64, 128, 64), (2, 256, 128, 32), (1, 1024, 512, 64), (4, 1024, 512, 64), (1, 256, 1024, 64), (2, 64, 1024, 64), (2, 256, 128, 64), (3, 128, 64, 64), (1, 128, 512, 64), (2, 384, 256, 64)])
 def test_attention_vs_torch(nn, N, T, Cc, D):
     L = nn['L']
     g = torch.Generator().manual_seed(T + Cc)

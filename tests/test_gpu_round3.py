@@ -262,3 +262,28 @@ def test_shape_graphs_replay_equals_eager(nn):
         pipeline.ShapeGraphs(1, NP, g['vertices'], g['faces'], g['f_normals'], xa, ci, V, RES, CAM, **dict(cfg, optimize_from='ours'))
     with pytest.raises(ValueError):
         sg.run([(clouds[0][0][:100], clouds[0][1][:100])])
+
+
+@pytest.mark.parametrize("film", [False, True])
+def test_groupnorm_apply_is_independent_of_pixels_per_thread(nn, film):
+    """k_gn_apply picks its pixels-per-thread from the launch size, so the same image goes through the 4-pixel main loop at batch 8 and
+    through the 1-pixel tail loop at batch 1: the bits must not depend on that (they did, by one f16 ulp in 4e-5 of the elements,
+    while the compiler was free to fuse an op with the f16 rounding behind it in one copy of the loop and not in the other)."""
+    L = nn['L']
+    H = W = 128; Cc = 256
+    g = torch.Generator().manual_seed(3)
+    x1 = (torch.randn((1, H, W, Cc), generator=g) * 1.3 + 0.2).half()
+    gamma = (1 + 0.2 * torch.randn((Cc,), generator=g)).to(DEV); beta = (0.2 * torch.randn((Cc,), generator=g)).to(DEV)
+    fl1 = 0.3 * torch.randn((1, 2 * Cc), generator=g)
+    outs = []
+    for N in (1, 8):
+        xd = x1.repeat(N, 1, 1, 1).contiguous().to(DEV)
+        fd = fl1.repeat(N, 1).contiguous().to(DEV) if film else None
+        y = torch.empty_like(xd)
+        stats = torch.empty((N * 64,), device=DEV); ws = torch.empty((N * 64 * ((H * W + 255) // 256),), device=DEV)
+        rc = L.pdhip_groupnorm_nhwc_f16(_ptr(xd), _ptr(gamma), _ptr(beta), _ptr(fd) if film else None, N, H, W, Cc, 1, 0, _ptr(y), _ptr(stats),
+                                        _ptr(ws), ws.numel(), _stream())
+        assert rc == 0, L.pdhip_last_error()
+        torch.cuda.synchronize()
+        outs.append(y.cpu())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[1][7])
