@@ -311,7 +311,7 @@ size_t pdhip_unet_head_ws_floats(int N, int H, int W, int C, int Cout);
 int pdhip_unet_head_f32(const void* x, const float* gamma, const float* beta, const float* w_oihw, const float* bias,
                         int N, int H, int W, int C, int Cout, float* y_nchw, float* ws, long long ws_floats, void* stream);
 int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim,
-                        void* vt_ws /*N*T*C halfs: enables the transposed-V kernel for T % 128 == 0, head_dim 64; may be NULL*/, void* stream);
+                        void* vt_ws /*N*T*C halfs, non-NULL selects the 128-query MFMA kernel for T % 128 == 0, head_dim 64, N*heads % 8 == 0 (QKVAttentionLegacy, unet.py:341-373); the buffer is written only in the transposed-V lab form (pdhip_debug_set_attn); NULL: the 64-query kernel*/, void* stream);
 int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream);
 
 #ifdef __cplusplus
