@@ -153,6 +153,21 @@ typedef __attribute__((address_space(3))) void lds_void_a;
 typedef const __attribute__((address_space(1))) void gbl_void_a;
 __device__ __forceinline__ void glds16a(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_void_a*)g, (lds_void_a*)l, 16, 0, 0); }
 
+// all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) without the LDS: v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the
+// second -- fed the same value twice, the two results hold both partners of every lane.  (__shfl_xor compiles to ds_bpermute_b32: an
+// LDS round trip and an lgkmcnt(0) wait on the softmax's critical path, four per query tile and chunk.)
+__device__ __forceinline__ float xr_max(float x) {
+    // (v_max_f32 through asm: fmaxf on the bit-cast halves would be preceded by a canonicalising v_max x, x each)
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    unsigned m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a[0]), "v"(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(b[0]), "v"(b[1]));
+    return r;
+}
+
 // QTN: 16-query tiles per wave (2: 128 queries per workgroup; 1: 64 -- twice the workgroups for the small grids of batch 1-2, where
 // 8 heads x 8 query blocks are 64 workgroups on 256 CUs)
 // NBUF: LDS chunk buffers; 3 = K / V^T chunks requested TWO iterations ahead (the one-workgroup-per-CU grids of batch 1-2 have no
@@ -161,12 +176,14 @@ __device__ __forceinline__ void glds16a(const void* g, void* l) { __builtin_amdg
 // transpose read: inside a 16-lane group lane i supplies the 8-byte address of (row i >> 2, columns 4 (i & 3) ..+3) of a 4 x 16 block
 // and receives column i of it (tools/ub/ub_tr.py prints the mapping) -- exactly "keys 4 g4 .. 4 g4 + 3 of d = r16", the A operand of
 // O^T = V^T P^T.  No k_transpose_v pass, no V^T workspace.  TR = false: the transposed-V workspace form (lab hook).
+// Register budget: left alone the compiler takes 208 registers for QTN = 2 (two waves per SIMD); held to three waves per SIMD it fits
+// 160 without spilling, and the third wave is what covers the per-chunk barrier and the LDS-DMA issue stalls of the other two.
 template <int QTN, int NBUF, bool TR>
-__global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict__ qkv, const half_t* __restrict__ vt,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((QTN == 2 || NBUF == 3) ? 3 : 4, (QTN == 2 || NBUF == 3) ? 3 : 4))) void k_attention_t64(const half_t* __restrict__ qkv, const half_t* __restrict__ vt,
                                                        half_t* __restrict__ out, int T, int C, float scale2) {
     constexpr int D = 64, KCH = 64, QPW = 16 * QTN, QPB = 4 * QPW;
     __shared__ __attribute__((aligned(16))) char lds[NBUF][2][KCH * 128];   // [buffer][K | Vt][64 rows x 128 B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: LDS-DMA destinations in SGPRs)
     const int r16 = lane & 15, g4 = lane >> 4;
     const int heads = C / D;
     const float scale2l = scale2 * 1.4426950408889634f;            // softmax in the log2 domain: exp(x) = 2^(x log2 e)
@@ -191,28 +208,39 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
     }
     (void)scale2l;
     float4_t o[QTN][4];
-    float mrun[QTN], lrun[QTN];
+    // the softmax denominators are a fifth accumulator tile of the PV product: V^T extended by a row of ones gives
+    // l[q] = sum_k P[k][q] from the MATRIX pipe (every register of the tile holds the lane's query's sum) -- the kernel is bound by
+    // VALU issue, the 16 adds + 2 cross-row exchanges per query tile and chunk were a fifth of it.  (The sum is then over the
+    // f16-rounded weights, i.e. exactly the weights the numerator uses.)
+    float mrun[QTN];
+    float4_t ol[QTN];
 #pragma unroll
     for (int qt = 0; qt < QTN; ++qt) {
-        mrun[qt] = -INFINITY; lrun[qt] = 0.f;
+        mrun[qt] = -INFINITY; ol[qt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (float4_t){0.f, 0.f, 0.f, 0.f};
     }
     // loader: wave w stages rows 16 w .. 16 w + 15 of the K chunk and of the V^T chunk (2 + 2 pieces of 8 rows x 128 B)
     const int lrow = lane >> 3, lslot = lane & 7;
-    auto stage = [&](int buf, int k0) {
+    // running source pointers of this lane's four pieces, advanced by one chunk per call (chunks are staged in order): the 64-bit
+    // address arithmetic per piece (row * stride + ...) was ~40 VALU instructions per chunk in a loop that is issue-bound
+    const half_t* kp[2];
+    const half_t* vp[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = wave * 16 + p * 8 + lrow;                                       // key (K, V) / d (V^T workspace form)
+        const int sl = lslot ^ ((row >> 1) & 7);                                        // source slot landing in physical slot lslot
+        kp[p] = base + (size_t)row * row_stride + D + sl * 8;
+        // TR: V row = key, 128 B = 64 d.  Slot swizzle 2 ((key >> 1) & 3): the 8 keys x 32 B a 32-lane half reads tile one bank row
+        vp[p] = TR ? base + (size_t)row * row_stride + 2 * D + (lslot ^ (2 * ((row >> 1) & 3))) * 8 : vbase + (size_t)row * T + sl * 8;
+    }
+    const size_t kstep = (size_t)KCH * row_stride, vstep = TR ? kstep : (size_t)KCH;
+    auto stage = [&](int buf, int) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int row = wave * 16 + p * 8 + lrow;                                   // key (K) / d (V^T)
-            const int sl = lslot ^ ((row >> 1) & 7);                                    // source slot landing in physical slot lslot
-            glds16a(base + (size_t)(k0 + row) * row_stride + D + sl * 8, &lds[buf][0][(wave * 16 + p * 8) * 128]);
-            if (TR) {
-                // V row = key, 128 B = 64 d.  Slot swizzle 2 ((key >> 1) & 3): the 8 keys x 32 B a 32-lane half reads tile one bank row
-                const int sv = lslot ^ (2 * ((row >> 1) & 3));
-                glds16a(base + (size_t)(k0 + row) * row_stride + 2 * D + sv * 8, &lds[buf][1][(wave * 16 + p * 8) * 128]);
-            } else {
-                glds16a(vbase + (size_t)row * T + k0 + sl * 8, &lds[buf][1][(wave * 16 + p * 8) * 128]);
-            }
+            glds16a(kp[p], &lds[buf][0][(wave * 16 + p * 8) * 128]);
+            glds16a(vp[p], &lds[buf][1][(wave * 16 + p * 8) * 128]);
+            kp[p] += kstep; vp[p] += vstep;
         }
     };
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0][0];
@@ -277,50 +305,65 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
                 }
             }
         half8 pf[QTN][2];                                          // [query tile][k-step of 32 keys]
+        // The query tiles go through the softmax side by side in straight-line code (one rescale branch for all of them): a branch per
+        // tile cut the block in two and left each tile's max -> exp2 -> convert chain to run alone.
+        float4_t st[QTN][4];
+        float mnew[QTN];
 #pragma unroll
-        for (int qt = 0; qt < QTN; ++qt) {
-            float4_t st[4];
+        for (int qt = 0; qt < QTN; ++qt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                st[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                st[qt][kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[qt][ks], st[kt], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) st[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ks], qf[qt][ks], st[qt][kt], 0, 0, 0);
             }
+        bool grew = false;
+#pragma unroll
+        for (int qt = 0; qt < QTN; ++qt) {
             // this lane: query r16 of the tile, keys 16 kt + 4 g4 + r
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qt], mx * scale2l);              // log2 domain; the scale is positive: max commutes with it
-            float sum = 0.f;
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[qt][kt][r]);
+            mx = xr_max(mx);
+            mnew[qt] = fmaxf(mrun[qt], mx * scale2l);                      // log2 domain; the scale is positive: max commutes with it
+            grew |= mnew[qt] > mrun[qt];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], scale2l, -mnew)); sum += st[kt][r]; }   // scale and shift in one FMA
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            // lazy rescale: the running maximum of a query stops moving after its first few key chunks -- when no lane's maximum grew
-            // (wave-uniform test) alpha is exactly 1 for every lane and the 16 multiplies of O and the exp2 are skipped
-            if (__builtin_amdgcn_ballot_w64(mnew > mrun[qt]) != 0ull) {
-                const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-                lrun[qt] = lrun[qt] * alpha + sum;
+                for (int r = 0; r < 4; ++r) st[qt][kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][kt][r], scale2l, -mnew[qt]));   // scale and shift in one FMA
+        }
+        // lazy rescale: the running maximum of a query stops moving after its first few key chunks -- when no lane's maximum grew
+        // (wave-uniform test) alpha is exactly 1 for every lane and the multiplies of O and the exp2 are skipped
+        if (__builtin_amdgcn_ballot_w64(grew) != 0ull) {
+#pragma unroll
+            for (int qt = 0; qt < QTN; ++qt) {
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew[qt]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ol[qt][r] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[qt][dt][r] *= alpha;
-            } else {
-                lrun[qt] += sum;
             }
-            mrun[qt] = mnew;
+        }
+#pragma unroll
+        for (int qt = 0; qt < QTN; ++qt) {
+            mrun[qt] = mnew[qt];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { pf[qt][u][r] = (half_t)st[2 * u][r]; pf[qt][u][4 + r] = (half_t)st[2 * u + 1][r]; }
+                for (int r = 0; r < 4; ++r) { pf[qt][u][r] = (half_t)st[qt][2 * u][r]; pf[qt][u][4 + r] = (half_t)st[qt][2 * u + 1][r]; }
         }
-        // O^T += V^T P^T
+        // O^T += V^T P^T (+ the row of ones)
+        {
+            const half8 ones = (half8){(half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f, (half_t)1.f};
+#pragma unroll
+            for (int qt = 0; qt < QTN; ++qt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) ol[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt][u], ol[qt], 0, 0, 0);
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             if (dt == 0) {
@@ -354,7 +397,7 @@ __global__ __launch_bounds__(256) void k_attention_t64(const half_t* __restrict_
 #pragma unroll
     for (int qt = 0; qt < QTN; ++qt) {
         const int q = qb * QPB + wave * QPW + qt * 16 + r16;
-        const float inv = 1.0f / lrun[qt];
+        const float inv = 1.0f / ol[qt][0];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             half4 hv;
