@@ -275,6 +275,15 @@ int pdhip_debug_set_conv_sk_stages(int stages);   /* lab hook: LDS stage count o
 int pdhip_debug_set_conv_sk_kgroups(int kg);   /* lab hook: K-groups (4-wave groups working on alternate K-steps of one tile) per workgroup of the small-M conv kernel: 1, 2, 4 (64-row tiles), 8 = loader-specialised (4 compute + 4 loader waves); 0 = default */
 int pdhip_debug_set_attn(int nbuf, int vt_form, int qtiles);   /* lab hook, T >= 128 attention kernel: qtiles = 16-query tiles per wave, 1 (64 queries per workgroup) or 2 (128), 0 automatic; nbuf = LDS chunk buffers, 2 (K / V requested one chunk ahead), 3 (two ahead), 0 automatic; vt_form 1 = V transposed into the workspace by a separate pass and read plainly, 0 = V staged row-major and read with the LDS transpose read */
 int pdhip_debug_set_conv_sk_order(int order);   /* lab hook: tile order of the small-M conv kernel inside an XCD's run: 0 automatic, 1 pixel tiles fastest (weight slices shared through L2), 2 n-tiles fastest */
+/* h0 = silu(GroupNorm32(x)) AND sk = conv1x1(x) (C -> 256 channels) in ONE pass over x: the in_layers normalisation and the
+ * skip_connection of a channel-changing ResBlock (unet.py:197-209, 236-256) both read the block input, which for the decoder blocks is a
+ * channel concat [xa (Ca channels) | xb (C - Ca)] that is never materialised (unet.py:657-659; xb NULL: x = xa, Ca == C).  stats [N][32][2] =
+ * (mean, rstd) of x per GroupNorm group, finished (pdhip_groupnorm_nhwc_f16's stats_ws).  C % 256 == 0, Ca % 64 == 0, H*W % 128 == 0;
+ * w_packed [256][C] f16, bias [256] f32 or NULL; h0 [N,H,W,C], sk [N,H,W,256] f16. */
+int pdhip_gn_silu_skip1x1_nhwc_f16(const void* xa, const void* xb, int Ca, int C, const float* stats, const float* gamma, const float* beta,
+                                   const void* w_packed, const float* bias, void* h0, void* sk, int N, int H, int W, void* stream);
+int pdhip_debug_set_gn_skip_variant(int v);   /* lab hook of the one-pass GroupNorm + skip kernel: 0 = two workgroups per CU, 1 (default) = one workgroup per CU with activation chunks requested three K-steps ahead; returns the previous value */
+int pdhip_debug_set_fuse_skip(int mode, int min_tiles);   /* ResBlock GroupNorm-apply + skip 1x1 as one pass: mode 0 never / 1 (default) layers of at least min_tiles 128-pixel tiles (default 1024; <= 0 keeps the value) / 2 every eligible layer; returns the previous mode */
 int pdhip_debug_set_fuse_gn(int on);   /* 1: the UNet uses the fused form wherever the halo kernel serves a conv; 0 (default, measured faster): stand-alone passes */
 /* ---- complete_unseen_by='neighbor' (pointdreamer/unproject.py:93-196, demo.py:180-200).
  * The mesh subdivision stays on the host (as in the reference); these are the per-texel / per-vertex kernels. */

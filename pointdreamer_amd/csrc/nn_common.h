@@ -27,7 +27,7 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
 extern thread_local int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
-extern thread_local int g_fuse_gn, g_fold_resample, g_fold_finalize;                                                   // tuning hook (nn_unet.hip)
+extern thread_local int g_fuse_gn, g_fold_resample, g_fold_finalize, g_fuse_skip;                                                   // tuning hook (nn_unet.hip)
 extern thread_local float* g_dbg_splitk_ws; extern thread_local size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
@@ -67,6 +67,11 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
 // input transform of the APPLY variant of the halo conv (the stand-alone gn_apply pass disappears)
 int gn_table(const float* stats, const float* gamma, const float* beta, const float* film, long long film_stride, int N, int C,
              float* table, hipStream_t s);
+// GroupNorm-apply (+ SiLU) of a ResBlock input AND the block's skip 1x1 conv (C -> 256) in one pass over x = [XA | XB] (channel concat,
+// XB may be null when Ca == C): H0 [N,HW,C] = silu(GN(x)), SK [N,HW,256] = f16(Wt x + bias).  stats [N][32][2] finished.
+bool gn_skip_eligible(int N, int HW, int Ca, int C, int Cout, int Cout_pad);
+int gn_skip(const half_t* XA, const half_t* XB, int Ca, int C, const float* stats, const float* gamma, const float* beta, const half_t* Wt,
+            const float* bias, half_t* H0, half_t* SK, int N, int HW, hipStream_t s);
 int resample2x(const half_t* X, int N, int H, int W, int C, int mode, half_t* Y, hipStream_t s);
 int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long pixels, half_t* Y, hipStream_t s);
 

@@ -437,4 +437,241 @@ int concat_channels(const half_t* A, int Ca, const half_t* B, int Cb, long long 
     return PDHIP_OK;
 }
 
+// ---- GroupNorm-apply + skip 1x1 of a channel-changing ResBlock in ONE pass over x (unet.py:197-209, 236-256: in_layers' GroupNorm32 ->
+// SiLU and skip_connection = conv_nd(1) both read the block input).  The decoder blocks of the 256^2 / 128^2 levels read a 512- /
+// 768-channel concat: as two launches (k_gn_apply, k_conv_igemm<1>) x is streamed from HBM twice (2 x 2.15 GB at UNet batch 32, 256^2).
+// Here a workgroup owns 128 pixels x all C input channels: per 64-channel chunk every thread loads 4 x 16 B of x ONCE, parks the raw
+// values in LDS as the MFMA operand of the skip GEMM (128 x 256 x 64 per chunk, weights chunk from L2) and stores silu(GN(x)) of the same
+// registers to h0.  HBM-bound by construction (MFMA time is a quarter of the stream time); two workgroups per CU overlap each other's
+// load waits.  Same arithmetic as the two-launch form: gn_elem on the f16 input, skip = f16(acc + bias).
+constexpr int GS_BM = 128, GS_BN = 256, GS_CLD = GS_BN + 8;
+constexpr int GS_SMEM = GS_BM * GS_CLD * 2;                 // epilogue staging [128][264] f16 = 67 584 B >= K-loop tiles (16 + 32 KiB)
+
+// epilogue shared by the variants: lane holds pixel 16 i + (lane & 15), channels 16 j + 4 (lane >> 4) + r (weights x activations) ->
+// f16(acc + bias) -> LDS -> 16-byte coalesced NHWC rows.  The caller has synchronised: the staging area is free.
+__device__ __forceinline__ void gs_epilogue(const float4_t (&acc)[4][8], char* smem, const float* __restrict__ bias, half_t* __restrict__ SK,
+                                            long long m0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    half_t* const Cs = reinterpret_cast<half_t*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int nl = wn * 128 + j * 16 + (lane >> 4) * 4;
+        float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) bv = *reinterpret_cast<const float4_t*>(bias + nl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + (lane & 15);
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
+            *reinterpret_cast<half4*>(&Cs[ml * GS_CLD + nl]) = h;
+        }
+    }
+    __syncthreads();
+    const int col8 = (tid & 31) * 8;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int row = p * 8 + (tid >> 5);
+        *reinterpret_cast<half8*>(SK + (size_t)(m0 + row) * GS_BN + col8) = *reinterpret_cast<const half8*>(&Cs[row * GS_CLD + col8]);
+    }
+}
+// one 64-deep K-step of the skip GEMM on the staged tiles (wave tile 64 px x 128 co)
+__device__ __forceinline__ void gs_mfma_step(float4_t (&acc)[4][8], const char* As, const char* Ws, int lane, int wm, int wn) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int fo = ((kk * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+        half8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + (wm * 64 + i * 16 + (lane & 15)) * 128 + fo);
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            half8 b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Ws + (wn * 128 + (jh * 4 + j) * 16 + (lane & 15)) * 128 + fo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][jh * 4 + j], 0, 0, 0);
+        }
+    }
+}
+
+// a wave-uniform pointer pinned to scalar registers (the compiler otherwise keeps selected / loop-carried bases in VGPR pairs)
+template <typename T> __device__ __forceinline__ T* gs_uniform(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// variant 0: two workgroups per CU, loads requested under the MFMA phase of the previous chunk
+__global__ __launch_bounds__(256, 2) void k_gn_skip(const half_t* __restrict__ XA, const half_t* __restrict__ XB, int Ca, int C,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const half_t* __restrict__ Wt,
+                                                    const float* __restrict__ bias, half_t* __restrict__ H0, half_t* __restrict__ SK,
+                                                    int HW) {
+    extern __shared__ __align__(16) char gs_smem[];
+    char* const As = gs_smem;                                // activations [128 px][64 ch] f16, 16-byte slots XOR-swizzled by (row & 7)
+    char* const Ws = gs_smem + GS_BM * 128;                  // weights     [256 co][64 ch]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const long long m0 = (long long)blockIdx.x * GS_BM;
+    const int n = (int)(m0 / HW), cg = C / 32, Cb = C - Ca, KC = C / 64;
+    const int slot = tid & 7, prow = tid >> 3;
+    half8 xa[4], wr[8];
+    float4_t g0, g1, b0, b1;
+    float mean, rstd;
+    auto issue = [&](int kc) {
+        const int c0 = kc * 64 + slot * 8;
+        const bool second = c0 >= Ca;                         // (uniform over the workgroup: Ca % 64 == 0)
+        const half_t* const src = second ? XB + (size_t)m0 * Cb + (c0 - Ca) : XA + (size_t)m0 * Ca + c0;
+        const int cs = second ? Cb : Ca;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const half8*>(src + (size_t)(prow + 32 * j) * cs);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wr[j] = *reinterpret_cast<const half8*>(Wt + (size_t)(prow + 32 * j) * C + c0);
+        g0 = *reinterpret_cast<const float4_t*>(gamma + c0); g1 = *reinterpret_cast<const float4_t*>(gamma + c0 + 4);
+        b0 = *reinterpret_cast<const float4_t*>(beta + c0);  b1 = *reinterpret_cast<const float4_t*>(beta + c0 + 4);
+        const float* st = stats + ((size_t)n * 32 + c0 / cg) * 2;   // (an octet lies inside one group: cg % 8 == 0)
+        mean = st[0]; rstd = st[1];
+    };
+    float4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    issue(0);
+    for (int kc = 0; kc < KC; ++kc) {
+        if (kc > 0) __syncthreads();                          // the previous chunk's fragment reads are done
+        const int sw = (slot ^ (prow & 7)) << 4;              // (rows prow + 32 j share prow & 7)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<half8*>(As + (prow + 32 * j) * 128 + sw) = xa[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<half8*>(Ws + (prow + 32 * j) * 128 + sw) = wr[j];
+        {   // h0 = silu(GN(x)) of the registers just parked
+            float ga[8], gb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                ga[e] = rstd * (e < 4 ? g0[e] : g1[e - 4]);
+                gb[e] = (e < 4 ? b0[e] : b1[e - 4]) - mean * ga[e];
+            }
+            const int c0 = kc * 64 + slot * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = (half_t)gn_elem<false, false>((float)xa[j][e], ga[e], gb[e], 1.f, 0.f, 1);
+                *reinterpret_cast<half8*>(H0 + (size_t)(m0 + prow + 32 * j) * C + c0) = hv;
+            }
+        }
+        __syncthreads();
+        if (kc + 1 < KC) issue(kc + 1);                       // in flight under this chunk's MFMAs (and the other workgroup's)
+        gs_mfma_step(acc, As, Ws, lane, wm, wn);
+    }
+    __syncthreads();
+    gs_epilogue(acc, gs_smem, bias, SK, m0, tid);
+}
+
+// variant 1: two workgroups per CU like variant 0, but the activation chunk k + 1 is requested at the TOP of iteration k (second
+// register set) and is in flight for the whole iteration -- GroupNorm math, barrier, MFMA phase -- instead of one MFMA phase
+// (0.45 us against an HBM latency of several us under load); the weight chunk k + 1 (L2) is requested under the MFMAs of chunk k and
+// parked first thing in iteration k + 1, so it is never live across the GroupNorm math (register budget 256); the affine constants
+// of the image sit in LDS.  Loads past the last chunk are clamped (re-read, unused): the loop body has no branches.
+constexpr int GS1_SMEM = GS_SMEM;                           // tiles 48 KiB + constants C * 8 B <= 16 KiB < epilogue staging 66 KiB
+__global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict__ XA, const half_t* __restrict__ XB, int Ca, int C,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const half_t* __restrict__ Wt,
+                                                       const float* __restrict__ bias, half_t* __restrict__ H0, half_t* __restrict__ SK,
+                                                       int HW) {
+    extern __shared__ __align__(16) char gs_smem[];
+    char* const As = gs_smem;
+    char* const Ws = gs_smem + GS_BM * 128;
+    float* const Gs = reinterpret_cast<float*>(gs_smem + GS_BM * 128 + GS_BN * 128);   // [C/8][16] = (ga0..7, gb0..7) per channel octet
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const long long m0 = (long long)blockIdx.x * GS_BM;
+    const int n = (int)(m0 / HW), cg = C / 32, Cb = C - Ca, KC = C / 64;
+    const int slot = tid & 7, prow = tid >> 3;
+    const int sw = (slot ^ (prow & 7)) << 4;                  // (rows prow + 32 j share prow & 7)
+    half8 xa[2][4], wr[8];
+    // addressing: wave-uniform 64-bit bases (scalar registers) + 32-bit per-lane byte offsets that do not depend on the chunk
+    const unsigned offA = (unsigned)(prow * Ca + slot * 8) * 2u, offB = (unsigned)(prow * Cb + slot * 8) * 2u;   // row prow of XA / XB
+    const unsigned offC = (unsigned)(prow * C + slot * 8) * 2u;                                                  // row prow of Wt / H0
+    const char* const baseA = reinterpret_cast<const char*>(XA + (size_t)m0 * Ca);
+    const char* const baseB = reinterpret_cast<const char*>(XB + (size_t)m0 * Cb);
+    const char* const baseW = reinterpret_cast<const char*>(Wt);
+    char* const baseH = reinterpret_cast<char*>(H0 + (size_t)m0 * C);
+    auto issue_acts = [&](int kc, half8* dst) {
+        const int cu = min(kc, KC - 1) * 64;                  // (uniform)
+        const bool second = cu >= Ca;                         // (uniform over the workgroup: Ca % 64 == 0)
+        const char* const src = gs_uniform(second ? baseB + (size_t)(cu - Ca) * 2 : baseA + (size_t)cu * 2);
+        const unsigned off = second ? offB : offA, rs = (unsigned)(second ? Cb : Ca) * 64u;   // 32 rows in bytes
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const half8*>(src + (off + j * rs));
+    };
+    auto issue_w = [&](int kc) {
+        const char* const src = gs_uniform(baseW + (size_t)(min(kc, KC - 1) * 64) * 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wr[j] = *reinterpret_cast<const half8*>(src + (offC + j * ((unsigned)C * 64u)));
+    };
+    issue_acts(0, xa[0]); issue_w(0);
+    // the affine constants of this image, once per workgroup: ga = rstd gamma, gb = beta - mean ga (k_gn_apply's expressions)
+    for (int c = tid; c < C; c += 256) {
+        const float* st = stats + ((size_t)n * 32 + c / cg) * 2;
+        const float ga = st[1] * gamma[c];
+        Gs[(c >> 3) * 16 + (c & 7)] = ga;
+        Gs[(c >> 3) * 16 + 8 + (c & 7)] = beta[c] - st[0] * ga;
+    }
+    float4_t acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    auto step = [&](int kc, const half8* cur, half8* nxt) {
+        __syncthreads();                                      // the previous chunk's fragment reads are done (kc == 0: Gs is complete)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<half8*>(Ws + (prow + 32 * j) * 128 + sw) = wr[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<half8*>(As + (prow + 32 * j) * 128 + sw) = cur[j];
+        issue_acts(kc + 1, nxt);
+        const int c0 = kc * 64 + slot * 8;
+        const float4_t* gp = reinterpret_cast<const float4_t*>(Gs + (c0 >> 3) * 16);
+        const float4_t a0 = gp[0], a1 = gp[1], b0 = gp[2], b1 = gp[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                hv[e] = (half_t)gn_elem<false, false>((float)cur[j][e], e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3], 1.f, 0.f, 1);
+            *reinterpret_cast<half8*>(gs_uniform(baseH + (size_t)(kc * 64) * 2) + (offC + j * ((unsigned)C * 64u))) = hv;
+        }
+        __syncthreads();
+        issue_w(kc + 1);
+        gs_mfma_step(acc, As, Ws, lane, wm, wn);
+    };
+    for (int kc = 0; kc < KC; kc += 2) {                      // (KC is even: C % 256 == 0) -- static register-set parities
+        step(kc, xa[0], xa[1]);
+        step(kc + 1, xa[1], xa[0]);
+    }
+    __syncthreads();
+    gs_epilogue(acc, gs_smem, bias, SK, m0, tid);
+}
+thread_local int g_gs_variant = 1;     // tuning hook (pdhip_debug_set_gn_skip_variant)
+
+bool gn_skip_eligible(int N, int HW, int Ca, int C, int Cout, int Cout_pad) {
+    return Cout == GS_BN && Cout_pad == GS_BN && C % 64 == 0 && Ca % 64 == 0 && Ca > 0 && Ca <= C && ((C / 32) % 8) == 0 && C <= 2048 && HW % GS_BM == 0;
+}
+
+int gn_skip(const half_t* XA, const half_t* XB, int Ca, int C, const float* stats, const float* gamma, const float* beta, const half_t* Wt,
+            const float* bias, half_t* H0, half_t* SK, int N, int HW, hipStream_t s) {
+    PD_REQUIRE(gn_skip_eligible(N, HW, Ca, C, GS_BN, GS_BN) && (Ca == C || XB != nullptr), "gn_skip: shape not served by the fused kernel");
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip, hipFuncAttributeMaxDynamicSharedMemorySize, GS_SMEM));
+        PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip_w1, hipFuncAttributeMaxDynamicSharedMemorySize, GS1_SMEM));
+        attr_set = true;
+    }
+    const long long tiles = (long long)N * HW / GS_BM;
+    if (g_gs_variant == 0) k_gn_skip<<<(int)tiles, 256, GS_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
+    else k_gn_skip_w1<<<(int)tiles, 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
 }  // namespace pdnn

@@ -41,6 +41,9 @@ namespace pdnn { thread_local int g_fold_resample = 1; }
 // tuning / test hook (pdhip_debug_set_fold_finalize): largest batch at which GroupNorm-apply reduces the conv epilogues' octet
 // partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never)
 namespace pdnn { thread_local int g_fold_finalize = 8; }
+// tuning / test hook (pdhip_debug_set_fuse_skip): 0 = never, 1 (default) = a channel-changing ResBlock whose skip conv is C -> 256 over
+// at least g_fuse_skip_min_tiles pixel tiles runs GroupNorm-apply and the skip 1x1 as ONE pass over its input (k_gn_skip), 2 = always
+namespace pdnn { thread_local int g_fuse_skip = 1; thread_local int g_fuse_skip_min_tiles = 1024; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
@@ -263,7 +266,23 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     // nearest x2 of the normalised input: index arithmetic in conv1's halo staging, the GroupNorm pass stays at half resolution
     const bool fold_in_up = fold && rb.mode == 2 && Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&
                             conv_uses_halo(c.N, Ho, Wo, rb.c1.cin, rb.c1.cout, rb.c1.cout_pad, 9, c.u->splitk_floats);
-    if (rb.mode == 0 && can_fuse_gn(c, x, rb.c1)) {
+    // channel-changing block: in_layers' GroupNorm-apply and the skip 1x1 read the same (virtual concat) input -- one pass (k_gn_skip)
+    const bool fuse_skip = rb.has_skip && rb.mode == 0 && g_fuse_skip != 0 && rb.skip.taps == 1 && x.C == rb.skip.cin &&
+                           gn_skip_eligible(c.N, x.H * x.W, x.p2 ? x.Ca : x.C, x.C, rb.skip.cout, rb.skip.cout_pad) &&
+                           (g_fuse_skip == 2 || (long long)c.N * x.H * x.W / 128 >= g_fuse_skip_min_tiles) &&
+                           (c.dry || (x.gn_part != nullptr && ((x.C / 32) % 8) == 0));
+    if (fuse_skip) {
+        h0 = Act{nullptr, x.C, x.H, x.W};
+        h0.p = arena_take(c.u, (size_t)c.N * x.H * x.W * x.C);
+        sk = Act{nullptr, rb.skip.cout, x.H, x.W};
+        sk.p = arena_take(c.u, (size_t)c.N * x.H * x.W * rb.skip.cout);
+        if (!c.dry) {
+            PD_REQUIRE(rb.n1.have_g && rb.n1.have_b && rb.skip.have_w && rb.skip.have_b, "unet: norm / skip weights of %s not loaded", rb.name.c_str());
+            PD_TRY(run_gn_stats(c, x));
+            PD_TRY(gn_skip(x.p, x.p2, x.p2 ? x.Ca : x.C, x.C, c.u->stats, rb.n1.g, rb.n1.b, rb.skip.w, rb.skip.b, h0.p, sk.p, c.N, x.H * x.W, c.s));
+        }
+        PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
+    } else if (rb.mode == 0 && can_fuse_gn(c, x, rb.c1)) {
         PD_TRY(run_gn_conv(c, x, rb.n1, nullptr, 0, rb.c1, nullptr, &h1));
     } else if (fold_in_up) {
         PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, 0, &h0));
@@ -273,8 +292,8 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
         PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
     }
     if (rb.mode != 0 && !c.dry && !fold_down && !fold_up) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
-    sk = fold_up ? x : xr;
-    if (rb.has_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
+    if (!fuse_skip) sk = fold_up ? x : xr;
+    if (rb.has_skip && !fuse_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
     if (can_fuse_gn(c, h1, rb.c2)) return run_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, out, fold_up ? 1 : 0);
     PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
     return run_conv(c, h2, rb.c2, sk.p, out, true, nullptr, fold_up ? 1 : 0);
@@ -807,6 +826,24 @@ extern "C" int pdhip_debug_set_conv_sk_order(int order) { int old = pdnn::g_sk_o
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }
 extern "C" int pdhip_debug_set_fold_finalize(int max_batch) { int old = pdnn::g_fold_finalize; pdnn::g_fold_finalize = max_batch; return old; }
+namespace pdnn { extern thread_local int g_gs_variant; }
+/* lab hook: 0 = two workgroups per CU, loads one MFMA phase ahead; 1 (default) = one workgroup per CU, activation chunks three K-steps ahead */
+extern "C" int pdhip_debug_set_gn_skip_variant(int v) { int old = pdnn::g_gs_variant; pdnn::g_gs_variant = v; return old; }
+extern "C" int pdhip_debug_set_fuse_skip(int mode, int min_tiles) {
+    int old = pdnn::g_fuse_skip;
+    pdnn::g_fuse_skip = mode;
+    if (min_tiles > 0) pdnn::g_fuse_skip_min_tiles = min_tiles;
+    return old;
+}
+/* stand-alone: h0 = silu(GroupNorm32(x)) and sk = conv1x1(x) (C -> 256) in one pass over x = [xa | xb] (xb NULL: single tensor, Ca == C);
+ * stats [N][32][2] (mean, rstd) of x finished by the caller.  C % 256 == 0, Ca % 64 == 0, H * W % 128 == 0. */
+extern "C" int pdhip_gn_silu_skip1x1_nhwc_f16(const void* xa, const void* xb, int Ca, int C, const float* stats, const float* gamma,
+                                              const float* beta, const void* w_packed, const float* bias, void* h0, void* sk, int N, int H,
+                                              int W, void* stream) {
+    PD_REQUIRE(xa && stats && gamma && beta && w_packed && h0 && sk, "pdhip_gn_silu_skip1x1_nhwc_f16: null argument");
+    return gn_skip((const half_t*)xa, (const half_t*)xb, Ca, C, stats, gamma, beta, (const half_t*)w_packed, bias, (half_t*)h0, (half_t*)sk,
+                   N, H * W, as_stream(stream));
+}
 extern "C" int pdhip_debug_set_fuse_gn(int on) { int old = pdnn::g_fuse_gn; pdnn::g_fuse_gn = on; return old; }
 /* stand-alone: y = conv3x3( silu( GroupNorm32(x) [* (1 + scale) + shift] ) ) (+ residual) with the transform applied inside the
  * conv (halo-resident kernel; W in {32, 64, 128, 256}, H * W % 512 == 0, Cin % 32 == 0).  ws: N*64 + N*64*ceil(HW/256) + N*Cin*2 floats. */

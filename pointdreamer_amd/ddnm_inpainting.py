@@ -47,6 +47,9 @@ _reg('pdhip_conv2d_nhwc_f16', C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, 
 _reg('pdhip_groupnorm_nhwc_f16', C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, C.c_longlong, vp])
 _reg('pdhip_gn_silu_conv3x3_nhwc_f16', C.c_int, [vp, vp, vp, vp, C.c_longlong, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, C.c_longlong, vp])
 _reg('pdhip_debug_set_fuse_gn', C.c_int, [i32])
+_reg('pdhip_gn_silu_skip1x1_nhwc_f16', C.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp])
+_reg('pdhip_debug_set_fuse_skip', C.c_int, [i32, i32])
+_reg('pdhip_debug_set_gn_skip_variant', C.c_int, [i32])
 _reg('pdhip_debug_set_fold_resample', C.c_int, [i32])
 _reg('pdhip_debug_set_fold_finalize', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk', C.c_int, [i32, i32, i32])

@@ -3,6 +3,7 @@ reference's own fp32 UNet (tools/gen_golden_nn.py ddnm_full), the small-batch ro
 combine, GroupNorm statistics reduced inside the apply kernel), and the RCCL all-gather of the view-parallel driver executed on
 the one GPU there is."""
 import ctypes as C
+import math
 import os
 import socket
 import sys
@@ -10,6 +11,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden
 from oracle import unet as ounet
@@ -287,3 +289,77 @@ def test_groupnorm_apply_is_independent_of_pixels_per_thread(nn, film):
         torch.cuda.synchronize()
         outs.append(y.cpu())
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[1][7])
+
+
+@pytest.mark.parametrize("N,H,W,Ca,Cb", [(2, 16, 16, 256, 256), (1, 32, 16, 512, 256), (3, 8, 16, 512, 0), (1, 64, 64, 256, 256)])
+def test_gn_skip_one_pass_equals_two_launches(nn, N, H, W, Ca, Cb):
+    """k_gn_skip (in_layers GroupNorm -> SiLU and the skip 1x1 of a channel-changing ResBlock in one pass over the never-materialised
+    concat, unet.py:197-209 / 236-256 / 657-659): h0 must equal the stand-alone GroupNorm-apply kernel bit for bit on the same
+    statistics, the skip output must equal the engine's own 1x1 conv within f16 rounding of the f32 accumulation order and torch fp32
+    within the single-kernel tolerance."""
+    L = nn['L']
+    Cc = Ca + Cb
+    g = torch.Generator().manual_seed(Ca + 7 * Cb + H)
+    x = (torch.randn((N, H, W, Cc), generator=g) * 1.4 + 0.25).half()
+    gamma = (1 + 0.2 * torch.randn((Cc,), generator=g)).to(DEV); beta = (0.2 * torch.randn((Cc,), generator=g)).to(DEV)
+    w = (torch.randn((256, Cc, 1, 1), generator=g) / math.sqrt(Cc)).half().float()
+    b = (0.1 * torch.randn((256,), generator=g)).to(DEV)
+    xd = x.to(DEV)
+    xa = xd[..., :Ca].contiguous(); xb = xd[..., Ca:].contiguous() if Cb else None
+    # two-launch form on the materialised concat
+    y_ref = torch.empty_like(xd)
+    stats = torch.empty((N * 64,), device=DEV); ws = torch.empty((N * 64 * ((H * W + 255) // 256),), device=DEV)
+    assert L.pdhip_groupnorm_nhwc_f16(_ptr(xd), _ptr(gamma), _ptr(beta), None, N, H, W, Cc, 1, 0, _ptr(y_ref), _ptr(stats), _ptr(ws),
+                                      ws.numel(), _stream()) == 0, L.pdhip_last_error()
+    wp = torch.zeros((256, Cc), dtype=torch.float16, device=DEV)
+    wd = w.contiguous().to(DEV)
+    assert L.pdhip_pack_conv_weight_f16(_ptr(wd), 256, Cc, 1, _ptr(wp), _stream()) == 0
+    zp = torch.zeros((128,), dtype=torch.float16, device=DEV)
+    sk_ref = torch.empty((N, H, W, 256), dtype=torch.float16, device=DEV)
+    assert L.pdhip_conv2d_nhwc_f16(_ptr(xd), _ptr(wp), _ptr(b), None, _ptr(sk_ref), N, H, W, Cc, 256, 256, 1, _ptr(zp), _stream()) == 0
+    # one pass, both launch forms of the kernel
+    t_ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, b.cpu()).permute(0, 2, 3, 1)
+    scale = t_ref.abs().max().item()
+    sks = []
+    for variant in (0, 1):
+        old = L.pdhip_debug_set_gn_skip_variant(variant)
+        try:
+            h0 = torch.full_like(xd, float('nan')); sk = torch.full_like(sk_ref, float('nan'))
+            rc = L.pdhip_gn_silu_skip1x1_nhwc_f16(_ptr(xa), _ptr(xb) if Cb else None, Ca, Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(wp),
+                                                  _ptr(b), _ptr(h0), _ptr(sk), N, H, W, _stream())
+            assert rc == 0, L.pdhip_last_error()
+            torch.cuda.synchronize()
+        finally:
+            L.pdhip_debug_set_gn_skip_variant(old)
+        assert torch.equal(h0, y_ref), variant
+        assert (sk.float().cpu() - t_ref).abs().max().item() <= 2e-3 * scale + 1e-3
+        assert (sk.float() - sk_ref.float()).abs().max().item() <= 2e-3 * scale          # (one f16 ulp at most: same products, f32 sums)
+        sks.append(sk)
+    assert torch.equal(sks[0], sks[1])                   # same K order, same fragments: the two forms agree bit for bit
+    # shapes the kernel does not serve are refused, not mis-computed
+    assert L.pdhip_gn_silu_skip1x1_nhwc_f16(_ptr(xa), _ptr(xb) if Cb else None, Ca, Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(wp), _ptr(b),
+                                            _ptr(h0), _ptr(sk), N, H, W - 1, _stream()) != 0
+
+
+def test_unet_full_256_fused_skip_equals_two_launch_routing(nn):
+    """The full 552.8 M UNet with the one-pass GroupNorm + skip kernel forced on for every eligible ResBlock against the two-launch
+    routing, batch 2: same activations up to the f32 summation order of the skip GEMM (h0 is bit-identical), so the outputs agree
+    far inside the U1 tolerance."""
+    di, L = nn['di'], nn['L']
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, 11)
+    m = di.UNetModel(max_batch=2, device=DEV, **di.IMAGENET_256)
+    m.load_state_dict(w, strict=True)
+    del w
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 3, 256, 256), generator=g).to(DEV); t = torch.tensor([37.0, 801.0], device=DEV)
+    outs = []
+    for mode in (0, 2):
+        old = L.pdhip_debug_set_fuse_skip(mode, 0)
+        try:
+            outs.append(m(x, t).float().cpu())
+        finally:
+            L.pdhip_debug_set_fuse_skip(old, 0)
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert d <= 2e-3 * outs[0].abs().max().item(), d
+    assert d > 0 or torch.equal(outs[0], outs[1])
