@@ -270,6 +270,7 @@ int pdhip_debug_conv3x3_apply(const void* x, const float* table /*[N][Cin/8][16]
                               void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, const void* zero_page, void* stream);   /* tuning hook */
 int pdhip_debug_set_fold_resample(int on);   /* 1 (default): the resampled x branch of up / down ResBlocks is folded into its consumers; 0: k_resample passes */
 int pdhip_debug_set_fold_finalize(int max_batch);   /* largest UNet batch at which GroupNorm-apply reduces the conv epilogues' statistics partials itself (no k_gn_finalize_oct launch); default 8, 0 = never */
+int pdhip_debug_set_fold_finalize_chunks(int chunks);   /* above that batch the in-kernel statistics are kept for tensors whose producers left at most this many chunks per image (default 16; 0 = batch rule only); returns the previous value */
 int pdhip_debug_set_conv_sk(int mode, int tile, int splits);   /* small-M conv kernel (in-launch split-K combine): mode 0 never / 1 automatic / 2 every eligible layer; tile 0 auto, 1..4 = 128x128, 128x64, 64x64, 64x32; splits 0 auto */
 int pdhip_debug_set_conv_sk_stages(int stages);   /* lab hook: LDS stage count of the small-M conv kernel (2, 3, 4 where the tile allows; 0 = default) */
 int pdhip_debug_set_conv_sk_kgroups(int kg);   /* lab hook: K-groups (4-wave groups working on alternate K-steps of one tile) per workgroup of the small-M conv kernel: 1, 2, 4 (64-row tiles), 8 = loader-specialised (4 compute + 4 loader waves); 0 = default */

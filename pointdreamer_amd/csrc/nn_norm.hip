@@ -368,7 +368,7 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     int iters = GNA_ITERS;
     // (with the in-kernel statistics every workgroup pays the re-reduction of its image's partials first: fewer, longer workgroups --
     // 512 against 2 048 is -2.3 % on the batch-1 forward, -1 % at batch 8; tools/time_unet.py)
-    const int tgt_blocks = parts != nullptr ? 512 : 2048;
+    const int tgt_blocks = parts != nullptr && N <= 8 ? 512 : 2048;
     while (iters > 1 && (long long)cdiv((long long)Ho * Wo, pps * iters) * N < tgt_blocks) iters >>= 1;
     dim3 grid(cdiv((long long)Ho * Wo, pps * iters), N);
 #define GNA_ARGS X, stats, gamma, beta, film, film_stride, H, W, C, silu, Y, XB, Ca, iters, Yraw, gp
@@ -475,7 +475,8 @@ __device__ __forceinline__ void gs_epilogue(const float4_t (&acc)[4][8], char* s
         *reinterpret_cast<half8*>(SK + (size_t)(m0 + row) * GS_BN + col8) = *reinterpret_cast<const half8*>(&Cs[row * GS_CLD + col8]);
     }
 }
-// one 64-deep K-step of the skip GEMM on the staged tiles (wave tile 64 px x 128 co)
+// one 64-deep K-step of the skip GEMM on the staged tiles (wave tile 64 px x 128 co); NB weight fragments per batch (register budget)
+template <int NB>
 __device__ __forceinline__ void gs_mfma_step(float4_t (&acc)[4][8], const char* As, const char* Ws, int lane, int wm, int wn) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -484,14 +485,14 @@ __device__ __forceinline__ void gs_mfma_step(float4_t (&acc)[4][8], const char* 
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + (wm * 64 + i * 16 + (lane & 15)) * 128 + fo);
 #pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
-            half8 b[4];
+        for (int jh = 0; jh < 8 / NB; ++jh) {
+            half8 b[NB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const half8*>(Ws + (wn * 128 + (jh * 4 + j) * 16 + (lane & 15)) * 128 + fo);
+            for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const half8*>(Ws + (wn * 128 + (jh * NB + j) * 16 + (lane & 15)) * 128 + fo);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][jh * 4 + j], 0, 0, 0);
+                for (int j = 0; j < NB; ++j) acc[i][jh * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][jh * NB + j], 0, 0, 0);
         }
     }
 }
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip(const half_t* __restrict__ X
         }
         __syncthreads();
         if (kc + 1 < KC) issue(kc + 1);                       // in flight under this chunk's MFMAs (and the other workgroup's)
-        gs_mfma_step(acc, As, Ws, lane, wm, wn);
+        gs_mfma_step<4>(acc, As, Ws, lane, wm, wn);
     }
     __syncthreads();
     gs_epilogue(acc, gs_smem, bias, SK, m0, tid);
@@ -574,6 +575,9 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip(const half_t* __restrict__ X
 // (0.45 us against an HBM latency of several us under load); the weight chunk k + 1 (L2) is requested under the MFMAs of chunk k and
 // parked first thing in iteration k + 1, so it is never live across the GroupNorm math (register budget 256); the affine constants
 // of the image sit in LDS.  Loads past the last chunk are clamped (re-read, unused): the loop body has no branches.
+#ifndef GS1_NB
+#define GS1_NB 2
+#endif
 constexpr int GS1_SMEM = GS_SMEM;                           // tiles 48 KiB + constants C * 8 B <= 16 KiB < epilogue staging 66 KiB
 __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict__ XA, const half_t* __restrict__ XB, int Ca, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -623,6 +627,20 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    auto gn_part = [&](int kc, const half8* cur) {           // h0 = silu(GN(x)) of chunk kc straight from its registers
+        const int c0 = kc * 64 + slot * 8;
+        const float4_t* gp = reinterpret_cast<const float4_t*>(Gs + (c0 >> 3) * 16);
+        const float4_t a0 = gp[0], a1 = gp[1], b0 = gp[2], b1 = gp[3];
+        char* const hb = gs_uniform(baseH + (size_t)(kc * 64) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            half8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                hv[e] = (half_t)gn_elem<false, false>((float)cur[j][e], e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3], 1.f, 0.f, 1);
+            *reinterpret_cast<half8*>(hb + (offC + j * ((unsigned)C * 64u))) = hv;
+        }
+    };
     auto step = [&](int kc, const half8* cur, half8* nxt) {
         __syncthreads();                                      // the previous chunk's fragment reads are done (kc == 0: Gs is complete)
 #pragma unroll
@@ -630,20 +648,28 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<half8*>(As + (prow + 32 * j) * 128 + sw) = cur[j];
         issue_acts(kc + 1, nxt);
-        const int c0 = kc * 64 + slot * 8;
-        const float4_t* gp = reinterpret_cast<const float4_t*>(Gs + (c0 >> 3) * 16);
-        const float4_t a0 = gp[0], a1 = gp[1], b0 = gp[2], b1 = gp[3];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            half8 hv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                hv[e] = (half_t)gn_elem<false, false>((float)cur[j][e], e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3], 1.f, 0.f, 1);
-            *reinterpret_cast<half8*>(gs_uniform(baseH + (size_t)(kc * 64) * 2) + (offC + j * ((unsigned)C * 64u))) = hv;
-        }
+#ifndef GS1_GN_LATE
+        gn_part(kc, cur);
+#endif
         __syncthreads();
+#ifndef GS1_W_LATE
         issue_w(kc + 1);
-        gs_mfma_step(acc, As, Ws, lane, wm, wn);
+#endif
+        gs_mfma_step<GS1_NB>(acc, As, Ws, lane, wm, wn);
+#ifdef GS1_GN_LATE
+        // the GroupNorm math needs registers only: same basic block as the MFMAs, interleaved (matrix pipe and VALU overlap in-wave)
+        gn_part(kc, cur);
+#if GS1_GN_LATE > 1
+#pragma unroll
+        for (int g = 0; g < 64; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, GS1_GN_LATE, 0);      // a few VALU
+        }
+#endif
+#endif
+#ifdef GS1_W_LATE
+        issue_w(kc + 1);
+#endif
     };
     for (int kc = 0; kc < KC; kc += 2) {                      // (KC is even: C % 256 == 0) -- static register-set parities
         step(kc, xa[0], xa[1]);

@@ -39,11 +39,14 @@ namespace pdnn { thread_local int g_fuse_gn = 0; }
 // nearest x2 copy is replaced by index arithmetic in the residual read of the consuming conv (unsplit halo layers)
 namespace pdnn { thread_local int g_fold_resample = 1; }
 // tuning / test hook (pdhip_debug_set_fold_finalize): largest batch at which GroupNorm-apply reduces the conv epilogues' octet
-// partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never)
-namespace pdnn { thread_local int g_fold_finalize = 8; }
+// partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never); above that batch the fold is kept for the
+// tensors whose producers left at most g_fold_finalize_chunks chunks per image (the 32^2 ... 8^2 levels: the re-reduction is a few
+// loads per thread against a 5.8 us launch, 2 020 of them per 20 forwards at batch 32)
+namespace pdnn { thread_local int g_fold_finalize = 8; thread_local int g_fold_finalize_chunks = 16; }
 // tuning / test hook (pdhip_debug_set_fuse_skip): 0 = never, 1 (default) = a channel-changing ResBlock whose skip conv is C -> 256 over
-// at least g_fuse_skip_min_tiles pixel tiles runs GroupNorm-apply and the skip 1x1 as ONE pass over its input (k_gn_skip), 2 = always
-namespace pdnn { thread_local int g_fuse_skip = 1; thread_local int g_fuse_skip_min_tiles = 1024; }
+// at least g_fuse_skip_min_tiles pixel tiles (default 1: measured a gain at every batch) runs GroupNorm-apply and the skip 1x1 as ONE
+// pass over its input (k_gn_skip), 2 = always
+namespace pdnn { thread_local int g_fuse_skip = 1; thread_local int g_fuse_skip_min_tiles = 1; }
 namespace {
 struct Prof { std::vector<hipEvent_t> ev; std::vector<uint8_t> cls; size_t used = 0; double flops[2] = {0, 0}; bool on = false; };   // cls 0: halo 3x3 conv, 1: attention
 
@@ -220,7 +223,8 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
     PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
     // small batches: the apply kernel reduces the octet partials itself (no k_gn_finalize_oct launch); large batches: every
     // workgroup re-reducing its image's partials costs more than the 5 us launch it removes
-    if (x.gn_part != nullptr && ((x.C / 32) % 8) == 0 && (x.C >> 3) <= 256 && g_fold_finalize > 0 && c.N <= g_fold_finalize) {
+    if (x.gn_part != nullptr && ((x.C / 32) % 8) == 0 && (x.C >> 3) <= 256 && g_fold_finalize > 0 &&
+        (c.N <= g_fold_finalize || (x.gn_chunks <= g_fold_finalize_chunks && x.gn_chunksB <= g_fold_finalize_chunks))) {
         const GnPartsArg pa{x.gn_part, x.Ca, x.gn_chunks, x.gn_partB, x.C - x.Ca, x.gn_chunksB, 1e-5f};
         return gn_apply(x.p, nullptr, n.g, n.b, film, film_stride, c.N, x.H, x.W, x.C, silu, resample, out->p, 0, c.s, x.p2,
                         x.p2 ? x.Ca : 0, raw_pool, &pa);
@@ -825,6 +829,7 @@ extern "C" int pdhip_debug_set_conv_sk_order(int order) { int old = pdnn::g_sk_o
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }
+extern "C" int pdhip_debug_set_fold_finalize_chunks(int chunks) { int old = pdnn::g_fold_finalize_chunks; pdnn::g_fold_finalize_chunks = chunks; return old; }
 extern "C" int pdhip_debug_set_fold_finalize(int max_batch) { int old = pdnn::g_fold_finalize; pdnn::g_fold_finalize = max_batch; return old; }
 namespace pdnn { extern thread_local int g_gs_variant; }
 /* lab hook: 0 = two workgroups per CU, loads one MFMA phase ahead; 1 (default) = one workgroup per CU, activation chunks three K-steps ahead */
