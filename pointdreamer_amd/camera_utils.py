@@ -102,3 +102,26 @@ def create_cameras(num_views=8, distance=1.6, res=512, distribution='fibonacci_s
         base_dirs[i] = torch.tensor(eye - at).float()
         up_dirs[i] = torch.tensor(up).float()
     return cams, base_dirs.to(device), eyes, up_dirs.to(device)
+
+
+def get_cam_Ks_RTs_from_locations(cam_locations):
+    """camera_utils.py:940-985: world -> camera [R | t] (rows U, V, N = right, up, look direction) of cameras at `cam_locations`
+    [V,3] looking at the origin, y-up (z-up when the view direction is vertical), and the fixed 512-pixel intrinsics.
+    Returns (cam_K [3,3], cam_RTs [V,3,4]) as float64 numpy arrays."""
+    loc = cam_locations.detach().cpu().numpy() if torch.is_tensor(cam_locations) else np.asarray(cam_locations)
+    loc = loc.astype(np.float64)
+    cam_RTs = np.zeros((len(loc), 3, 4))
+    target = np.array([0.0, 0.0, 0.0])
+    for i, eye in enumerate(loc):
+        N = target - eye
+        N = N / np.linalg.norm(N)
+        up = np.array([0.0, 0.0, 1.0]) if (N[0] == 0 and N[2] == 0) else np.array([0.0, 1.0, 0.0])
+        U = np.cross(N, up)
+        U = U / np.linalg.norm(U)
+        V = np.cross(U, N)
+        V = V / np.linalg.norm(V)
+        cam_RTs[i] = np.array([[U[0], U[1], U[2], np.dot(-U, eye)],
+                               [V[0], V[1], V[2], np.dot(-V, eye)],
+                               [N[0], N[1], N[2], np.dot(-N, eye)]])
+    cam_K = np.array([[560.0, 0, 256], [0, 560, 256], [0, 0, 1]])
+    return cam_K, cam_RTs

@@ -76,8 +76,10 @@ def load_config(cfg_file, overrides=None):
         raise KeyError(f"{cfg_file}: texture_gen_method is required")
     for k, v in DEFAULTS.items():
         cfg.setdefault(k, v)
-    if cfg.camera_distribution != 'fibonacci_sphere':
-        raise NotImplementedError(f"camera_distribution={cfg.camera_distribution!r}: every shipped config uses fibonacci_sphere")
+    # camera_utils.py:116-245: 'blender' / 'exact_blender' always place 20 cameras, 'self_defined' knows 6 or 20 -- the per-view
+    # arrays of the path are sized by view_num, so a mismatch is an error here instead of an index error later
+    if cfg.camera_distribution in ('blender', 'exact_blender') and cfg.view_num != 20:
+        raise ValueError(f"camera_distribution={cfg.camera_distribution!r} places 20 cameras: set view_num: 20 (got {cfg.view_num})")
     if cfg.optimize_from == 'None':                      # YAML `None` is the string 'None' (demo.py:213 treats both alike)
         cfg['optimize_from'] = None
     return cfg

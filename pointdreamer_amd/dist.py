@@ -62,7 +62,7 @@ def unpack_view_records(rec, img_shape, A, K):
 
 def _subset_camera_info(camera_info, sl):
     out = dict(camera_info)
-    for k in ('cams', 'base_dirs', 'eye_positions', 'up_dirs'):
+    for k in ('cams', 'base_dirs', 'eye_positions', 'up_dirs', 'cam_RTs'):
         if camera_info.get(k) is not None:
             out[k] = camera_info[k][sl]
     return out
@@ -77,7 +77,8 @@ def default_stages():
         return pl._before_inpaint(coords, colors, vertices, faces, cam_info_local, n_local, res, cam_res, save_img_path,
                                   opts['point_validation_by_o3d'], opts['hidden_point_removal_radius'], opts['point_size'],
                                   opts['edge_point_size'], opts['crop_img'], opts['crop_padding'], opts['mask_ratio_thresh'],
-                                  view_offset=view_offset)
+                                  view_offset=view_offset, refine_point_validation=opts.get('refine_point_validation', False),
+                                  refine_res=opts.get('refine_res', 512))
 
     def inpaint(pre, save_img_path, inpainter, n_local, method, first_key, advance, view_offset):
         return ou.get_inpainted_images(pre['sparse'], pre['mask0'], pre['mask2'], save_img_path, inpainter, n_local, method=method,
@@ -103,13 +104,14 @@ def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, 
                                     mask_ratio_thresh=0.82, edge_dilate_kernels=(21,), point_validation_by_o3d=True,
                                     hidden_point_removal_radius=100, complete_unseen_by='unproject', optimize_from=None,
                                     save_img_path=None, group=None, stages=None, shape_key=None, return_full=False,
-                                    force_collective=False, **unused):
+                                    force_collective=False, refine_point_validation_by_remove_abnormal_depth=False, refine_res=512,
+                                    **unused):
     """View-parallel demo.colorize_one_mesh: same keyword surface and defaults as pipeline.colorize_one_mesh, same atlas on
     every rank (bit-identical to the single-process result for the index / copy stages; for DDNM the noise of view k is keyed by
     its global index, so the result does not depend on `world` either).  shape_key: running index of the shape (noise key base
     = shape_key * view_num); default = the inpainter's own image counter, which every rank advances by view_num."""
     from . import pipeline as pl
-    pl._check_options(xatlas_dict, False, complete_unseen_by, optimize_from)
+    pl._check_options(xatlas_dict, refine_point_validation_by_remove_abnormal_depth, complete_unseen_by, optimize_from)
     if world > view_num:
         # a rank without views would enter the per-view stages with V = 0 (the HIP entry points require V > 0) while the others
         # block in the all_gather: refuse up front, on every rank alike
@@ -120,7 +122,8 @@ def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, 
     sl = slice(mine.start, mine.stop)
     opts = dict(point_validation_by_o3d=point_validation_by_o3d, hidden_point_removal_radius=hidden_point_removal_radius,
                 point_size=point_size, edge_point_size=edge_point_size, crop_img=crop_img, crop_padding=crop_padding,
-                mask_ratio_thresh=mask_ratio_thresh)
+                mask_ratio_thresh=mask_ratio_thresh, refine_point_validation=refine_point_validation_by_remove_abnormal_depth,
+                refine_res=refine_res)
     A = xatlas_dict['mask'].shape[1]
     with torch.no_grad():
         cam_local = _subset_camera_info(camera_info, sl)

@@ -145,6 +145,46 @@ def get_point_validation_by_o3d(points, eye_positions=None, hidden_point_removal
     return hidden_point_removal(points, eye_positions, hidden_point_removal_radius)
 
 
+def refine_point_validation(cam_RTs, cam_K, res, hard_masks, point_validation, point_uvs, points, save_path, view_offset=0):
+    """ours_utils.py:227-305 (`refine_point_validation_by_remove_abnormal_depth`, off in the shipped configs): per view, the camera-space
+    depth z of the visible points is painted into a res x res map, filled to a dense map from the nearest painted pixel, and small
+    foreground regions that are BRIGHTER (farther) than their surroundings -- points of the far side showing through -- are found
+    by `utils_2d.detect_abnormal_bright_spots_in_gray_img`; visible points that land on such a region lose their visibility.
+    cam_RTs [V,3,4] world -> camera, hard_masks [V,h,w] bool, point_validation [V,N] bool, point_uvs [V,N,2], points [N,3].
+    The pixel arithmetic, the mask resize and the nearest fill run in the HIP kernels of rows P3 / P2b / I0; the blob test is host
+    code as in the reference.  z = (x r20 + y r21) + z r22 + t2 in float32, in that order (the reference's torch.matmul leaves the
+    summation order to the BLAS); several points on one pixel: the last one in point order wins (torch's CPU index_put order;
+    on CUDA the reference's winner is unspecified).  save_path: directory for the `{i}_depth.png` panels, or None; view_offset: index of
+    the first view in those names (view-parallel shards)."""
+    from . import utils_2d
+    dev = _dev(point_uvs)
+    V, N = point_validation.shape
+    pix = get_point_pixels(point_uvs, res)                                      # [V,N,2] (row, col), clipped
+    fg = resize_masks(hard_masks, res)                                          # transforms.Resize((res, res)) then .astype(bool)
+    RT = np.asarray(cam_RTs.detach().cpu() if torch.is_tensor(cam_RTs) else cam_RTs).astype(np.float32)
+    pts = points.detach().float().cpu().numpy()
+    zs_h = ((pts[None, :, 0] * RT[:, 2, 0:1] + pts[None, :, 1] * RT[:, 2, 1:2]) + pts[None, :, 2] * RT[:, 2, 2:3]) + RT[:, 2, 3:4]   # [V,N] f32
+    pix_h, val_h, fg_h = pix.cpu().numpy(), point_validation.cpu().numpy().astype(bool), fg.cpu().numpy()
+    sparse = np.full((V, res, res), -100.0, dtype=np.float32)
+    for i in range(V):
+        rc = pix_h[i][val_h[i]]
+        sparse[i][rc[:, 0], rc[:, 1]] = zs_h[i][val_h[i]]                       # duplicates: last point wins
+    sp = torch.from_numpy(sparse).to(dev)
+    dense = nearest_fill(sp[:, None], sp != -100.0, 'CHW')[:, 0].cpu().numpy()  # naive_inpainting(method='nearest') per view
+    new_val = val_h.copy()
+    for i in range(V):
+        path = None
+        if save_path is not None:
+            os.makedirs(save_path, exist_ok=True)
+            path = os.path.join(save_path, f'{i + view_offset}_depth.png')
+        abnormal = utils_2d.detect_abnormal_bright_spots_in_gray_img(dense[i], fg_h[i], save_path=path, min_for_norm=0.5, max_for_norm=2.5,
+                                                                    edge_thresh=25, pixel_num_thresh=2000, area_expand_thresh=5,
+                                                                    area_same_color_thres=5, brighter_thresh=5)
+        rc = pix_h[i][val_h[i]]
+        new_val[i][val_h[i]] = ~abnormal[rc[:, 0], rc[:, 1]]
+    return torch.from_numpy(new_val).to(dev)
+
+
 def get_sparse_images(point_pixels, colors, point_validation, hard_masks, save_path, view_num, res, point_size,
                       edge_point_size, mask_ratio_thresh, view_offset=0):
     """ours_utils.py:848-882 -> sparse_imgs[V,3,r,r], hard_mask0s, hard_mask2s, scale_factors[V].

@@ -2,10 +2,10 @@
 
 `colorize_one_mesh` keeps the keyword surface of the reference's demo.colorize_one_mesh
 (/root/reference/demo.py:38-253).  Built: texture_gen_method 'nearest' / 'linear' / 'DDNM_inpaint', complete_unseen_by
-'unproject' / 'neighbor', optimize_from None / 'scratch' / 'naive' / 'ours'.  Not built, and refused with NotImplementedError instead
-of silently doing something else: `complete_unseen_by='optimize'` (a per-shape TextureField training loop, outside SURVEY 8) and
-`refine_point_validation_by_remove_abnormal_depth` (cv2 blob heuristics, off in every shipped config).  The measured path of
-bench.py is `complete_unseen_by='unproject'`, `optimize_from=None`.
+'unproject' / 'neighbor', optimize_from None / 'scratch' / 'naive' / 'ours', `refine_point_validation_by_remove_abnormal_depth`
+(ours_utils.refine_point_validation; off in every shipped config).  Not built, and refused with NotImplementedError instead of
+silently doing something else: `complete_unseen_by='optimize'` (a per-shape TextureField training loop, outside SURVEY 8).  The
+measured path of bench.py is `complete_unseen_by='unproject'`, `optimize_from=None`.
 """
 import torch
 
@@ -14,8 +14,6 @@ from . import unproject as up
 
 
 def _check_options(xatlas_dict, refine_point_validation_by_remove_abnormal_depth, complete_unseen_by, optimize_from):
-    if refine_point_validation_by_remove_abnormal_depth:
-        raise NotImplementedError("refine_point_validation_by_remove_abnormal_depth (off in every shipped config) is not built")
     if complete_unseen_by not in ('unproject', 'neighbor'):
         raise NotImplementedError(f"complete_unseen_by={complete_unseen_by!r}: 'unproject' and 'neighbor' are built ('optimize' "
                                   "needs the TextureField network, outside SURVEY 8)")
@@ -27,7 +25,7 @@ def _check_options(xatlas_dict, refine_point_validation_by_remove_abnormal_depth
 
 def _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res, cam_res, save_img_path, point_validation_by_o3d,
                     hidden_point_removal_radius, point_size, edge_point_size, crop_img, crop_padding, mask_ratio_thresh, glctx=None,
-                    view_offset=0):
+                    view_offset=0, refine_point_validation=False, refine_res=512):
     """demo.py:93-129: project, rasterise, visibility, sparse views -- everything of one shape ahead of the inpainter.
     Every view is independent here: `camera_info` may hold a subset of a shape's cameras (view-parallel sharding), view_offset
     is then the index of its first view in the per-view file names."""
@@ -43,6 +41,13 @@ def _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res,
         # demo.py:108-110 ORs the two tests: only points the depth test rejected need the hull query
         point_validation = hidden_point_removal(coords, camera_info['eye_positions'], hidden_point_removal_radius,
                                                 already_valid=point_validation)
+    if refine_point_validation:                              # demo.py:115-117 (False by default)
+        cam_RTs = camera_info.get('cam_RTs')
+        if cam_RTs is None:                                  # demo.py:334-335
+            from .camera_utils import get_cam_Ks_RTs_from_locations
+            cam_RTs = get_cam_Ks_RTs_from_locations(camera_info['eye_positions'])[1]
+        point_validation = ou.refine_point_validation(cam_RTs, camera_info.get('cam_K'), refine_res, hard_masks, point_validation,
+                                                      point_uvs, coords, save_img_path, view_offset=view_offset)
     sparse_imgs, hard_mask0s, hard_mask2s, scale_factors = ou.get_sparse_images(
         point_pixels, colors, point_validation, hard_masks, save_img_path, view_num, res, point_size,
         edge_point_size, mask_ratio_thresh, view_offset=view_offset)
@@ -91,7 +96,8 @@ def colorize_one_mesh(coords, colors, vertices, faces, f_normals, xatlas_dict, c
     with torch.no_grad():
         pre = _before_inpaint(coords, colors, vertices, faces, camera_info, view_num, res, cam_res, save_img_path,
                               point_validation_by_o3d, hidden_point_removal_radius, point_size, edge_point_size, crop_img,
-                              crop_padding, mask_ratio_thresh, glctx)
+                              crop_padding, mask_ratio_thresh, glctx,
+                              refine_point_validation=refine_point_validation_by_remove_abnormal_depth, refine_res=refine_res)
         # demo.py:138-147: every {i}_inpainted.png already on disk -> load them instead of inpainting again (resume surface)
         inpainted = ou.load_inpainted_images(save_img_path, view_num, coords.device) if reuse_inpainted else None
         if inpainted is None:
@@ -161,7 +167,8 @@ def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpaint
         pres = [on_stream(st, lambda sh=sh, pth=pth: _before_inpaint(
                     sh['coords'], sh['colors'], sh['vertices'], sh['faces'], camera_info, view_num, res, cam_res, pth,
                     point_validation_by_o3d, hidden_point_removal_radius, point_size, edge_point_size, crop_img, crop_padding,
-                    mask_ratio_thresh)) for sh, pth, st in zip(shapes, paths, streams)]
+                    mask_ratio_thresh, refine_point_validation=refine_point_validation_by_remove_abnormal_depth,
+                    refine_res=unused.get('refine_res', 512))) for sh, pth, st in zip(shapes, paths, streams)]
         for st, pr in zip(streams, pres):
             back_to_main(st, pr)
         cat = lambda k: torch.cat([pr[k] for pr in pres], 0).contiguous()

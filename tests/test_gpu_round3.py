@@ -363,3 +363,69 @@ def test_unet_full_256_fused_skip_equals_two_launch_routing(nn):
     d = (outs[0] - outs[1]).abs().max().item()
     assert d <= 2e-3 * outs[0].abs().max().item(), d
     assert d > 0 or torch.equal(outs[0], outs[1])
+
+
+def test_refine_point_validation_vs_oracle(nn):
+    """ours_utils.refine_point_validation (ours_utils.py:227-305): pixel arithmetic, mask resize and the nearest fill on the device,
+    the blob test on the host -- against the oracle's literal composition (oracle/refine.py with the oracle's P2b / I0 functions).
+    The scene: a smooth depth field seen from two cameras, with clusters of 'see-through' points 0.45 farther than their
+    neighbourhood; those, and only points on such regions, lose their visibility."""
+    import pointdreamer_amd.ours_utils as ou
+    from oracle import refine as oref, project as oproj, inpaint as oinp
+    V, N, res, hres = 2, 6000, 128, 64
+    rng = np.random.default_rng(11)
+    uv = rng.uniform(0.12, 0.88, (V, N, 2)).astype(np.float32)
+    yy, xx = np.mgrid[0:hres, 0:hres]
+    hard = np.stack([((yy - hres / 2) ** 2 + (xx - hres / 2) ** 2) < (0.47 * hres) ** 2] * V)
+    # camera 0 reads z, camera 1 reads 1.6 - x; the points are built so that both depth fields are smooth in the view's own uv
+    RT = np.zeros((V, 3, 4)); RT[0, 2] = [0, 0, 1, 0]; RT[1, 2] = [-1, 0, 0, 1.6]
+    pts = np.zeros((N, 3), np.float32)
+    pts[:, 2] = 1.0 + 0.25 * uv[0, :, 0] + 0.02 * np.sin(7 * uv[0, :, 1])
+    pts[:, 0] = 1.6 - (1.2 + 0.2 * uv[1, :, 1])
+    planted = np.zeros((V, N), bool)
+    for v, centres in enumerate([[(0.3, 0.3), (0.6, 0.55), (0.45, 0.7)], [(0.35, 0.6), (0.65, 0.35)]]):
+        for cx, cy in centres:
+            sel = ((uv[v, :, 0] - cx) ** 2 + (uv[v, :, 1] - cy) ** 2) < 0.045 ** 2
+            planted[v] |= sel
+    pts[planted[0], 2] += 0.45
+    pts[planted[1] & ~planted[0], 0] -= 0.45
+    valid = rng.uniform(size=(V, N)) < 0.9
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = ou.refine_point_validation(RT, None, res, T(hard), T(valid), T(uv), T(pts), None).cpu().numpy()
+    want = oref.refine_point_validation(RT, res, hard, valid, uv, pts, oproj.resize_mask_bilinear_nonzero, oinp.nearest_inpaint)
+    assert np.array_equal(got, want)
+    removed = valid & ~got
+    assert removed.any() and not (got & ~valid).any()                   # visibility is only ever taken away
+    assert removed[0].sum() > 20 and (removed[0] & planted[0]).sum() >= 0.8 * removed[0].sum()      # what goes is what was planted
+    assert (valid[0] & planted[0] & ~removed[0]).sum() <= 0.5 * (valid[0] & planted[0]).sum()
+
+
+def test_colorize_one_mesh_with_refine_option(nn, tmp_path):
+    """`refine_point_validation_by_remove_abnormal_depth=True` (demo.py:115-117) runs through the pipeline: cam_RTs derived from the eye
+    positions (demo.py:334-335), `{i}_depth.png` panels written, an atlas comes out; with nothing abnormal in the cloud the atlas
+    equals the one without the option."""
+    from pointdreamer_amd import synthetic, pipeline
+    import pointdreamer_amd.camera_utils as cu
+    V, RES, CAM, A, NP = 3, 128, 256, 256, 5000
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    g = {k: T(v) for k, v in synthetic.make_shape(NP, A, seed=3).items()}
+    cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, CAM, device=DEV)
+    ci = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    xa = dict(gb_pos=g['gb_pos'], mask=g['mask'], per_atlas_pixel_face_id=g['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
+    cfg = dict(point_validation_by_o3d=True, texture_gen_method='nearest', point_size=1, edge_point_size=1, crop_img=True,
+               crop_padding=0.05, mask_ratio_thresh=0.82, optimize_from=None, edge_dilate_kernels=[21], complete_unseen_by='unproject')
+    outs = {}
+    for on in (False, True):
+        d = str(tmp_path / f"o{int(on)}")
+        outs[on] = pipeline.colorize_one_mesh(g['points'], g['colors'], g['vertices'], g['faces'], g['f_normals'], xa, ci, view_num=V, res=RES,
+                                              cam_res=CAM, inpainter=None, save_img_path=d, return_intermediates=True,
+                                              refine_point_validation_by_remove_abnormal_depth=on, refine_res=256, **cfg)
+    from pointdreamer_amd import io_utils
+    io_utils.flush()
+    for i in range(V):
+        assert os.path.exists(str(tmp_path / "o1" / f"{i}_depth.png")) and not os.path.exists(str(tmp_path / "o0" / f"{i}_depth.png"))
+    pv0, pv1 = outs[False]['point_validation'], outs[True]['point_validation']
+    assert not (pv1 & ~pv0).any()                                      # refinement only removes
+    assert (pv0 & ~pv1).float().mean().item() < 0.02                   # a clean sphere: (almost) nothing to remove
+    if torch.equal(pv0, pv1):
+        assert torch.equal(outs[False]['atlas'], outs[True]['atlas'])
