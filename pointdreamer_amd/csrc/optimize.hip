@@ -62,46 +62,46 @@ __global__ void k_optcolor_target(const float* __restrict__ inp, int r, const fl
     }
 }
 
-// ---- gather formulation.  The texture coordinates are fixed for the whole optimisation, so the transpose of the bilinear
-// sampling operator is built ONCE as a CSR table: texel -> (pixel, weight) contributions, sorted by pixel index inside a texel
-// (deterministic summation order -- the reference's grid_sample backward / index_put atomics are not).  An iteration is then
-//   forward : per masked pixel, bilinear lookup (f64), clamp, sign of the L1 residual per channel -> 3 bytes
-//   backward: per texel, sum of weight * sign over its contributions (f64, fixed order) -> Adam update, fused
-// ~0.75 GB of streaming traffic per iteration at V = 8, res = 1024 instead of ~100 M f64 atomics (2.3 ms -> see DESIGN.md).
+// ---- gather formulation on COMPACT lists (round 3).  The texture coordinates and the masks are fixed for the whole optimisation, so
+// everything an iteration needs is laid out once:
+//   * the masked pixels, in pixel order, as 16-byte records {fx, fy, tex, sgn}: the bilinear fractions (exactly representable in
+//     f32: ix = u A - 0.5 with a 24-bit u and A = 2^k leaves at most 24 significant bits below the binary point, and out-of-range
+//     coordinates are clamped to integers), the index of the top-left texel, and the sign bytes the forward pass writes;
+//     their targets as float4 next to them.  The forward pass is a coalesced stream over these two arrays + four 16-byte gathers
+//     from the interleaved atlas per pixel (no mask test, no uv arithmetic, no divergence);
+//   * the transpose of the sampling operator as a CSR table texel -> entries, an entry = (compact pixel << 2 | corner) in 4 bytes,
+//     sorted ascending inside a texel (deterministic f64 summation order -- the reference's grid_sample backward / index_put atomics
+//     are not).  The backward pass gathers the pixel's record (one 16-byte request gives the sign AND the fractions the weight is
+//     recomputed from, exactly) instead of streaming an 8-byte weight next to a 4-byte gather;
+//   * the texels that receive any contribution: the others have zero gradient and zero Adam moments for ever, their update is
+//     exactly + 0, so they -- and their 40 bytes of optimiser state per iteration -- are skipped.
+// Round 2 (uv arithmetic + mask test per pixel and iteration, 12-byte entries, every texel updated): 129 + 154 us per iteration at
+// V = 8, res = 1024 on the stage benchmark; this form: see DESIGN.md.
 
-// the (up to 4) texels a pixel reads and their float64 weights (kaolin texture_mapping == grid_sample(align_corners=False,
-// padding 'border', v flipped)); returns the number of valid corners
-__device__ __forceinline__ int oc_corners(const float* __restrict__ uv_map, size_t src, int A, int* tex /*[4]*/, double* wt /*[4]*/) {
+struct __align__(16) OcRec { float fx, fy; int tex; char4 sgn; };
+
+// the top-left texel and the fractions of a pixel (kaolin texture_mapping == grid_sample(align_corners=False, padding 'border', v
+// flipped)): gx = 2u-1, gy = -(2w-1); ix = ((g+1)/2)*A - 0.5; border padding = clamp to [0, A-1]
+__device__ __forceinline__ void oc_base(const float* __restrict__ uv_map, size_t src, int A, int* tex, double* fx, double* fy) {
     const double u = (double)uv_map[2 * src], w = (double)uv_map[2 * src + 1];
-    // grid_sample unnormalise: gx = 2u-1, gy = -(2w-1); ix = ((g+1)/2)*A - 0.5; border padding = clamp to [0, A-1]
     double ix = (((u * 2.0 - 1.0) + 1.0) / 2.0) * A - 0.5, iy = ((-(w * 2.0 - 1.0) + 1.0) / 2.0) * A - 0.5;
     ix = fmin(fmax(ix, 0.0), (double)(A - 1));
     iy = fmin(fmax(iy, 0.0), (double)(A - 1));
-    const int x0 = (int)floor(ix), y0 = (int)floor(iy), x1 = x0 + 1, y1 = y0 + 1;
-    const double fx = ix - x0, fy = iy - y0;
-    const bool bx = x1 < A, by = y1 < A;
-    int n = 0;
-    tex[n] = y0 * A + x0; wt[n++] = (1.0 - fx) * (1.0 - fy);
-    if (bx) { tex[n] = y0 * A + x1; wt[n++] = fx * (1.0 - fy); }
-    if (by) { tex[n] = y1 * A + x0; wt[n++] = (1.0 - fx) * fy; }
-    if (bx && by) { tex[n] = y1 * A + x1; wt[n++] = fx * fy; }
-    return n;
+    const int x0 = (int)floor(ix), y0 = (int)floor(iy);
+    *tex = y0 * A + x0; *fx = ix - x0; *fy = iy - y0;
+}
+// corner c (0 = (x0, y0), 1 = (x1, y0), 2 = (x0, y1), 3 = (x1, y1)) of a record: valid?, texel, float64 weight
+__device__ __forceinline__ bool oc_corner(int tex, double fx, double fy, int A, int c, int* t, double* wt) {
+    const int x0 = tex % A, y0 = tex / A;
+    const bool bx = x0 + 1 < A, by = y0 + 1 < A;
+    if (c == 0) { *t = tex; *wt = (1.0 - fx) * (1.0 - fy); return true; }
+    if (c == 1) { *t = tex + 1; *wt = fx * (1.0 - fy); return bx; }
+    if (c == 2) { *t = tex + A; *wt = (1.0 - fx) * fy; return by; }
+    *t = tex + A + 1; *wt = fx * fy; return bx && by;
 }
 
-__global__ void k_oc_count(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, int V, int res, int A,
-                           int* __restrict__ cnt) {
-    const long long total = (long long)V * res * res;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
-        if (!wmask[p]) continue;
-        const int v = (int)(p / ((long long)res * res)), idx = (int)(p - (long long)v * res * res);
-        const int y = idx / res, x = idx - y * res;
-        int tex[4]; double wt[4];
-        const int n = oc_corners(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, tex, wt);
-        for (int k = 0; k < n; ++k) atomicAdd(&cnt[tex[k]], 1);
-    }
-}
-
-// exclusive prefix sum of n ints in three steps (block sums -> scan of the block sums -> add): n <= 1024 * 1024 * 4
+// exclusive prefix sum of n ints in three steps (block sums -> scan of the block sums -> add): n <= 16384 * 1024.  total (may be
+// null) receives the sum of all elements.
 __global__ void k_oc_scan1(const int* __restrict__ in, int n, int* __restrict__ out, int* __restrict__ bsum) {
     __shared__ int sh[1024];
     const int i = blockIdx.x * 1024 + threadIdx.x;
@@ -117,11 +117,15 @@ __global__ void k_oc_scan1(const int* __restrict__ in, int n, int* __restrict__ 
     if (i < n) out[i] = sh[threadIdx.x] - v;
     if (threadIdx.x == 1023) bsum[blockIdx.x] = sh[1023];
 }
-__global__ void k_oc_scan2(int* __restrict__ bsum, int nb) {          // one block: exclusive scan of <= 4096 block sums
-    __shared__ int sh[4096];
-    for (int i = threadIdx.x; i < 4096; i += blockDim.x) sh[i] = i < nb ? bsum[i] : 0;
+__global__ void k_oc_scan2(int* __restrict__ bsum, int nb, int* __restrict__ total) {   // one block: exclusive scan of <= 16384 block sums
+    __shared__ int sh[16384];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) sh[i] = i < nb ? bsum[i] : 0;
     __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < nb; ++i) { const int t = sh[i]; sh[i] = run; run += t; } }
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < nb; ++i) { const int t = sh[i]; sh[i] = run; run += t; }
+        if (total != nullptr) *total = run;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < nb; i += blockDim.x) bsum[i] = sh[i];
 }
@@ -129,62 +133,95 @@ __global__ void k_oc_scan3(int* __restrict__ out, int n, const int* __restrict__
     const int i = blockIdx.x * 1024 + threadIdx.x;
     if (i < n) out[i] += bsum[blockIdx.x];
 }
+#define OC_TRY(expr) do { int rc_ = (expr); if (rc_ != PDHIP_OK) return rc_; } while (0)
+static int oc_scan(const int* in, int n, int* out, int* bsum, int* total, hipStream_t s) {
+    const int nb = cdiv(n, 1024);
+    PD_REQUIRE(nb <= 16384, "optimize_color: scan of %d elements", n);
+    k_oc_scan1<<<nb, 1024, 0, s>>>(in, n, out, bsum);
+    k_oc_scan2<<<1, 1024, 0, s>>>(bsum, nb, total);
+    k_oc_scan3<<<nb, 1024, 0, s>>>(out, n, bsum);
+    return PDHIP_OK;
+}
 
-__global__ void k_oc_fill(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, int V, int res, int A,
-                          const int* __restrict__ off, int* __restrict__ cursor, int* __restrict__ e_pix, double* __restrict__ e_w) {
+__global__ void k_oc_flags(const uint8_t* __restrict__ b, long long n, int* __restrict__ f) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) f[i] = b[i] ? 1 : 0;
+}
+__global__ void k_oc_flags_pos(const int* __restrict__ c, int n, int* __restrict__ f) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) f[i] = c[i] > 0 ? 1 : 0;
+}
+
+// masked pixel p -> record cid_of[p]; counts the texel contributions on the way
+__global__ void k_oc_records(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, const int* __restrict__ cid_of,
+                             const float* __restrict__ target, int V, int res, int A, OcRec* __restrict__ rec,
+                             float4* __restrict__ tgt4, int* __restrict__ pix_of, int* __restrict__ cnt) {
     const long long total = (long long)V * res * res;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
         if (!wmask[p]) continue;
         const int v = (int)(p / ((long long)res * res)), idx = (int)(p - (long long)v * res * res);
         const int y = idx / res, x = idx - y * res;
-        int tex[4]; double wt[4];
-        const int n = oc_corners(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, tex, wt);
-        for (int k = 0; k < n; ++k) {
-            const int slot = off[tex[k]] + atomicAdd(&cursor[tex[k]], 1);
-            e_pix[slot] = (int)p; e_w[slot] = wt[k];
+        int tex; double fx, fy;
+        oc_base(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, &tex, &fx, &fy);
+        const int cid = cid_of[p];
+        OcRec r; r.fx = (float)fx; r.fy = (float)fy; r.tex = tex; r.sgn = make_char4(0, 0, 0, 0);
+        rec[cid] = r;
+        const size_t plane = (size_t)res * res, o = (size_t)v * 3 * plane + (size_t)y * res + x;
+        tgt4[cid] = make_float4(target[o], target[o + plane], target[o + 2 * plane], 0.f);
+        pix_of[cid] = (int)p;
+        for (int c = 0; c < 4; ++c) { int t; double wt; if (oc_corner(tex, fx, fy, A, c, &t, &wt)) atomicAdd(&cnt[t], 1); }
+    }
+}
+__global__ void k_oc_fill(const OcRec* __restrict__ rec, const int* __restrict__ npix, int A, const int* __restrict__ off,
+                          int* __restrict__ cursor, int* __restrict__ ent) {
+    const int n = *npix;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const OcRec r = rec[i];
+        for (int c = 0; c < 4; ++c) {
+            int t; double wt;
+            if (oc_corner(r.tex, (double)r.fx, (double)r.fy, A, c, &t, &wt)) ent[off[t] + atomicAdd(&cursor[t], 1)] = (i << 2) | c;
         }
     }
 }
+__global__ void k_oc_active(const int* __restrict__ cnt, const int* __restrict__ apos, int ntex, int* __restrict__ act) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x) if (cnt[t] > 0) act[apos[t]] = t;
+}
 
-// contributions of one texel in ascending pixel order (the cursor order above is a race): insertion sort, lists are short.
-// One wave owns 64 consecutive texels, whose lists are one contiguous CSR range: the range is staged through LDS (coalesced
-// loads and stores), every lane sorts its own list there.  Ranges longer than OC_SORT_CAP fall back to sorting in global memory.
-#define OC_SORT_CAP 3072
-__global__ __launch_bounds__(64) void k_oc_sort(const int* __restrict__ off, const int* __restrict__ cnt, int ntex,
-                                                int* __restrict__ e_pix, double* __restrict__ e_w) {
-    __shared__ int s_p[OC_SORT_CAP];
-    __shared__ double s_w[OC_SORT_CAP];
-    const int lane = threadIdx.x;
-    for (int t0 = blockIdx.x * 64; t0 < ntex; t0 += gridDim.x * 64) {
-        const int t = t0 + lane;
-        const int b = t < ntex ? off[t] : 0, n = t < ntex ? cnt[t] : 0;
-        const int tl = min(t0 + 63, ntex - 1);
-        const int R0 = off[t0], R1 = off[tl] + cnt[tl], len = R1 - R0;
+// entries of one texel in ascending order (the cursor order above is a race): insertion sort, lists are short.  One wave owns 64
+// consecutive ACTIVE texels, whose lists are one contiguous CSR range staged through LDS; longer ranges are sorted in global memory.
+#define OC_SORT_CAP 4096
+__global__ __launch_bounds__(64) void k_oc_sort(const int* __restrict__ off, const int* __restrict__ cnt, const int* __restrict__ act,
+                                                const int* __restrict__ nact, int* __restrict__ ent) {
+    __shared__ int s_e[OC_SORT_CAP];
+    const int lane = threadIdx.x, na = *nact;
+    for (int a0 = blockIdx.x * 64; a0 < na; a0 += gridDim.x * 64) {
+        const int a = a0 + lane;
+        const int t = a < na ? act[a] : 0;
+        const int b = a < na ? off[t] : 0, n = a < na ? cnt[t] : 0;
+        const int tl = act[min(a0 + 63, na - 1)];
+        const int R0 = off[act[a0]], R1 = off[tl] + cnt[tl], len = R1 - R0;
         if (len <= OC_SORT_CAP) {
-            for (int i = lane; i < len; i += 64) { s_p[i] = e_pix[R0 + i]; s_w[i] = e_w[R0 + i]; }
+            for (int i = lane; i < len; i += 64) s_e[i] = ent[R0 + i];
             __syncthreads();
             const int lb = b - R0;
             for (int i = 1; i < n; ++i) {
-                const int kp = s_p[lb + i]; const double kw = s_w[lb + i];
+                const int k = s_e[lb + i];
                 int j = i - 1;
-                while (j >= 0 && s_p[lb + j] > kp) { s_p[lb + j + 1] = s_p[lb + j]; s_w[lb + j + 1] = s_w[lb + j]; --j; }
-                s_p[lb + j + 1] = kp; s_w[lb + j + 1] = kw;
+                while (j >= 0 && s_e[lb + j] > k) { s_e[lb + j + 1] = s_e[lb + j]; --j; }
+                s_e[lb + j + 1] = k;
             }
             __syncthreads();
-            for (int i = lane; i < len; i += 64) { e_pix[R0 + i] = s_p[i]; e_w[R0 + i] = s_w[i]; }
+            for (int i = lane; i < len; i += 64) ent[R0 + i] = s_e[i];
             __syncthreads();
         } else {
             for (int i = 1; i < n; ++i) {
-                const int kp = e_pix[b + i]; const double kw = e_w[b + i];
+                const int k = ent[b + i];
                 int j = i - 1;
-                while (j >= 0 && e_pix[b + j] > kp) { e_pix[b + j + 1] = e_pix[b + j]; e_w[b + j + 1] = e_w[b + j]; --j; }
-                e_pix[b + j + 1] = kp; e_w[b + j + 1] = kw;
+                while (j >= 0 && ent[b + j] > k) { ent[b + j + 1] = ent[b + j]; --j; }
+                ent[b + j + 1] = k;
             }
         }
     }
 }
 
-// forward: sign of the L1 residual per masked pixel and channel (0 where the clamp or the residual kills the gradient)
 // interleaved copy of the atlas being optimised (x, y, z = the three planes): the forward pass fetches a corner with one 16-byte
 // gather instead of three 4-byte ones; the backward pass keeps it in step with the planar parameter
 __global__ void k_oc_pack(const float* __restrict__ atlas, int ntex, float4* __restrict__ at4) {
@@ -192,63 +229,90 @@ __global__ void k_oc_pack(const float* __restrict__ atlas, int ntex, float4* __r
         at4[t] = make_float4(atlas[t], atlas[(size_t)ntex + t], atlas[2 * (size_t)ntex + t], 0.f);
 }
 
-__global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ at4, int A, const float* __restrict__ uv_map, int V,
-                                                    int res, const float* __restrict__ target, const uint8_t* __restrict__ wmask,
-                                                    int8_t* __restrict__ sgn /*[V*res*res][4]*/, float* __restrict__ images) {
-    const long long total = (long long)V * res * res;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
-        const int v = (int)(p / ((long long)res * res)), idx = (int)(p - (long long)v * res * res);
-        const int y = idx / res, x = idx - y * res;
-        if (!wmask[p]) {
-            if (images) for (int c = 0; c < 3; ++c) images[(((size_t)v * 3 + c) * res + y) * res + x] = 0.f;
-            continue;
-        }
-        int tex[4]; double wt[4];
-        const int n = oc_corners(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, tex, wt);
+// forward: bilinear lookup (f64), clamp, sign of the L1 residual per channel (0 where the clamp or the residual kills the gradient)
+__global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ at4, int A, OcRec* __restrict__ rec,
+                                                    const float4* __restrict__ tgt4, const int* __restrict__ npix,
+                                                    const int* __restrict__ pix_of, int res, float* __restrict__ images) {
+    const int n = *npix;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const OcRec r = rec[i];
+        const float4 tg = tgt4[i];
+        const double fx = (double)r.fx, fy = (double)r.fy;
+        int tex[4]; double wt[4]; bool ok[4]; float4 cor[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ok[c] = oc_corner(r.tex, fx, fy, A, c, &tex[c], &wt[c]); cor[c] = at4[ok[c] ? tex[c] : r.tex]; }
         char4 sg = make_char4(0, 0, 0, 0);
-        float4 cor[4];
-        for (int k = 0; k < n; ++k) cor[k] = at4[tex[k]];
+        float im[3];
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
             double val = 0.0;
-            for (int k = 0; k < n; ++k) val += wt[k] * (double)(c == 0 ? cor[k].x : (c == 1 ? cor[k].y : cor[k].z));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (ok[k]) val += wt[k] * (double)(c == 0 ? cor[k].x : (c == 1 ? cor[k].y : cor[k].z));
             const bool pass = val >= 0.0 && val <= 1.0;                 // clamp backward is inclusive
             const double img = fmin(fmax(val, 0.0), 1.0);
-            if (images) images[(((size_t)v * 3 + c) * res + y) * res + x] = (float)img;
-            const double d = img - (double)target[(((size_t)v * 3 + c) * res + y) * res + x];
+            im[c] = (float)img;
+            const double d = img - (double)(c == 0 ? tg.x : (c == 1 ? tg.y : tg.z));
             const signed char sc = (!pass || d == 0.0) ? 0 : (d > 0.0 ? 1 : -1);
             if (c == 0) sg.x = sc; else if (c == 1) sg.y = sc; else sg.z = sc;
         }
-        reinterpret_cast<char4*>(sgn)[p] = sg;
+        rec[i].sgn = sg;
+        if (images) {                                                   // last iteration: the final render (masked-out pixels stay 0)
+            const int p = pix_of[i];
+            const size_t plane = (size_t)res * res;
+            const int v = (int)(p / plane);
+            const size_t o = (size_t)v * 3 * plane + (p - (size_t)v * plane);
+            images[o] = im[0]; images[o + plane] = im[1]; images[o + 2 * plane] = im[2];
+        }
     }
 }
 
-// backward + torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay; single-tensor update order), per texel.
-// One wave owns 64 consecutive texels = one contiguous CSR range.  The range is streamed through LDS in chunks: 64 lanes load
-// (pixel, weight) coalesced and gather the pixels' sign bytes with 64 independent requests in flight, then every lane adds the
-// entries of its own list that fall into the chunk, in list order (same f64 summation order as a plain per-texel walk).
-#define OC_BW_CHUNK 1024
+// backward + torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay; single-tensor update order), per ACTIVE texel.
+// One wave owns 64 consecutive active texels = one contiguous CSR range.  The range is streamed through LDS in chunks: 64 lanes load
+// entries coalesced and gather the pixels' records with 64 independent 16-byte requests in flight (sign + the fractions the f64
+// weight is recomputed from), then every lane adds the entries of its own list that fall into the chunk, in list order.
+#define OC_BW_CHUNK 512
+#define OC_BW_U (OC_BW_CHUNK / 64)
 __global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__ off, const int* __restrict__ cnt,
-                                                         const int* __restrict__ e_pix, const double* __restrict__ e_w,
-                                                         const int8_t* __restrict__ sgn, double inv_count, float* __restrict__ param,
-                                                         float* __restrict__ m, float* __restrict__ vv, int ntex, float step_size,
-                                                         float bc2_sqrt, float4* __restrict__ at4) {
+                                                         const int* __restrict__ act, const int* __restrict__ nact,
+                                                         const int* __restrict__ ent, const OcRec* __restrict__ rec, double inv_count,
+                                                         float* __restrict__ param, float* __restrict__ m, float* __restrict__ vv,
+                                                         int ntex, float step_size, float bc2_sqrt, float4* __restrict__ at4) {
     __shared__ double sw[OC_BW_CHUNK];                         // one wave per workgroup: the barriers below are wave-local
     __shared__ char4 ss[OC_BW_CHUNK];
-    const int lane = threadIdx.x;
-    for (int t0 = blockIdx.x * 64; t0 < ntex; t0 += gridDim.x * 64) {
-        const int t = t0 + lane;
-        const int b = t < ntex ? off[t] : 0, n = t < ntex ? cnt[t] : 0;
-        const int tl = min(t0 + 63, ntex - 1);
-        const int R0 = off[t0], R1 = off[tl] + cnt[tl];
+    const int lane = threadIdx.x, na = *nact;
+    for (int a0 = blockIdx.x * 64; a0 < na; a0 += gridDim.x * 64) {
+        const int a = a0 + lane;
+        const int t = a < na ? act[a] : 0;
+        const int b = a < na ? off[t] : 0, n = a < na ? cnt[t] : 0;
+        const int tl = act[min(a0 + 63, na - 1)];
+        const int R0 = off[act[a0]], R1 = off[tl] + cnt[tl];
+        // the optimiser state of this lane's texel: requested now, used after the gradient is summed
+        float pm[3], pv[3], pp[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t i = (size_t)c * ntex + t;
+            pm[c] = m[i]; pv[c] = vv[i]; pp[c] = param[i];
+        }
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
         int cur = b;
         const int e = b + n;
         for (int c0 = R0; c0 < R1; c0 += OC_BW_CHUNK) {
             const int len = min(OC_BW_CHUNK, R1 - c0);
-            for (int i = lane; i < len; i += 64) {
-                const int px = e_pix[c0 + i];
-                sw[i] = e_w[c0 + i];
-                ss[i] = reinterpret_cast<const char4*>(sgn)[px];
+            // a chunk = OC_BW_U entries per lane: all entry loads, then all record gathers in flight together (the staging loop used
+            // to be a chain of dependent round trips, one entry per lane at a time)
+            int en[OC_BW_U];
+            OcRec rr[OC_BW_U];
+#pragma unroll
+            for (int u = 0; u < OC_BW_U; ++u) { const int i = u * 64 + lane; en[u] = i < len ? ent[c0 + i] : 0; }
+#pragma unroll
+            for (int u = 0; u < OC_BW_U; ++u) rr[u] = rec[en[u] >> 2];
+#pragma unroll
+            for (int u = 0; u < OC_BW_U; ++u) {
+                const int i = u * 64 + lane;
+                const double fx = (double)rr[u].fx, fy = (double)rr[u].fy;
+                const int c = en[u] & 3;
+                sw[i] = (c & 1 ? fx : 1.0 - fx) * (c & 2 ? fy : 1.0 - fy);
+                ss[i] = rr[u].sgn;
             }
             __syncthreads();
             const int stop = min(e, c0 + len);
@@ -259,17 +323,18 @@ __global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__
             }
             __syncthreads();
         }
-        if (t < ntex) {
+        if (a < na) {
             const double gs[3] = {g0, g1, g2};
             float np[3];
+#pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const size_t i = (size_t)c * ntex + t;
                 const float g = (float)gs[c];
-                const float mi = m[i] + (g - m[i]) * (1.0f - 0.9f);
-                const float vi = vv[i] * 0.999f + (g * g) * (1.0f - 0.999f);
+                const float mi = pm[c] + (g - pm[c]) * (1.0f - 0.9f);
+                const float vi = pv[c] * 0.999f + (g * g) * (1.0f - 0.999f);
                 m[i] = mi; vv[i] = vi;
                 const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
-                np[c] = param[i] + (-step_size) * (mi / denom);
+                np[c] = pp[c] + (-step_size) * (mi / denom);
                 param[i] = np[c];
             }
             at4[t] = make_float4(np[0], np[1], np[2], 0.f);
@@ -280,9 +345,9 @@ __global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t pdhip_optimize_color_ws_bytes(int V, int res, int A) {
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
-    return a256(px * 3 * 4) /*target*/ + a256(px) /*wmask*/ + a256(px * 4) /*sgn*/ + 2 * a256(tx * 3 * 4) /*m, v*/ +
-           3 * a256((tx + 4096) * 4) /*cnt, off, cursor*/ + a256(4096 * 4) /*block sums*/ + a256(px * 4 * 4) /*e_pix*/ + a256(px * 4 * 8) /*e_w*/ +
-           a256(tx * 16) /*interleaved atlas*/;
+    return a256(px * 3 * 4) /*target*/ + a256(px) /*wmask*/ + 2 * a256(px * 4) /*flags -> cid_of, pix_of*/ + 2 * a256(px * 16) /*records, targets*/ +
+           2 * a256(tx * 3 * 4) /*m, v*/ + 5 * a256((tx + 4096) * 4) /*cnt, off, cursor, apos, act*/ + a256(16384 * 4) /*block sums*/ +
+           a256(px * 4 * 4) /*entries*/ + a256(tx * 16) /*interleaved atlas*/ + 256 /*counters*/;
 }
 
 extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, const float* uv_map, const int64_t* face_idxs, int V,
@@ -290,47 +355,59 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
                                     float* final_images /*[V,3,res,res] or NULL*/, void* ws, void* stream) {
     PD_REQUIRE(atlas && uv_map && face_idxs && inpainted && ws && A > 0 && V > 0 && res > 0 && r > 0 && iterations >= 0,
                "pdhip_optimize_color: bad arguments");
-    PD_REQUIRE((long long)A * A <= 4096LL * 1024 && (long long)V * res * res * 4 < 0x7fffffffLL, "pdhip_optimize_color: atlas / view size too large");
+    PD_REQUIRE((long long)A * A <= 4096LL * 1024 && (long long)V * res * res <= 16384LL * 1024, "pdhip_optimize_color: atlas / view size too large");
     hipStream_t s = as_stream(stream);
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
     char* p = reinterpret_cast<char*>(ws);
     float* target = reinterpret_cast<float*>(p); p += a256(px * 3 * 4);
     uint8_t* wmask = reinterpret_cast<uint8_t*>(p); p += a256(px);
-    int8_t* sgn = reinterpret_cast<int8_t*>(p); p += a256(px * 4);
+    int* cid_of = reinterpret_cast<int*>(p); p += a256(px * 4);
+    int* pix_of = reinterpret_cast<int*>(p); p += a256(px * 4);
+    OcRec* rec = reinterpret_cast<OcRec*>(p); p += a256(px * 16);
+    float4* tgt4 = reinterpret_cast<float4*>(p); p += a256(px * 16);
     float* m = reinterpret_cast<float*>(p); p += a256(tx * 3 * 4);
     float* vv = reinterpret_cast<float*>(p); p += a256(tx * 3 * 4);
     int* cnt = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
     int* off = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
     int* cursor = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
-    int* bsum = reinterpret_cast<int*>(p); p += a256(4096 * 4);
-    int* e_pix = reinterpret_cast<int*>(p); p += a256(px * 4 * 4);
-    double* e_w = reinterpret_cast<double*>(p); p += a256(px * 4 * 8);
-    float4* at4 = reinterpret_cast<float4*>(p);
+    int* apos = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
+    int* act = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
+    int* bsum = reinterpret_cast<int*>(p); p += a256(16384 * 4);
+    int* ent = reinterpret_cast<int*>(p); p += a256(px * 4 * 4);
+    float4* at4 = reinterpret_cast<float4*>(p); p += a256(tx * 16);
+    int* npix = reinterpret_cast<int*>(p);                   // [0] masked pixels, [1] active texels
+    int* nact = npix + 1;
     const long long n = 3LL * A * A;
     PD_HIP(hipMemsetAsync(m, 0, n * 4, s));
     PD_HIP(hipMemsetAsync(vv, 0, n * 4, s));
     PD_HIP(hipMemsetAsync(cnt, 0, tx * 4, s));
     PD_HIP(hipMemsetAsync(cursor, 0, tx * 4, s));
+    if (final_images != nullptr) PD_HIP(hipMemsetAsync(final_images, 0, px * 3 * 4, s));
     dim3 g(min(cdiv((long long)res * res, 256), 2048), V);
     k_optcolor_target<<<g, 256, 0, s>>>(inpainted, r, uv_map, face_idxs, res, shrinked, A, target, wmask);
     const int gp = min(cdiv((long long)px, 256), 8192);
-    const int nb = cdiv((long long)tx, 1024);
-    k_oc_count<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, cnt);
-    k_oc_scan1<<<nb, 1024, 0, s>>>(cnt, (int)tx, off, bsum);
-    k_oc_scan2<<<1, 1024, 0, s>>>(bsum, nb);
-    k_oc_scan3<<<nb, 1024, 0, s>>>(off, (int)tx, bsum);
-    k_oc_fill<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, off, cursor, e_pix, e_w);
-    k_oc_sort<<<min(cdiv((long long)tx, 64), 16384), 64, 0, s>>>(off, cnt, (int)tx, e_pix, e_w);
-    k_oc_pack<<<min(cdiv((long long)tx, 256), 4096), 256, 0, s>>>(atlas, (int)tx, at4);
+    const int gt = min(cdiv((long long)tx, 256), 4096);
+    // masked pixels -> compact records (pixel order); texel contribution counts -> CSR offsets; active texels
+    k_oc_flags<<<gp, 256, 0, s>>>(wmask, (long long)px, pix_of);
+    OC_TRY(oc_scan(pix_of, (int)px, cid_of, bsum, npix, s));
+    k_oc_records<<<gp, 256, 0, s>>>(uv_map, wmask, cid_of, target, V, res, A, rec, tgt4, pix_of, cnt);
+    OC_TRY(oc_scan(cnt, (int)tx, off, bsum, nullptr, s));
+    k_oc_flags_pos<<<gt, 256, 0, s>>>(cnt, (int)tx, act);
+    OC_TRY(oc_scan(act, (int)tx, apos, bsum, nact, s));
+    k_oc_active<<<gt, 256, 0, s>>>(cnt, apos, (int)tx, act);
+    k_oc_fill<<<gp, 256, 0, s>>>(rec, npix, A, off, cursor, ent);
+    const int gw = min(cdiv((long long)tx, 64), 16384);
+    k_oc_sort<<<gw, 64, 0, s>>>(off, cnt, act, nact, ent);
+    k_oc_pack<<<gt, 256, 0, s>>>(atlas, (int)tx, at4);
     const double inv_count = 1.0 / ((double)V * 3.0 * res * res);
     for (int it = 0; it < iterations; ++it) {
         const bool last = it == iterations - 1;
-        k_oc_forward<<<gp, 256, 0, s>>>(at4, A, uv_map, V, res, target, wmask, sgn, last ? final_images : nullptr);
+        k_oc_forward<<<gp, 256, 0, s>>>(at4, A, rec, tgt4, npix, pix_of, res, last ? final_images : nullptr);
         const int step = it + 1;
         const double cur_lr = lr * pow(0.5, (double)(it / 15));            // StepLR(step_size 15, gamma 0.5)
         const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
-        k_oc_backward_adam<<<min(cdiv((long long)tx, 64), 16384), 64, 0, s>>>(off, cnt, e_pix, e_w, sgn, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
-                                              (float)sqrt(bc2), at4);
+        k_oc_backward_adam<<<gw, 64, 0, s>>>(off, cnt, act, nact, ent, rec, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
+                                             (float)sqrt(bc2), at4);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
