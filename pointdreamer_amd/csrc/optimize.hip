@@ -181,23 +181,24 @@ __global__ void k_oc_fill(const OcRec* __restrict__ rec, const int* __restrict__
         }
     }
 }
-__global__ void k_oc_active(const int* __restrict__ cnt, const int* __restrict__ apos, int ntex, int* __restrict__ act) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x) if (cnt[t] > 0) act[apos[t]] = t;
+// active texel a -> (texel, first entry, entries) as one int4-sized record: the per-iteration kernels read them with one coalesced load
+__global__ void k_oc_active(const int* __restrict__ cnt, const int* __restrict__ off, const int* __restrict__ apos, int ntex,
+                            int4* __restrict__ act) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x)
+        if (cnt[t] > 0) act[apos[t]] = make_int4(t, off[t], cnt[t], 0);
 }
 
 // entries of one texel in ascending order (the cursor order above is a race): insertion sort, lists are short.  One wave owns 64
 // consecutive ACTIVE texels, whose lists are one contiguous CSR range staged through LDS; longer ranges are sorted in global memory.
 #define OC_SORT_CAP 4096
-__global__ __launch_bounds__(64) void k_oc_sort(const int* __restrict__ off, const int* __restrict__ cnt, const int* __restrict__ act,
-                                                const int* __restrict__ nact, int* __restrict__ ent) {
+__global__ __launch_bounds__(64) void k_oc_sort(const int4* __restrict__ act, const int* __restrict__ nact, int* __restrict__ ent) {
     __shared__ int s_e[OC_SORT_CAP];
     const int lane = threadIdx.x, na = *nact;
     for (int a0 = blockIdx.x * 64; a0 < na; a0 += gridDim.x * 64) {
         const int a = a0 + lane;
-        const int t = a < na ? act[a] : 0;
-        const int b = a < na ? off[t] : 0, n = a < na ? cnt[t] : 0;
-        const int tl = act[min(a0 + 63, na - 1)];
-        const int R0 = off[act[a0]], R1 = off[tl] + cnt[tl], len = R1 - R0;
+        const int4 me = act[min(a, na - 1)], first = act[a0], lastr = act[min(a0 + 63, na - 1)];
+        const int b = me.y, n = a < na ? me.z : 0;
+        const int R0 = first.y, R1 = lastr.y + lastr.z, len = R1 - R0;
         if (len <= OC_SORT_CAP) {
             for (int i = lane; i < len; i += 64) s_e[i] = ent[R0 + i];
             __syncthreads();
@@ -234,34 +235,45 @@ __global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ a
                                                     const float4* __restrict__ tgt4, const int* __restrict__ npix,
                                                     const int* __restrict__ pix_of, int res, float* __restrict__ images) {
     const int n = *npix;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const OcRec r = rec[i];
-        const float4 tg = tgt4[i];
-        const double fx = (double)r.fx, fy = (double)r.fy;
-        int tex[4]; double wt[4]; bool ok[4]; float4 cor[4];
+    const int stride = gridDim.x * blockDim.x;
+    // two records per thread and trip: both records' streams and all eight corner gathers are requested before the first is used
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 2 * stride) {
+        OcRec r[2]; float4 tg[2]; int tex[2][4]; double wt[2][4]; bool ok[2][4]; float4 cor[2][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { ok[c] = oc_corner(r.tex, fx, fy, A, c, &tex[c], &wt[c]); cor[c] = at4[ok[c] ? tex[c] : r.tex]; }
-        char4 sg = make_char4(0, 0, 0, 0);
-        float im[3];
+        for (int q = 0; q < 2; ++q) { const int i = min(i0 + q * stride, n - 1); r[q] = rec[i]; tg[q] = tgt4[i]; }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double val = 0.0;
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (ok[k]) val += wt[k] * (double)(c == 0 ? cor[k].x : (c == 1 ? cor[k].y : cor[k].z));
-            const bool pass = val >= 0.0 && val <= 1.0;                 // clamp backward is inclusive
-            const double img = fmin(fmax(val, 0.0), 1.0);
-            im[c] = (float)img;
-            const double d = img - (double)(c == 0 ? tg.x : (c == 1 ? tg.y : tg.z));
-            const signed char sc = (!pass || d == 0.0) ? 0 : (d > 0.0 ? 1 : -1);
-            if (c == 0) sg.x = sc; else if (c == 1) sg.y = sc; else sg.z = sc;
-        }
-        rec[i].sgn = sg;
-        if (images) {                                                   // last iteration: the final render (masked-out pixels stay 0)
-            const int p = pix_of[i];
-            const size_t plane = (size_t)res * res;
-            const int v = (int)(p / plane);
-            const size_t o = (size_t)v * 3 * plane + (p - (size_t)v * plane);
-            images[o] = im[0]; images[o + plane] = im[1]; images[o + 2 * plane] = im[2];
+            for (int c = 0; c < 4; ++c) {
+                ok[q][c] = oc_corner(r[q].tex, (double)r[q].fx, (double)r[q].fy, A, c, &tex[q][c], &wt[q][c]);
+                cor[q][c] = at4[ok[q][c] ? tex[q][c] : r[q].tex];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = i0 + q * stride;
+            if (i >= n) break;
+            char4 sg = make_char4(0, 0, 0, 0);
+            float im[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double val = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (ok[q][k]) val += wt[q][k] * (double)(c == 0 ? cor[q][k].x : (c == 1 ? cor[q][k].y : cor[q][k].z));
+                const bool pass = val >= 0.0 && val <= 1.0;                 // clamp backward is inclusive
+                const double img = fmin(fmax(val, 0.0), 1.0);
+                im[c] = (float)img;
+                const double d = img - (double)(c == 0 ? tg[q].x : (c == 1 ? tg[q].y : tg[q].z));
+                const signed char sc = (!pass || d == 0.0) ? 0 : (d > 0.0 ? 1 : -1);
+                if (c == 0) sg.x = sc; else if (c == 1) sg.y = sc; else sg.z = sc;
+            }
+            rec[i].sgn = sg;
+            if (images) {                                                   // last iteration: the final render (masked-out pixels stay 0)
+                const int p = pix_of[i];
+                const size_t plane = (size_t)res * res;
+                const int v = (int)(p / plane);
+                const size_t o = (size_t)v * 3 * plane + (p - (size_t)v * plane);
+                images[o] = im[0]; images[o + plane] = im[1]; images[o + 2 * plane] = im[2];
+            }
         }
     }
 }
@@ -272,8 +284,7 @@ __global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ a
 // weight is recomputed from), then every lane adds the entries of its own list that fall into the chunk, in list order.
 #define OC_BW_CHUNK 512
 #define OC_BW_U (OC_BW_CHUNK / 64)
-__global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__ off, const int* __restrict__ cnt,
-                                                         const int* __restrict__ act, const int* __restrict__ nact,
+__global__ __launch_bounds__(64) void k_oc_backward_adam(const int4* __restrict__ act, const int* __restrict__ nact,
                                                          const int* __restrict__ ent, const OcRec* __restrict__ rec, double inv_count,
                                                          float* __restrict__ param, float* __restrict__ m, float* __restrict__ vv,
                                                          int ntex, float step_size, float bc2_sqrt, float4* __restrict__ at4) {
@@ -282,10 +293,9 @@ __global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__
     const int lane = threadIdx.x, na = *nact;
     for (int a0 = blockIdx.x * 64; a0 < na; a0 += gridDim.x * 64) {
         const int a = a0 + lane;
-        const int t = a < na ? act[a] : 0;
-        const int b = a < na ? off[t] : 0, n = a < na ? cnt[t] : 0;
-        const int tl = act[min(a0 + 63, na - 1)];
-        const int R0 = off[act[a0]], R1 = off[tl] + cnt[tl];
+        const int4 me = act[min(a, na - 1)], first = act[a0], lastr = act[min(a0 + 63, na - 1)];
+        const int t = me.x, b = me.y, n = a < na ? me.z : 0;
+        const int R0 = first.y, R1 = lastr.y + lastr.z;
         // the optimiser state of this lane's texel: requested now, used after the gradient is summed
         float pm[3], pv[3], pp[3];
 #pragma unroll
@@ -346,7 +356,7 @@ static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t pdhip_optimize_color_ws_bytes(int V, int res, int A) {
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
     return a256(px * 3 * 4) /*target*/ + a256(px) /*wmask*/ + 2 * a256(px * 4) /*flags -> cid_of, pix_of*/ + 2 * a256(px * 16) /*records, targets*/ +
-           2 * a256(tx * 3 * 4) /*m, v*/ + 5 * a256((tx + 4096) * 4) /*cnt, off, cursor, apos, act*/ + a256(16384 * 4) /*block sums*/ +
+           2 * a256(tx * 3 * 4) /*m, v*/ + 5 * a256((tx + 4096) * 4) /*cnt, off, cursor, apos, flags*/ + a256((tx + 4096) * 16) /*active texels*/ + a256(16384 * 4) /*block sums*/ +
            a256(px * 4 * 4) /*entries*/ + a256(tx * 16) /*interleaved atlas*/ + 256 /*counters*/;
 }
 
@@ -371,7 +381,8 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
     int* off = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
     int* cursor = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
     int* apos = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
-    int* act = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
+    int* aflag = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
+    int4* act = reinterpret_cast<int4*>(p); p += a256((tx + 4096) * 16);
     int* bsum = reinterpret_cast<int*>(p); p += a256(16384 * 4);
     int* ent = reinterpret_cast<int*>(p); p += a256(px * 4 * 4);
     float4* at4 = reinterpret_cast<float4*>(p); p += a256(tx * 16);
@@ -392,12 +403,12 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
     OC_TRY(oc_scan(pix_of, (int)px, cid_of, bsum, npix, s));
     k_oc_records<<<gp, 256, 0, s>>>(uv_map, wmask, cid_of, target, V, res, A, rec, tgt4, pix_of, cnt);
     OC_TRY(oc_scan(cnt, (int)tx, off, bsum, nullptr, s));
-    k_oc_flags_pos<<<gt, 256, 0, s>>>(cnt, (int)tx, act);
-    OC_TRY(oc_scan(act, (int)tx, apos, bsum, nact, s));
-    k_oc_active<<<gt, 256, 0, s>>>(cnt, apos, (int)tx, act);
+    k_oc_flags_pos<<<gt, 256, 0, s>>>(cnt, (int)tx, aflag);
+    OC_TRY(oc_scan(aflag, (int)tx, apos, bsum, nact, s));
+    k_oc_active<<<gt, 256, 0, s>>>(cnt, off, apos, (int)tx, act);
     k_oc_fill<<<gp, 256, 0, s>>>(rec, npix, A, off, cursor, ent);
     const int gw = min(cdiv((long long)tx, 64), 16384);
-    k_oc_sort<<<gw, 64, 0, s>>>(off, cnt, act, nact, ent);
+    k_oc_sort<<<gw, 64, 0, s>>>(act, nact, ent);
     k_oc_pack<<<gt, 256, 0, s>>>(atlas, (int)tx, at4);
     const double inv_count = 1.0 / ((double)V * 3.0 * res * res);
     for (int it = 0; it < iterations; ++it) {
@@ -406,7 +417,7 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
         const int step = it + 1;
         const double cur_lr = lr * pow(0.5, (double)(it / 15));            // StepLR(step_size 15, gamma 0.5)
         const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
-        k_oc_backward_adam<<<gw, 64, 0, s>>>(off, cnt, act, nact, ent, rec, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
+        k_oc_backward_adam<<<gw, 64, 0, s>>>(act, nact, ent, rec, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
                                              (float)sqrt(bc2), at4);
     }
     PD_LAUNCH_CHECK();
