@@ -157,6 +157,8 @@ def main():
     ap.add_argument('--parallel', default='shapes', choices=['shapes', 'views'])
     ap.add_argument('--ddnm-steps', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-period', type=int, default=1, help='HIP events around the dominant kernel in every k-th UNet forward of the timed '
+                    'region (1 = every forward, 0 = none: roofline.achieved is then null)')
     ap.add_argument('--no-graphs', action='store_true', help='nearest workload with several shapes per step: eager launches on streams '
                                                              'instead of one HIP graph per shape')
     ap.add_argument('--no-extras', action='store_true', help='skip the nearest-workload / one-shape-latency side measurements')
@@ -240,7 +242,7 @@ def main():
         step()
     sync()
     if inpainter is not None:
-        inpainter.model.profile(True)
+        inpainter.model.profile(args.profile_period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -218,7 +218,8 @@ int pdhip_unet_load_tensor(pdhip_unet* u, const char* name, const void* data, in
 int pdhip_unet_missing_tensors(const pdhip_unet* u, char* buf, int buf_len);
 /* UNetModel.forward (unet.py:635-664): x[N,3,S,S] f32, t[N] f32 -> out[N,out_channels,S,S] f32. */
 int pdhip_unet_forward(pdhip_unet* u, const float* x, const float* t, int N, float* out, void* stream);
-/* HIP-event timing of the dominant kernel (3x3 implicit-GEMM conv launches) on the launch stream. */
+/* HIP-event timing of the dominant kernel (3x3 implicit-GEMM conv launches) on the launch stream.  enable: 0 off, 1 every
+ * forward, k > 1 every k-th forward (an event record costs the stream a few us of pipeline bubble; 108 of them per forward). */
 int pdhip_unet_profile(pdhip_unet* u, int enable);
 int pdhip_unet_profile_read(pdhip_unet* u, double* total_ms, double* total_flops, long long* launches);
 /* the same for the attention launches (QK^T + softmax + PV, 4 T^2 C flop per image) -- north_star's MFMA-utilisation evidence */

@@ -142,7 +142,8 @@ class UNetModel:
     __call__ = forward
 
     def profile(self, enable):
-        check(self._L.pdhip_unet_profile(self._h, 1 if enable else 0), 'pdhip_unet_profile')
+        """enable: False / 0 off, True / 1 events around every forward's launches, k > 1 around every k-th forward's."""
+        check(self._L.pdhip_unet_profile(self._h, int(enable)), 'pdhip_unet_profile')
 
     def profile_read(self, attention=False):
         ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
