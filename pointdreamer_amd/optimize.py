@@ -9,6 +9,9 @@ from .extract_texture_map import rasterize, interpolate
 from .ours_utils import crop_params
 
 
+_DEBUG_COUNTS = None      # set to a list by a tool to receive [masked pixels, active texels, pixels, texels] of each call
+
+
 def texture_coordinates(cams, vertices, faces, uvs, mesh_tex_idx, uv_centers, uv_scales, padding, inpaint_scale_factors, res):
     """ours_utils.py:1675-1706 (unflipped): uv_map [V,res,res,2], face_idx [V,res,res]."""
     L = _lib.lib()
@@ -48,4 +51,7 @@ def optimize_color(atlas_img, inpainted_imgs, vertices, faces, uvs, mesh_tex_idx
     ws = torch.empty((L.pdhip_optimize_color_ws_bytes(V, res, A),), dtype=torch.uint8, device=dev)
     check(L.pdhip_optimize_color(ptr(atlas), A, ptr(uv_map), ptr(fidx), V, res, ptr(inp), inp.shape[-1], ptr(shr, allow_none=True),
                                  float(lr), int(iterations), ptr(final), ptr(ws), stream()), 'pdhip_optimize_color')
+    if _DEBUG_COUNTS is not None:                       # tools: (masked pixels, active texels) of the last call -- synchronises
+        c = ws[-256:].view(torch.int32)[:2].cpu()
+        _DEBUG_COUNTS[:] = [int(c[0]), int(c[1]), V * res * res, A * A]
     return atlas.unsqueeze(0), final

@@ -60,6 +60,10 @@ vv, ff, xd = standin_geometry(g['points'], A, dev, logging.getLogger('x'))
 us, oc = timed(lambda: popt.optimize_color(dil.permute(2, 0, 1).flip(1), inp, vv, ff, xd['uvs'], xd['mesh_tex_idx'], cams, None, None, None,
                                            uvc, uvs, pad, sf, None, un[1]), 3)
 add('8f-1 optimize_color (100 Adam iterations, res 1024)', us, 100 * V * 1024 * 1024 * (8 + 12 + 12))
+popt._DEBUG_COUNTS = [0, 0, 0, 0]
+popt.optimize_color(dil.permute(2, 0, 1).flip(1), inp, vv, ff, xd['uvs'], xd['mesh_tex_idx'], cams, None, None, None, uvc, uvs, pad, sf, None, un[1], iterations=1)
+rows[-1].update(masked_pixels=popt._DEBUG_COUNTS[0], active_texels=popt._DEBUG_COUNTS[1], pixels=popt._DEBUG_COUNTS[2], texels=popt._DEBUG_COUNTS[3])
+popt._DEBUG_COUNTS = None
 _, st = hpr.hidden_point_removal(g['points'], eyes, 100, already_valid=pv[0], return_stats=True)
 rows.append(dict(stage='P3b certificate statistics (8 views x 30k points)', **st))
 tot = [r_ for r_ in rows if r_['stage'].split()[0] in ('P1+P2', 'P2b', 'P3', 'P4-P6', 'I0', 'Uq1-Uq4', 'Uq5') and 'linear' not in r_['stage']]
