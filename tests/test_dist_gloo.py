@@ -47,6 +47,8 @@ def _worker(rank, world, port, n_views, ret):
         def before(coords, colors, vertices, faces, cam_local, n_local, res, cam_res, save, opts, view_offset):
             assert n_local == len(mine) and view_offset == mine.start and cam_local['cams'] == list(mine)
             assert opts['point_validation_by_o3d'] is True          # same default as pipeline.colorize_one_mesh
+            # demo.py:115-117: the optional depth-outlier refinement reaches the rank's own per-view stage (it used to be swallowed)
+            assert opts['refine_point_validation'] is True and opts['refine_res'] == 256
             sl = slice(mine.start, mine.stop)
             return dict(sparse=full[sl].clone(), mask0=torch.ones_like(full[sl]), mask2=torch.ones_like(full[sl]),
                         scale_factors=all_sf[sl].clone(), uv_centers=all_uvc[sl].clone(), uv_scales=all_uvs[sl].clone(), padding=0.05,
@@ -69,6 +71,7 @@ def _worker(rank, world, port, n_views, ret):
         atlas = pdist.colorize_one_mesh_view_parallel(
             None, None, None, None, None, dict(gb_pos=None, mask=torch.zeros((1, A, A, 1)), per_atlas_pixel_face_id=None),
             dict(cams=list(range(n_views)), base_dirs=None, eye_positions=None), n_views, r, 8, rank, world, shape_key=3,
+            refine_point_validation_by_remove_abnormal_depth=True, refine_res=256,
             stages=dict(before=before, inpaint=inpaint, visibility=visibility, after=after))
         expect = (full * 2.0 + 1.0).sum(0).permute(1, 2, 0)
         assert torch.equal(atlas, expect), "every rank must hold the full atlas built from all views"
