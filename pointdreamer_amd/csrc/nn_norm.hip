@@ -304,16 +304,19 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
         if (RES == 0) {
             // four independent 16-byte loads in flight per thread (memory-level parallelism for the HBM stream)
             int p = p_begin + sub;
-            for (; p + 3 * pps < p_end; p += 4 * pps) {
-                half8 v[4];
+#ifndef GNA_U
+#define GNA_U 4
+#endif
+            for (; p + (GNA_U - 1) * pps < p_end; p += GNA_U * pps) {
+                half8 v[GNA_U];
 #pragma unroll
 #ifdef PD_LAB_GN_NTL                                       // (lab builds only: streaming loads -- no effect on the step)
-                for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs));
+                for (int u = 0; u < GNA_U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs));
 #else
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs);
+                for (int u = 0; u < GNA_U; ++u) v[u] = *reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p + u * pps) * cs);
 #endif
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { float r[8]; finish(v[u], r); store(p + u * pps, r); }
+                for (int u = 0; u < GNA_U; ++u) { float r[8]; finish(v[u], r); store(p + u * pps, r); }
             }
             for (; p < p_end; p += pps) {
                 const half8 v = *reinterpret_cast<const half8*>(Xs + ((size_t)n * H * W + p) * cs);

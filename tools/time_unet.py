@@ -19,6 +19,8 @@ ap.add_argument('--sampler-steps', type=int, default=10, help='also time this ma
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 from pointdreamer_amd import _lib
+if os.environ.get('PDHIP_LAB_LIB'):                      # lab builds: PDHIP_LAB_LIB=path/to/lab.so python tools/time_unet.py
+    _lib.LIB_PATH = os.path.abspath(os.environ['PDHIP_LAB_LIB'])
 _lib.lib().pdhip_debug_set_fuse_gn(a.fuse); _lib.lib().pdhip_debug_set_fold_resample(a.fold)
 if a.fin >= 0:
     _lib.lib().pdhip_debug_set_fold_finalize(a.fin)
