@@ -218,7 +218,8 @@ def get_sparse_images(point_pixels, colors, point_validation, hard_masks, save_p
 
 def nearest_fill(img, site_mask, layout='CHW'):
     """Batched exact nearest-site fill.  img [B,C,H,W] (layout 'CHW') or [B,H,W,C] ('HWC') float32;
-    site_mask [B,H,W] bool/uint8 or float (site iff != 0)."""
+    site_mask [B,H,W] bool/uint8 or float (site iff != 0), or [B,K,H,W] of which plane 0 of every image is used in place
+    (the kernel takes a batch stride: no copy of `mask2[:, 0]`)."""
     L = _lib.lib()
     img = img.float().contiguous()
     dev = _dev(img)
@@ -229,6 +230,7 @@ def nearest_fill(img, site_mask, layout='CHW'):
         B, H, W, Cn = img.shape
         bs, cs, ps = H * W * Cn, 1, Cn
     site_mask = site_mask.contiguous()
+    mstride = H * W * (site_mask.shape[1] if site_mask.dim() == 4 else 1)
     is_f32 = 1 if site_mask.dtype == torch.float32 else 0
     if not is_f32:
         site_mask = as_u8(site_mask)
@@ -236,7 +238,7 @@ def nearest_fill(img, site_mask, layout='CHW'):
             raise _lib.PdhipError("site mask must be bool, uint8 or float32")
     out = torch.empty_like(img)
     ws = torch.empty((L.pdhip_nearest_fill_ws_ints(B, H, W),), dtype=torch.int32, device=dev)
-    check(L.pdhip_nearest_fill(ptr(img), ptr(out), B, Cn, H, W, bs, cs, ps, ptr(site_mask), is_f32, H * W, ptr(ws),
+    check(L.pdhip_nearest_fill(ptr(img), ptr(out), B, Cn, H, W, bs, cs, ps, ptr(site_mask), is_f32, mstride, ptr(ws),
                                stream()), 'pdhip_nearest_fill')
     return out
 
@@ -314,7 +316,7 @@ def get_inpainted_images(sparse_imgs, hard_mask0s, hard_mask2s, save_path, inpai
     if method == 'DDNM_inpaint':
         out = inpainter.inpaint_views(sparse_imgs, hard_mask2s[:, 0].contiguous(), first_key=first_key, advance=advance)
     elif method == 'nearest':
-        out = nearest_fill(sparse_imgs, hard_mask2s[:, 0].contiguous(), 'CHW')
+        out = nearest_fill(sparse_imgs, hard_mask2s, 'CHW')                  # (plane 0 of every view's mask, read in place)
     elif method == 'linear':
         out = linear_fill(sparse_imgs, hard_mask2s[:, 0].contiguous())
     else:
