@@ -291,7 +291,8 @@ def test_groupnorm_apply_is_independent_of_pixels_per_thread(nn, film):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0], outs[1][7])
 
 
-@pytest.mark.parametrize("N,H,W,Ca,Cb", [(2, 16, 16, 256, 256), (1, 32, 16, 512, 256), (3, 8, 16, 512, 0), (1, 64, 64, 256, 256)])
+@pytest.mark.parametrize("N,H,W,Ca,Cb", [(2, 16, 16, 256, 256), (1, 32, 16, 512, 256), (3, 8, 16, 512, 0), (1, 64, 64, 256, 256),
+                                          (1, 256, 256, 256, 256), (2, 128, 128, 512, 256)])     # the last two: the UNet's own decoder shapes
 def test_gn_skip_one_pass_equals_two_launches(nn, N, H, W, Ca, Cb):
     """k_gn_skip (in_layers GroupNorm -> SiLU and the skip 1x1 of a channel-changing ResBlock in one pass over the never-materialised
     concat, unet.py:197-209 / 236-256 / 657-659): h0 must equal the stand-alone GroupNorm-apply kernel bit for bit on the same
@@ -338,7 +339,7 @@ def test_gn_skip_one_pass_equals_two_launches(nn, N, H, W, Ca, Cb):
     assert torch.equal(sks[0], sks[1])                   # same K order, same fragments: the two forms agree bit for bit
     # shapes the kernel does not serve are refused, not mis-computed
     assert L.pdhip_gn_silu_skip1x1_nhwc_f16(_ptr(xa), _ptr(xb) if Cb else None, Ca, Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(wp), _ptr(b),
-                                            _ptr(h0), _ptr(sk), N, H, W - 1, _stream()) != 0
+                                            _ptr(h0), _ptr(sk), N, 1, 127, _stream()) != 0      # (H * W not a multiple of the 128-pixel tile)
 
 
 def test_unet_full_256_fused_skip_equals_two_launch_routing(nn):
@@ -429,3 +430,37 @@ def test_colorize_one_mesh_with_refine_option(nn, tmp_path):
     assert (pv0 & ~pv1).float().mean().item() < 0.02                   # a clean sphere: (almost) nothing to remove
     if torch.equal(pv0, pv1):
         assert torch.equal(outs[False]['atlas'], outs[True]['atlas'])
+
+
+def test_optimize_color_is_deterministic_and_leaves_unsampled_texels(nn):
+    """optimize_color (ours_utils.py:1583-1785) on compact lists: the CSR entries are sorted inside a texel and every sum runs in list
+    order, so two runs on the same inputs agree bit for bit (the reference's grid_sample backward uses atomics and does not); texels
+    no masked pixel samples are never touched; the final render is zero outside the mask."""
+    from pointdreamer_amd import synthetic, optimize as popt
+    import pointdreamer_amd.camera_utils as cu
+    from pointdreamer_amd.demo import standin_geometry
+    import logging
+    V, CAM, A, res, r = 3, 256, 256, 192, 64
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    xyz, _ = synthetic.sphere_points(2000, seed=2)
+    vv, ff, xd = standin_geometry(T(xyz), A, torch.device(DEV), logging.getLogger('t'))
+    cams, _, _, _ = cu.create_cameras(V, 1.6, CAM, device=DEV)
+    g = torch.Generator().manual_seed(9)
+    atlas0 = torch.rand((3, A, A), generator=g).to(DEV)
+    inp = torch.rand((V, 3, r, r), generator=g).to(DEV)
+    shr = (torch.rand((V, A, A), generator=g) > 0.25).to(DEV)
+    uvc = torch.zeros((V, 1, 2), device=DEV); uvs = torch.full((V, 1, 1), 1.1, device=DEV); sf = torch.ones((V,), device=DEV)
+    runs = []
+    for _ in range(2):
+        popt._DEBUG_COUNTS = [0, 0, 0, 0]
+        a, im = popt.optimize_color(atlas0, inp, vv, ff, xd['uvs'], xd['mesh_tex_idx'], cams, None, None, None, uvc, uvs, 0.05, sf, None, shr,
+                                    iterations=12, res=res)
+        counts = list(popt._DEBUG_COUNTS); popt._DEBUG_COUNTS = None
+        runs.append((a.clone(), im.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    masked, active, pixels, texels = counts
+    assert 0 < masked < pixels and 0 < active <= texels
+    moved = (runs[0][0][0] != atlas0).any(0)
+    assert 0 < int(moved.sum()) <= active                       # only texels that receive a contribution can move
+    assert int((runs[0][1] != 0).any(1).sum()) <= masked        # the render is zero outside the masked pixels
+    assert runs[0][1].min() >= 0 and runs[0][1].max() <= 1
