@@ -221,6 +221,85 @@ def gen_ddnm_full(name, steps=10, n_img=2, seed=2024, stride=4):
                         xs=np.stack(xs_all), x_last=np.stack(final_all))
 
 
+def gen_ddnm_full100(name, n_img=2, seed=4100, stride=4, every=10, threads=6):
+    """D1 o U1 over the WHOLE 100-step schedule at full size (VERDICT r3 missing 1): the reference's simplified_ddnm_inpainting
+    (diffusion.py:459-570) driving the reference's fp32 UNetModel to completion, nothing cut.  Stored: a strided sample of the
+    sampler state after updates every-1, 2*every-1, ... (k = 9, 19, .., 99), and the sampler's full return value (the
+    inverse_data_transform'ed, clamped image, diffusion.py:563-566)."""
+    diffusion = _import_diffusion()
+    import yaml
+    import time
+
+    class NS(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+        __setattr__ = dict.__setitem__
+
+    def to_ns(d):
+        return NS({k: to_ns(v) if isinstance(v, dict) else v for k, v in d.items()})
+    torch.set_num_threads(threads)
+    steps = 100
+    config = to_ns(yaml.safe_load(open(os.path.join(rh.REF, 'models/DDNM/configs/imagenet_256.yml'))))
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, 12)
+    model = ref_unet(FULL, w)
+    masked, masks, tape = ddnm_full_inputs(seed, n_img, steps)
+    xs_all, out_all, ks = [], [], list(range(every - 1, steps, every))
+    orig_to, orig_randn, orig_randn_like = torch.Tensor.to, torch.randn, torch.randn_like
+    for im in range(n_img):
+        args = NS(sigma_y=0, eta=0.85, seed=1234)
+        runner = diffusion.Diffusion(args, config, device=torch.device('cpu'))
+        pos = {'i': 0}
+        seen = []
+        t0 = time.time()
+
+        def next_noise(*a, **k):
+            n = torch.from_numpy(tape[im, pos['i']][None].copy())
+            pos['i'] += 1
+            return n
+
+        def wrapped(x, t):
+            k = len(seen)                                  # x = the state after update k - 1
+            assert float(t[0]) == 990.0 - 10.0 * k
+            seen.append(x.detach()[:, :, ::stride, ::stride].clone() if (k - 1) in ks else None)
+            with torch.no_grad():
+                y = model(x, t)
+            if k % 10 == 0:
+                print(name, 'image', im, 'step', k, 'x std %.4f' % float(x.std()), '%.0f s' % (time.time() - t0), flush=True)
+            return y
+
+        def to(self, *a, **k):
+            if a and a[0] == 'cuda':
+                return self
+            return orig_to(self, *a, **k)
+        last = []
+        orig_inv = diffusion.inverse_data_transform
+
+        def inv(config_, xi):                              # the un-clamped final state x_0 is what the sampler hands to this
+            last.append(xi.detach().clone())
+            return orig_inv(config_, xi)
+        torch.Tensor.to, torch.randn, torch.randn_like = to, next_noise, next_noise
+        diffusion.inverse_data_transform = inv
+        try:
+            out = runner.simplified_ddnm_inpainting(wrapped, torch.from_numpy(masked[im:im + 1]).unsqueeze(0),
+                                                    torch.from_numpy(masks[im:im + 1]))
+        finally:
+            torch.Tensor.to, torch.randn, torch.randn_like = orig_to, orig_randn, orig_randn_like
+            diffusion.inverse_data_transform = orig_inv
+        assert pos['i'] == steps + 1 and len(seen) == steps and len(last) == 1
+        out = out[0, 0].numpy() if out.dim() == 5 else out[0].numpy()
+        assert out.shape == (3, 256, 256) and out.min() >= 0.0 and out.max() <= 1.0
+        xs = [seen[k + 1][0].numpy() for k in ks[:-1]] + [last[0].reshape(3, 256, 256)[:, ::stride, ::stride].numpy()]
+        xs_all.append(np.stack(xs))
+        out_all.append(out.copy())
+        np.savez_compressed(os.path.join(OUT, name), seed=seed, steps=steps, n_img=im + 1, stride=stride, weight_seed=12,
+                            ks=np.array(ks), xs=np.stack(xs_all), out=np.stack(out_all))
+        print(name, 'image', im, 'done in %.0f s' % (time.time() - t0), flush=True)
+
+
 def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -233,6 +312,8 @@ def main():
         gen_unet('unet_full.npz', FULL, seed=12, batch=1, stride=8)
     if 'ddnm_full' in which:
         gen_ddnm_full('ddnm_unet_full.npz')
+    if 'ddnm_full100' in which:
+        gen_ddnm_full100('ddnm_unet_full100.npz')
 
 
 if __name__ == '__main__':
