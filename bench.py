@@ -78,7 +78,7 @@ def _cpu_worker(args):
     return wall, stages, off
 
 
-def cpu_baseline(timed=2, max_workers=None):
+def cpu_baseline(timed=3, max_workers=None):
     """Reference CPU 'nearest' path next to the GPU number.  kind = "port": the reference has no runnable
     CPU pipeline (demo.py:12,19 hard-code CUDA; kaolin / nvdiffrast are CUDA-only), so this is the oracle's CPU restatement of
     it -- project, raster, depth test + hidden-point removal through qhull, sparse images, scipy griddata nearest inpaint, NBF
@@ -145,7 +145,59 @@ def cpu_baseline(timed=2, max_workers=None):
                        f"{workers} cores = every core the container may use (cgroup quota / affinity; the host shows {cores} logical CPUs; {model}): one independent 30k-point 8-view shape stream per core at A=1024, "
                        f"1 warm-up + {timed} timed shapes each = {workers * timed} shapes in {slowest:.1f} s (pool wall {total_wall:.1f} s); "
                        f"median {per_shape:.2f} s/shape/core with hidden-point removal, {off:.2f} s without; no diffusion on the CPU "
-                       f"(a CPU fp32 UNet forward is ~8 s, x800 per DDNM shape)")
+                       f"(a CPU fp32 UNet forward is ~8 s, x800 per DDNM shape).  Protocol note: SURVEY 8d asks for 3 warm-up + 10 timed shapes and "
+                       f"the median; the task statement bounds this leg to a ~10-30 s sample, so every core runs 1 warm-up + {timed} timed shapes "
+                       f"({workers * timed} timed shapes in all), value = aggregate rate over the slowest core, the per-shape figure is the median")
+
+
+def calibrate(dev, seconds=3.0):
+    """In-run calibration of the box ("calibrate with a measured GEMM and a copy kernel, and report both"), untimed, after
+    the timed region: the vendor's plain f16 GEMM (hipBLASLt through torch.matmul, 8192^3) on operands with the bench's statistics
+    (activations ~ N(0, 1), weights ~ N(0, 0.05^2)) and on zeros -- the gap between the two is the data-dependent power limit --
+    and a device-to-device copy of a 1 GiB f16 tensor (read + write).  sclk / power are read from sysfs when the box exposes them."""
+    import glob
+    out = {}
+    n = 8192
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, budget):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        it = max(5, min(400, int(budget * 1e3 / max(e0.elapsed_time(e1), 1e-3))))
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / it * 1e-3
+    try:
+        a = torch.randn((n, n), device=dev).half(); b = (torch.randn((n, n), device=dev) * 0.05).half(); c = torch.empty((n, n), device=dev, dtype=torch.float16)
+        t = timed(lambda: torch.matmul(a, b, out=c), seconds * 0.4)
+        out['gemm_f16_random_tflops'] = 2.0 * n ** 3 / t / 1e12
+        a.zero_(); b.zero_()
+        t = timed(lambda: torch.matmul(a, b, out=c), seconds * 0.3)
+        out['gemm_f16_zeros_tflops'] = 2.0 * n ** 3 / t / 1e12
+        del a, b, c
+        x = torch.empty((512 * 1024 * 1024,), device=dev, dtype=torch.float16).normal_(); y = torch.empty_like(x)
+        t = timed(lambda: y.copy_(x), seconds * 0.3)
+        out['copy_gbs'] = 2.0 * x.numel() * 2 / t / 1e9
+        del x, y
+    except Exception as e:                                  # noqa: BLE001 -- a side figure must not take the headline line down
+        out['error'] = str(e)[:200]
+    try:
+        for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))[:1]:
+            cur = [l for l in open(f).read().splitlines() if l.strip().endswith('*')]
+            if cur:
+                out['sclk_mhz_idle_after_run'] = int(''.join(ch for ch in cur[0].split(':')[1] if ch.isdigit()))
+        for f in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_average'))[:1]:
+            out['power_w_after_run'] = int(open(f).read()) / 1e6
+    except Exception:                                       # noqa: BLE001 -- sysfs is optional
+        pass
+    out['note'] = ("torch.matmul (hipBLASLt) 8192^3 f16 on N(0,1) x N(0,0.05^2) operands and on zeros; copy = 1 GiB f16 device-to-device, "
+                   "read + write bytes; measured by this run after the timed region")
+    return out
 
 
 def main():
@@ -161,10 +213,12 @@ def main():
                     'region (1 = every forward, 0 = none: roofline.achieved is then null)')
     ap.add_argument('--no-graphs', action='store_true', help='nearest workload with several shapes per step: eager launches on streams '
                                                              'instead of one HIP graph per shape')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU rehearsal of the N > 1 path)")
+    ap.add_argument('--one-device', action='store_true', help='rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0 (with --backend gloo)')
     ap.add_argument('--no-extras', action='store_true', help='skip the nearest-workload / one-shape-latency side measurements')
     ap.add_argument('--shapes-per-step', type=int, default=4,
                     help='independent shapes textured per step on each GPU, their 8-view sets batched through the UNet together '
-                         '(BASELINE configs[4] style).  Measured on one MI355X: 1 -> 1670, 2 -> 1836, 4 -> 1939, 8 -> 1953 '
+                         '(BASELINE configs[4] style).  Measured on one MI355X (round 3): 1 -> 1 926, 4 -> 2 100-2 150, 8 -> 2 081 '
                          'shapes/hour; 1 = one shape at a time (configs[2], lowest latency)')
     args = ap.parse_args()
 
@@ -173,12 +227,17 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from pointdreamer_amd import synthetic, pipeline, _lib
     import pointdreamer_amd.camera_utils as cu
@@ -193,6 +252,12 @@ def main():
     cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, CAM_RES, device=dev)
     camera_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
     xatlas = dict(gb_pos=g['gb_pos'], mask=g['mask'], per_atlas_pixel_face_id=g['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
+    if world > 1 and args.parallel == 'shapes':            # the view-parallel extra textures the SAME shape on every rank (seed 0)
+        sh0 = synthetic.make_shape(30000, A, seed=0)
+        g0 = {k: T(v) for k, v in sh0.items()}
+        xatlas0 = dict(gb_pos=g0['gb_pos'], mask=g0['mask'], per_atlas_pixel_face_id=g0['per_atlas_pixel_face_id'], uvs=None, mesh_tex_idx=None)
+    else:
+        g0, xatlas0 = g, xatlas
     inpainter = None
     SPS = max(1, args.shapes_per_step) if args.parallel == 'shapes' else 1
     views_here = V * SPS if args.parallel == 'shapes' else len(pdist.shard_range(V, rank, world))
@@ -330,14 +395,57 @@ def main():
             except Exception as e:                      # noqa: BLE001 -- a side figure must not take the headline line down
                 extras['nearest_graphs'] = dict(error=str(e)[:200])
             one(cfg)
-            sync(); t1 = time.perf_counter()
-            one(cfg)
-            sync(); d1 = time.perf_counter() - t1
-            extras['ddnm_one_shape'] = dict(metric="seconds per shape, configs[2] with one shape per step (UNet batch 8)", seconds=d1,
-                                            value=3600.0 / d1)
+            d1s = []
+            for _ in range(3):
+                sync(); t1 = time.perf_counter()
+                one(cfg)
+                sync(); d1s.append(time.perf_counter() - t1)
+            d1 = float(np.median(d1s))
+            extras['ddnm_one_shape'] = dict(metric="seconds per shape, configs[2] with one shape per step (UNet batch 8); median of 3", seconds=d1,
+                                            samples=d1s, value=3600.0 / d1)
+        # the north_star's scaling claim (configs[3]): ONE shape, its 8 views sharded over the ranks, one RCCL all_gather -- run after the
+        # timed region on every rank, next to the same shape on rank 0 alone (UNet batch 8), so the line carries the speed-up itself
+        if world > 1 and args.parallel == 'shapes' and not args.no_extras and world <= V:
+            try:
+                vp = lambda: pdist.colorize_one_mesh_view_parallel(g0['points'], g0['colors'], g0['vertices'], g0['faces'], g0['f_normals'],
+                                                                  xatlas0, camera_info, rank=rank, world=world, **cfg)
+                vp(); vps = []
+                for _ in range(3):
+                    sync(); t1 = time.perf_counter()
+                    vp()
+                    sync(); tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    vps.append(float(tt.item()))
+                dvp = float(np.median(vps))
+                d1 = None
+                if rank == 0:
+                    one = lambda c: pipeline.colorize_one_mesh(g0['points'], g0['colors'], g0['vertices'], g0['faces'], g0['f_normals'], xatlas0,
+                                                               camera_info, **c)
+                    one(cfg); d1s = []
+                    for _ in range(3):
+                        torch.cuda.synchronize(); t1 = time.perf_counter()
+                        one(cfg)
+                        torch.cuda.synchronize(); d1s.append(time.perf_counter() - t1)
+                    d1 = float(np.median(d1s))
+                sync()
+                extras['view_parallel'] = dict(metric=f"configs[3]: one shape, 8 views sharded over {world} GPUs ({len(pdist.shard_range(V, 0, world))} per rank), "
+                                                      "one RCCL all_gather of the per-view records; median of 3, max over ranks",
+                                               seconds_per_shape=dvp, samples=vps, n1_one_shape_seconds=d1,
+                                               speedup_vs_n1_one_shape=(d1 / dvp) if d1 else None)
+            except Exception as e:                          # noqa: BLE001 -- a side figure must not take the headline line down
+                extras['view_parallel'] = dict(error=str(e)[:300])
     else:
         roofline = dict(bound="hbm", kernel="n/a (nearest workload: sub-millisecond HBM-bound kernels)", achieved=None, peak=8000.0,
                         unit="GB/s", frac=None, traffic=None)
+    calib = None
+    if rank == 0 and inpainter is not None and not args.no_extras:
+        calib = calibrate(dev)
+        if roofline is not None and calib.get('gemm_f16_random_tflops'):
+            roofline['calibrated_peak'] = calib['gemm_f16_random_tflops']
+            roofline['frac_of_calibrated'] = roofline['achieved'] / calib['gemm_f16_random_tflops'] if roofline.get('achieved') else None
+            roofline['calibration'] = calib
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         out = dict(metric=f"shapes/hour (30k-pt cloud, 8x256^2 views, {'DDNM' if args.workload == 'ddnm' else 'nearest inpainting, no diffusion'}) on MI355X", value=value, unit="shapes/hour",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,

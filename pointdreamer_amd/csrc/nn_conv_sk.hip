@@ -526,6 +526,8 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     // second wave on every SIMD; with >= 1.5 rounds co-resident workgroups do that already and the lock-step of the groups only
     // costs (tools/bench_sk.py, 512 tiles of 128x128: 148 us with one group, 184 with two)
     // The 128x128 tile takes the loader-specialised form instead (8): 26.2 vs 26.8 us at 128^2 batch 1, 42.4 vs 44.3 at 32^2 batch 8.
+    // (four K-groups exist for the 64x32 tile only: on the 64x64 tile the form needed 138 spilled VGPRs and was never routed)
+    if (kg == 4 && pl.tile_id != 4) kg = 2;
     if (kg == 0) kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 8 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
 #define SK_L(T, BM_, BN_, NST_, KG_) launch_sk<T, BM_, BN_, NST_, KG_>(SK_ARGS)
 #define SK_LS(T, BM_, BN_, NST_) launch_sk<T, BM_, BN_, NST_, 1, true>(SK_ARGS)
@@ -543,7 +545,7 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     (pl.tile_id == 1 ? (kg == 1 ? (st == 3 ? SK_L(T, 128, 128, 3, 1) : st == 4 ? SK_L(T, 128, 128, 4, 1) : SK_L(T, 128, 128, 2, 1)) : SK_L(T, 128, 128, 2, 2))        \
      : pl.tile_id == 2 ? (kg == 1 ? (st == 2 ? SK_L(T, 128, 64, 2, 1) : st == 4 ? SK_L(T, 128, 64, 4, 1) : SK_L(T, 128, 64, 3, 1))                                   \
                           : (st == 2 ? SK_L(T, 128, 64, 2, 2) : SK_L(T, 128, 64, 3, 2)))                                                                          \
-     : pl.tile_id == 3 ? (kg == 1 ? (st == 2 ? SK_L(T, 64, 64, 2, 1) : SK_L(T, 64, 64, 4, 1)) : kg == 4 ? SK_L(T, 64, 64, 2, 4)                                       \
+     : pl.tile_id == 3 ? (kg == 1 ? (st == 2 ? SK_L(T, 64, 64, 2, 1) : SK_L(T, 64, 64, 4, 1))                                                                      \
                           : (st == 2 ? SK_L(T, 64, 64, 2, 2) : st == 3 ? SK_L(T, 64, 64, 3, 2) : SK_L(T, 64, 64, 4, 2)))                                             \
                        : (kg == 1 ? (st == 2 ? SK_L(T, 64, 32, 2, 1) : SK_L(T, 64, 32, 4, 1)) : kg == 4 ? (st == 2 ? SK_L(T, 64, 32, 2, 4) : SK_L(T, 64, 32, 3, 4))    \
                           : (st == 2 ? SK_L(T, 64, 32, 2, 2) : st == 3 ? SK_L(T, 64, 32, 3, 2) : SK_L(T, 64, 32, 4, 2))))

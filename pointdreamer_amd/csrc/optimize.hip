@@ -100,13 +100,17 @@ __device__ __forceinline__ bool oc_corner(int tex, double fx, double fy, int A, 
     *t = tex + A + 1; *wt = fx * fy; return bx && by;
 }
 
-// exclusive prefix sum of n ints in three steps (block sums -> scan of the block sums -> add): n <= 16384 * 1024.  total (may be
-// null) receives the sum of all elements.
+// exclusive prefix sum of n ints in three steps (block sums -> scan of the block sums -> add), four elements per thread:
+// n <= 16384 * 4096 = 64 Mi (20 views of 1024^2 are 20 Mi pixels -- the 20-view camera distributions of demo.py).  total (may be
+// null) receives the sum of all elements.  Integer sums: the result does not depend on the partition.
+constexpr int OC_SCAN_EPT = 4, OC_SCAN_BLK = 1024 * OC_SCAN_EPT, OC_SCAN_MAXB = 16384;
 __global__ void k_oc_scan1(const int* __restrict__ in, int n, int* __restrict__ out, int* __restrict__ bsum) {
     __shared__ int sh[1024];
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const int v = i < n ? in[i] : 0;
-    sh[threadIdx.x] = v;
+    const long long i0 = (long long)blockIdx.x * OC_SCAN_BLK + threadIdx.x * OC_SCAN_EPT;
+    int v[OC_SCAN_EPT], s4 = 0;
+#pragma unroll
+    for (int j = 0; j < OC_SCAN_EPT; ++j) { v[j] = i0 + j < n ? in[i0 + j] : 0; s4 += v[j]; }
+    sh[threadIdx.x] = s4;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
         const int t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
@@ -114,12 +118,14 @@ __global__ void k_oc_scan1(const int* __restrict__ in, int n, int* __restrict__ 
         sh[threadIdx.x] += t;
         __syncthreads();
     }
-    if (i < n) out[i] = sh[threadIdx.x] - v;
+    int run = sh[threadIdx.x] - s4;
+#pragma unroll
+    for (int j = 0; j < OC_SCAN_EPT; ++j) { if (i0 + j < n) out[i0 + j] = run; run += v[j]; }
     if (threadIdx.x == 1023) bsum[blockIdx.x] = sh[1023];
 }
 __global__ void k_oc_scan2(int* __restrict__ bsum, int nb, int* __restrict__ total) {   // one block: exclusive scan of <= 16384 block sums
-    __shared__ int sh[16384];
-    for (int i = threadIdx.x; i < 16384; i += blockDim.x) sh[i] = i < nb ? bsum[i] : 0;
+    __shared__ int sh[OC_SCAN_MAXB];
+    for (int i = threadIdx.x; i < OC_SCAN_MAXB; i += blockDim.x) sh[i] = i < nb ? bsum[i] : 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         int run = 0;
@@ -130,13 +136,16 @@ __global__ void k_oc_scan2(int* __restrict__ bsum, int nb, int* __restrict__ tot
     for (int i = threadIdx.x; i < nb; i += blockDim.x) bsum[i] = sh[i];
 }
 __global__ void k_oc_scan3(int* __restrict__ out, int n, const int* __restrict__ bsum) {
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    if (i < n) out[i] += bsum[blockIdx.x];
+    const long long i0 = (long long)blockIdx.x * OC_SCAN_BLK + threadIdx.x * OC_SCAN_EPT;
+    const int add = bsum[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < OC_SCAN_EPT; ++j)
+        if (i0 + j < n) out[i0 + j] += add;
 }
 #define OC_TRY(expr) do { int rc_ = (expr); if (rc_ != PDHIP_OK) return rc_; } while (0)
 static int oc_scan(const int* in, int n, int* out, int* bsum, int* total, hipStream_t s) {
-    const int nb = cdiv(n, 1024);
-    PD_REQUIRE(nb <= 16384, "optimize_color: scan of %d elements", n);
+    const int nb = cdiv(n, OC_SCAN_BLK);
+    PD_REQUIRE(nb <= OC_SCAN_MAXB, "optimize_color: scan of %d elements", n);
     k_oc_scan1<<<nb, 1024, 0, s>>>(in, n, out, bsum);
     k_oc_scan2<<<1, 1024, 0, s>>>(bsum, nb, total);
     k_oc_scan3<<<nb, 1024, 0, s>>>(out, n, bsum);
@@ -365,7 +374,8 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
                                     float* final_images /*[V,3,res,res] or NULL*/, void* ws, void* stream) {
     PD_REQUIRE(atlas && uv_map && face_idxs && inpainted && ws && A > 0 && V > 0 && res > 0 && r > 0 && iterations >= 0,
                "pdhip_optimize_color: bad arguments");
-    PD_REQUIRE((long long)A * A <= 4096LL * 1024 && (long long)V * res * res <= 16384LL * 1024, "pdhip_optimize_color: atlas / view size too large");
+    PD_REQUIRE((long long)A * A <= 4096LL * 1024 && (long long)V * res * res <= (long long)OC_SCAN_MAXB * OC_SCAN_BLK,
+               "pdhip_optimize_color: atlas / view size too large (A^2 <= 4 Mi texels, V res^2 <= 64 Mi pixels)");
     hipStream_t s = as_stream(stream);
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
     char* p = reinterpret_cast<char*>(ws);

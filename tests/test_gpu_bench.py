@@ -29,3 +29,30 @@ def test_bench_prints_one_json_line_with_the_contract_fields(extra):
     if "nearest" not in extra:
         assert r["bound"] == "mfma" and r["achieved"] > 100 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
         assert d["config"]["shapes_per_step"] == (1 if "--shapes-per-step" in extra else 4)
+        # in-run calibration: the vendor GEMM on operands with the bench's statistics and on zeros, and a copy
+        cal = r["calibration"]
+        assert cal["gemm_f16_random_tflops"] > 300 and cal["gemm_f16_zeros_tflops"] >= 0.9 * cal["gemm_f16_random_tflops"] and cal["copy_gbs"] > 1000, cal
+        assert abs(r["frac_of_calibrated"] - r["achieved"] / r["calibrated_peak"]) < 1e-9
+        one = d["extras"]["ddnm_one_shape"]
+        assert len(one["samples"]) == 3 and min(one["samples"]) <= one["seconds"] <= max(one["samples"])
+
+
+def test_bench_two_ranks_rehearsal_carries_the_view_parallel_figure():
+    """The N > 1 code path of bench.py on the one GPU there is (two ranks on cuda:0 over gloo): weak-scaling headline over both ranks'
+    shapes, plus extras.view_parallel = one shape with its 8 views sharded 4 + 4 and gathered once, next to the same shape on rank 0
+    alone -- the figure the driver's 8-GPU run needs for the >= 6x view-parallel claim (BASELINE.json north_star)."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ddnm-steps", "2", "--shapes-per-step", "1",
+           "--backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["shapes_per_step"] == 2 and d["cpu_baseline"] is None
+    vp = d["extras"]["view_parallel"]
+    assert "error" not in vp, vp
+    assert vp["seconds_per_shape"] > 0 and vp["n1_one_shape_seconds"] > 0 and abs(vp["speedup_vs_n1_one_shape"] - vp["n1_one_shape_seconds"] / vp["seconds_per_shape"]) < 1e-9
+    assert len(vp["samples"]) == 3

@@ -165,3 +165,32 @@ def test_state_dict_unexpected_and_missing_keys(nn):
     m4 = di.UNetModel(max_batch=1, device=DEV, **kw)
     with pytest.raises(lib.PdhipError):
         m4.load_state_dict(bad, strict=False)
+
+
+def test_twenty_views_with_optimize_from_ours_at_the_default_size():
+    """demo.py's 20-view camera distributions ('blender' / 'exact_blender' / 'self_defined') with the shipped `optimize_from: ours`:
+    optimize_color at its default res = 1024 sees 20 x 1024^2 = 20 Mi pixels (round 3 capped the pixel scan at 16 Mi and raised).
+    Runs end to end, is deterministic, stays in range and actually moves the atlas (the arithmetic itself is pinned at small sizes by
+    test_optimize_color_vs_oracle; the integer scan's result does not depend on its partition)."""
+    import numpy as np
+    from pointdreamer_amd import pipeline, synthetic as syn
+    import pointdreamer_amd.camera_utils as cu
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    stacks, slices, A, V, R, r = 24, 48, 1024, 20, 512, 256
+    verts, faces, lut = syn.uv_sphere(stacks, slices)
+    gb_pos, mask, fid = syn.latlong_atlas(A, stacks, slices, gutter=2, lut=lut)
+    uvs, fuv = syn.uv_sphere_uvs(stacks, slices, A, gutter=2)
+    cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, R, device=DEV)
+    xat = dict(gb_pos=T(gb_pos), mask=T(mask), per_atlas_pixel_face_id=T(fid), uvs=T(uvs), mesh_tex_idx=T(fuv))
+    cam_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    fn = T(syn.face_normals(verts, faces))
+    x, c = syn.sphere_points(20000, seed=3)
+    kw = dict(view_num=V, res=r, cam_res=R, point_validation_by_o3d=True, texture_gen_method='nearest', point_size=1, edge_point_size=1,
+              crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82, edge_dilate_kernels=[21], complete_unseen_by='unproject')
+    base = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, optimize_from=None, **kw)[4]
+    a1 = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, optimize_from='ours', **kw)[4]
+    a2 = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, optimize_from='ours', **kw)[4]
+    assert a1.shape == base.shape and torch.isfinite(a1).all() and float(a1.min()) >= 0.0 and float(a1.max()) <= 1.0
+    assert torch.equal(a1, a2)
+    d = (a1 - base).abs()
+    assert float(d.max()) > 1e-3 and float((d > 0).float().mean()) > 0.2          # the 100 Adam steps moved the sampled texels

@@ -24,7 +24,7 @@ ap.add_argument('--order', type=int, default=0, help='tile order hook: 0 auto, 1
 ap.add_argument('--iters', type=int, default=30)
 ap.add_argument('--fixed', action='store_true')
 ap.add_argument('--stamps', action='store_true', help='lab stamp build: print the per-wave loop time split of the last launch')
-ap.add_argument('--lib', default=None, help='alternative libpdhip.so (tools/lab_sk.sh builds)')
+ap.add_argument('--lib', default=None, help='alternative libpdhip.so (tools/lab_unit.sh NAME nn_conv_sk -D... builds)')
 a = ap.parse_args()
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
