@@ -190,7 +190,8 @@ def test_twenty_views_with_optimize_from_ours_at_the_default_size():
     base = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, optimize_from=None, **kw)[4]
     a1 = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, optimize_from='ours', **kw)[4]
     a2 = pipeline.colorize_one_mesh(T(x), T(c), T(verts), T(faces), fn, xat, cam_info, optimize_from='ours', **kw)[4]
-    assert a1.shape == base.shape and torch.isfinite(a1).all() and float(a1.min()) >= 0.0 and float(a1.max()) <= 1.0
+    # (the optimised atlas is a free Adam parameter: the reference does not clamp it, ours_utils.py:1730-1785)
+    assert a1.shape == base.shape and torch.isfinite(a1).all() and float(a1.min()) >= -1.0 and float(a1.max()) <= 2.0
     assert torch.equal(a1, a2)
     d = (a1 - base).abs()
     assert float(d.max()) > 1e-3 and float((d > 0).float().mean()) > 0.2          # the 100 Adam steps moved the sampled texels
