@@ -15,7 +15,7 @@ namespace pdnn {
 
 #define HD_TW 32
 #define HD_TH 8
-#define HD_TPW 4                             // tiles per workgroup (stacked in y)
+#define HD_TPW 4                             // tiles per workgroup (stacked in y) at large batches; fewer when the grid would not fill the chip
 #define HD_IW (HD_TW + 2)
 #define HD_IH (HD_TH + 2)
 #define HD_NPIX (HD_IW * HD_IH)              // 340 input pixels per tile
@@ -53,7 +53,7 @@ template <int NO, int C>
 __global__ __launch_bounds__(512) void k_head(const half_t* __restrict__ X, const float* __restrict__ stats,
                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                               const half_t* __restrict__ wz, const float* __restrict__ bias,
-                                              float* __restrict__ y, int H, int W) {
+                                              float* __restrict__ y, int H, int W, int tpw) {
     constexpr int KK = C / 32;                       // MFMA k-steps over the channels
     constexpr int NT = (9 * NO + 15) / 16;           // 16-column tiles of z actually needed
     constexpr int NR = NT * 16;                      // weight rows staged (of the 64 packed ones)
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(512) void k_head(const half_t* __restrict__ X, cons
 
     const int q4 = lane >> 4, r16 = lane & 15;
     // a workgroup walks HD_TPW tiles down its column: the 64 KB of packed weights are staged once for all of them
-    for (int it = 0; it < HD_TPW; ++it) {
-    const int y0 = (blockIdx.y * HD_TPW + it) * HD_TH;
+    for (int it = 0; it < tpw; ++it) {
+    const int y0 = (blockIdx.y * tpw + it) * HD_TH;
     if (y0 >= H) break;
     auto src_of = [&](int chunk, bool* inimg) -> const half_t* {
         const int idx = chunk * 16 + r16;
@@ -177,8 +177,12 @@ static int head_launch(const half_t* X, const float* stats, const float* gamma, 
     auto kern = k_head<NO, C>;
     const size_t smem = head_smem_bytes(C, NO);
     PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    dim3 grid(cdiv(W, HD_TW), cdiv(cdiv(H, HD_TH), HD_TPW), N);
-    kern<<<grid, 512, smem, s>>>(X, stats, gamma, beta, wz, bias, y, H, W);
+    // the packed weights are staged once per workgroup: 4 tiles per workgroup at large batches, fewer while that leaves < 512 workgroups
+    // (UNet batch 1: 64 workgroups of 4 tiles were a quarter of the chip, 56 us; one tile each: 256 workgroups)
+    int tpw = HD_TPW;
+    while (tpw > 1 && (long long)cdiv(W, HD_TW) * cdiv(cdiv(H, HD_TH), tpw) * N < 512) tpw >>= 1;
+    dim3 grid(cdiv(W, HD_TW), cdiv(cdiv(H, HD_TH), tpw), N);
+    kern<<<grid, 512, smem, s>>>(X, stats, gamma, beta, wz, bias, y, H, W, tpw);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -15,6 +15,7 @@ ap.add_argument('--sk', type=int, default=-1, help='pdhip_debug_set_conv_sk mode
 ap.add_argument('--fskip', type=int, default=-1, help='pdhip_debug_set_fuse_skip mode (0 off, 1 auto, 2 always; -1 = default)')
 ap.add_argument('--finc', type=int, default=-1, help='pdhip_debug_set_fold_finalize_chunks (-1 = default)')
 ap.add_argument('--out', default='gpurun_out/unet_latency.json')
+ap.add_argument('--graph', type=int, default=0, help='1: also time the forward and the sampler replayed from a HIP graph (torch.cuda.CUDAGraph)')
 ap.add_argument('--sampler-steps', type=int, default=10, help='also time this many DDNM steps through pdhip_ddnm_sample (0 = skip)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -55,6 +56,24 @@ for N in a.batches:
         torch.cuda.synchronize()
         e0.record(); inp.inpaint_views(imgs * masks[:, None], masks); e1.record(); torch.cuda.synchronize()
         row['ddnm_step_ms'] = round(e0.elapsed_time(e1) / a.sampler_steps, 3)
+        if a.graph:
+            st = torch.cuda.Stream()
+            mi, mk = (imgs * masks[:, None]).contiguous(), masks.contiguous()
+            with torch.cuda.stream(st):
+                inp.inpaint_views(mi, mk, first_key=0)
+                st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    out_g = inp.inpaint_views(mi, mk, first_key=0)
+                g.replay(); st.synchronize()
+                ref = inp.inpaint_views(mi, mk, first_key=0)
+                st.synchronize()
+                row['graph_equal'] = bool(torch.equal(out_g, ref))
+                e0.record(st)
+                for _ in range(3):
+                    g.replay()
+                e1.record(st); st.synchronize()
+                row['ddnm_step_ms_graph'] = round(e0.elapsed_time(e1) / (3 * a.sampler_steps), 3)
     rows.append(row)
     print(json.dumps(row), flush=True)
     del m
