@@ -216,7 +216,9 @@ int pdhip_unet_num_tensors(const pdhip_unet* u);
 int pdhip_unet_load_tensor(pdhip_unet* u, const char* name, const void* data, int is_f16, const int64_t* shape, int ndim,
                            void* stream);
 int pdhip_unet_missing_tensors(const pdhip_unet* u, char* buf, int buf_len);
-/* UNetModel.forward (unet.py:635-664): x[N,3,S,S] f32, t[N] f32 -> out[N,out_channels,S,S] f32. */
+/* UNetModel.forward (unet.py:635-664): x[N,3,S,S] f32, t[N] f32 -> out[N,out_channels,S,S] f32.
+ * A handle owns its activation arena and split-K workspace (ticket words + slabs): at most ONE forward / sampler call of a handle may
+ * be in flight at a time (calls on one stream are ordered by the stream; two streams need two handles). */
 int pdhip_unet_forward(pdhip_unet* u, const float* x, const float* t, int N, float* out, void* stream);
 /* HIP-event timing of the dominant kernel (3x3 implicit-GEMM conv launches) on the launch stream.  enable: 0 off, 1 every
  * forward, k > 1 every k-th forward (an event record costs the stream a few us of pipeline bubble; 108 of them per forward). */

@@ -307,6 +307,12 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
                                                            split * SLAB_BYTES + ((i * TN + j) * 256 + t4) * 16, 0, /*sc1: write-through*/ 16);
         }
+        // hand-off form R1 of the cdna guide (section 6, guideline 16; microarch "valid forms"): the payload is stored WRITE-THROUGH (sc1:
+        // it is in memory, not in this XCD's L2, once the store has completed), every storing wave drains with an asm vmcnt(0) the
+        // compiler cannot drop, the workgroup joins, and only then one lane takes the ticket with a relaxed agent-scope atomic; the last
+        // arriver reads the slabs with sc1 loads (L1 bypass).  No release / acquire fence: a buffer_wbl2 / buffer_inv pair per workgroup
+        // measured 3.9x slower in the guide's own table and orders nothing the write-through + drain does not.  Contract (pdhip.h,
+        // pdhip_unet_forward): ONE forward in flight per handle -- tickets and slabs live in the handle's workspace.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
         __syncthreads();                                   // ... before ONE lane takes the ticket
         volatile int* flag = reinterpret_cast<volatile int*>(smem + FLAG_OFF);

@@ -590,9 +590,15 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const long long M = (long long)N * H * W;
     // large-image 3x3 layers: halo-resident kernel (2.1x less L2 -> LDS traffic per flop) once it fills the chip
     // (tuning hook: tile geometry 32 forces it, any other forced geometry disables it)
-    if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0))
-        return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused, splitk_ws,
-                            splitk_ws_floats, apply_table, res_up, in_up);
+    if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0)) {
+        // (the first PD_SK_TICKET_FLOATS words of the workspace are k_conv_sk's self-resetting ticket counters: the halo kernel's f32
+        // partials -- only under the forced-split tuning hooks -- must not land on them, or the next split k_conv_sk launch never
+        // sees its last ticket)
+        float* hws = splitk_ws != nullptr && splitk_ws_floats > PD_SK_TICKET_FLOATS ? splitk_ws + PD_SK_TICKET_FLOATS : nullptr;
+        const size_t hfl = hws != nullptr ? splitk_ws_floats - PD_SK_TICKET_FLOATS : 0;
+        return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused, hws, hfl, apply_table,
+                            res_up, in_up);
+    }
     // small-M layers (output tiles do not fill the chip): small tiles, deep staging, split-K combined inside the launch
     if (in_up == 0 && res_up == 0 && apply_table == nullptr && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
         const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, X2 != nullptr, splitk_ws ? splitk_ws_floats : 0);

@@ -869,8 +869,10 @@ extern "C" int pdhip_gn_silu_conv3x3_nhwc_f16(const void* x, const float* gamma,
     float* table = ws + (size_t)N * 64 + gws;
     PD_TRY(gn_stats((const half_t*)x, N, H * W, Cin, 1e-5f, stats, ws + (size_t)N * 64, gws, s));
     PD_TRY(gn_table(stats, gamma, beta, film, film_stride, N, Cin, table, s));
+    // (the debug split-K workspace is shared with pdhip_conv2d_nhwc_f16, whose k_conv_sk route keeps its tickets in the first words)
+    float* hws = pdnn::g_dbg_splitk_ws != nullptr && pdnn::g_dbg_splitk_floats > PD_SK_TICKET_FLOATS ? pdnn::g_dbg_splitk_ws + PD_SK_TICKET_FLOATS : nullptr;
     return conv3x3_halo((const half_t*)x, (const half_t*)w_packed, bias, (const half_t*)residual, (half_t*)y, N, H, W, Cin, Cout,
-                        Cout_pad, (const half_t*)zero_page, s, nullptr, nullptr, pdnn::g_dbg_splitk_ws, pdnn::g_dbg_splitk_floats, table);
+                        Cout_pad, (const half_t*)zero_page, s, nullptr, nullptr, hws, hws ? pdnn::g_dbg_splitk_floats - PD_SK_TICKET_FLOATS : 0, table);
 }
 /* tuning hook: the APPLY conv on a ready-made (A, B) table [N][Cin/8][16] (tools/bench_conv.py --apply) */
 extern "C" int pdhip_debug_conv3x3_apply(const void* x, const float* table, const void* w_packed, const float* bias, const void* residual,

@@ -62,23 +62,24 @@ __global__ void k_optcolor_target(const float* __restrict__ inp, int r, const fl
     }
 }
 
-// ---- gather formulation on COMPACT lists (round 3).  The texture coordinates and the masks are fixed for the whole optimisation, so
-// everything an iteration needs is laid out once:
-//   * the masked pixels, in pixel order, as 16-byte records {fx, fy, tex, sgn}: the bilinear fractions (exactly representable in
-//     f32: ix = u A - 0.5 with a 24-bit u and A = 2^k leaves at most 24 significant bits below the binary point, and out-of-range
-//     coordinates are clamped to integers), the index of the top-left texel, and the sign bytes the forward pass writes;
-//     their targets as float4 next to them.  The forward pass is a coalesced stream over these two arrays + four 16-byte gathers
-//     from the interleaved atlas per pixel (no mask test, no uv arithmetic, no divergence);
-//   * the transpose of the sampling operator as a CSR table texel -> entries, an entry = (compact pixel << 2 | corner) in 4 bytes,
-//     sorted ascending inside a texel (deterministic f64 summation order -- the reference's grid_sample backward / index_put atomics
-//     are not).  The backward pass gathers the pixel's record (one 16-byte request gives the sign AND the fractions the weight is
-//     recomputed from, exactly) instead of streaming an 8-byte weight next to a 4-byte gather;
-//   * the texels that receive any contribution: the others have zero gradient and zero Adam moments for ever, their update is
-//     exactly + 0, so they -- and their 40 bytes of optimiser state per iteration -- are skipped.
-// Round 2 (uv arithmetic + mask test per pixel and iteration, 12-byte entries, every texel updated): 129 + 154 us per iteration at
-// V = 8, res = 1024 on the stage benchmark; this form: see DESIGN.md.
-
-struct __align__(16) OcRec { float fx, fy; int tex; char4 sgn; };
+// ---- gather formulation on lists SORTED BY BASE TEXEL (round 4; round 3 kept a CSR table texel -> (pixel, corner) entries).
+// The texture coordinates and the masks are fixed for the whole optimisation, so everything an iteration needs is laid out once:
+//   * the masked pixels, counting-sorted by the texel their bilinear footprint starts at (`base` = top-left texel; inside a bucket
+//     ascending pixel index: a deterministic f64 summation order -- the reference's grid_sample backward / index_put atomics are
+//     not), as structure-of-arrays: fxy[i] = the bilinear fractions (exactly representable in f32: ix = u A - 0.5 with a 24-bit u
+//     and A = 2^k leaves at most 24 significant bits below the binary point, out-of-range coordinates are clamped to integers),
+//     tgt4[i] = (target r, g, b, base texel), sgn[i] = the three L1 signs of the current iteration in one byte, boff[t] = first
+//     pixel of bucket t;
+//   * forward = a coalesced stream over fxy / tgt4 (24 bytes per pixel) + four 16-byte gathers from the interleaved atlas, which
+//     neighbouring threads share (sorted by base texel), writing ONE byte per pixel;
+//   * backward + Adam = one wave per 64 consecutive texels.  Texel t receives corner 0 of bucket t, corner 1 of bucket t - 1,
+//     corner 2 of bucket t - A and corner 3 of bucket t - A - 1: two CONTIGUOUS pixel ranges per wave ([t0 - 1, t0 + 63] and the
+//     same one row up) streamed through LDS -- 9 bytes per pixel, each pixel read by exactly two waves.  No entry table (round 3:
+//     4 bytes per corner + a 16-byte record gather per corner = 80 + 320 MB of requests per iteration at V = 8, res = 1024), no
+//     active-texel records; texels without a contribution are skipped (zero gradient and zero Adam moments for ever: their update
+//     is exactly + 0), so they and their 36 bytes of optimiser state per iteration are never touched.
+// Per iteration at V = 8, res = 1024, A = 1024 (5.2 M masked pixels): ~130 MB forward + ~135 MB backward out of a ~190 MB working set
+// (inside the 256 MB Infinity Cache; round 3: ~460 MB out of ~290 MB).  Timings: DESIGN.md.
 
 // the top-left texel and the fractions of a pixel (kaolin texture_mapping == grid_sample(align_corners=False, padding 'border', v
 // flipped)): gx = 2u-1, gy = -(2w-1); ix = ((g+1)/2)*A - 0.5; border padding = clamp to [0, A-1]
@@ -152,17 +153,9 @@ static int oc_scan(const int* in, int n, int* out, int* bsum, int* total, hipStr
     return PDHIP_OK;
 }
 
-__global__ void k_oc_flags(const uint8_t* __restrict__ b, long long n, int* __restrict__ f) {
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) f[i] = b[i] ? 1 : 0;
-}
-__global__ void k_oc_flags_pos(const int* __restrict__ c, int n, int* __restrict__ f) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) f[i] = c[i] > 0 ? 1 : 0;
-}
 
-// masked pixel p -> record cid_of[p]; counts the texel contributions on the way
-__global__ void k_oc_records(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, const int* __restrict__ cid_of,
-                             const float* __restrict__ target, int V, int res, int A, OcRec* __restrict__ rec,
-                             float4* __restrict__ tgt4, int* __restrict__ pix_of, int* __restrict__ cnt) {
+// masked pixel -> its base texel's bucket count
+__global__ void k_oc_count(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, int V, int res, int A, int* __restrict__ cntb) {
     const long long total = (long long)V * res * res;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
         if (!wmask[p]) continue;
@@ -170,46 +163,34 @@ __global__ void k_oc_records(const float* __restrict__ uv_map, const uint8_t* __
         const int y = idx / res, x = idx - y * res;
         int tex; double fx, fy;
         oc_base(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, &tex, &fx, &fy);
-        const int cid = cid_of[p];
-        OcRec r; r.fx = (float)fx; r.fy = (float)fy; r.tex = tex; r.sgn = make_char4(0, 0, 0, 0);
-        rec[cid] = r;
-        const size_t plane = (size_t)res * res, o = (size_t)v * 3 * plane + (size_t)y * res + x;
-        tgt4[cid] = make_float4(target[o], target[o + plane], target[o + 2 * plane], 0.f);
-        pix_of[cid] = (int)p;
-        for (int c = 0; c < 4; ++c) { int t; double wt; if (oc_corner(tex, fx, fy, A, c, &t, &wt)) atomicAdd(&cnt[t], 1); }
+        atomicAdd(&cntb[tex], 1);
     }
 }
-__global__ void k_oc_fill(const OcRec* __restrict__ rec, const int* __restrict__ npix, int A, const int* __restrict__ off,
-                          int* __restrict__ cursor, int* __restrict__ ent) {
-    const int n = *npix;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const OcRec r = rec[i];
-        for (int c = 0; c < 4; ++c) {
-            int t; double wt;
-            if (oc_corner(r.tex, (double)r.fx, (double)r.fy, A, c, &t, &wt)) ent[off[t] + atomicAdd(&cursor[t], 1)] = (i << 2) | c;
-        }
+// ... and into the bucket (arrival order: a race, repaired by k_oc_sortb)
+__global__ void k_oc_scatter(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, int V, int res, int A,
+                             const int* __restrict__ boff, int* __restrict__ cursor, int* __restrict__ pix) {
+    const long long total = (long long)V * res * res;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        if (!wmask[p]) continue;
+        const int v = (int)(p / ((long long)res * res)), idx = (int)(p - (long long)v * res * res);
+        const int y = idx / res, x = idx - y * res;
+        int tex; double fx, fy;
+        oc_base(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, &tex, &fx, &fy);
+        pix[boff[tex] + atomicAdd(&cursor[tex], 1)] = (int)p;
     }
 }
-// active texel a -> (texel, first entry, entries) as one int4-sized record: the per-iteration kernels read them with one coalesced load
-__global__ void k_oc_active(const int* __restrict__ cnt, const int* __restrict__ off, const int* __restrict__ apos, int ntex,
-                            int4* __restrict__ act) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x)
-        if (cnt[t] > 0) act[apos[t]] = make_int4(t, off[t], cnt[t], 0);
-}
-
-// entries of one texel in ascending order (the cursor order above is a race): insertion sort, lists are short.  One wave owns 64
-// consecutive ACTIVE texels, whose lists are one contiguous CSR range staged through LDS; longer ranges are sorted in global memory.
+// pixels of one bucket in ascending order: insertion sort, buckets are short.  One wave owns 64 consecutive texels, whose buckets are
+// one contiguous range staged through LDS; longer ranges are sorted in global memory.
 #define OC_SORT_CAP 4096
-__global__ __launch_bounds__(64) void k_oc_sort(const int4* __restrict__ act, const int* __restrict__ nact, int* __restrict__ ent) {
+__global__ __launch_bounds__(64) void k_oc_sortb(const int* __restrict__ boff, int ntex, int* __restrict__ pix) {
     __shared__ int s_e[OC_SORT_CAP];
-    const int lane = threadIdx.x, na = *nact;
-    for (int a0 = blockIdx.x * 64; a0 < na; a0 += gridDim.x * 64) {
-        const int a = a0 + lane;
-        const int4 me = act[min(a, na - 1)], first = act[a0], lastr = act[min(a0 + 63, na - 1)];
-        const int b = me.y, n = a < na ? me.z : 0;
-        const int R0 = first.y, R1 = lastr.y + lastr.z, len = R1 - R0;
+    const int lane = threadIdx.x;
+    for (int t0 = blockIdx.x * 64; t0 < ntex; t0 += gridDim.x * 64) {
+        const int t = min(t0 + lane, ntex - 1);
+        const int b = boff[t], n = t0 + lane < ntex ? boff[t + 1] - b : 0;
+        const int R0 = boff[t0], R1 = boff[min(t0 + 64, ntex)], len = R1 - R0;
         if (len <= OC_SORT_CAP) {
-            for (int i = lane; i < len; i += 64) s_e[i] = ent[R0 + i];
+            for (int i = lane; i < len; i += 64) s_e[i] = pix[R0 + i];
             __syncthreads();
             const int lb = b - R0;
             for (int i = 1; i < n; ++i) {
@@ -219,17 +200,47 @@ __global__ __launch_bounds__(64) void k_oc_sort(const int4* __restrict__ act, co
                 s_e[lb + j + 1] = k;
             }
             __syncthreads();
-            for (int i = lane; i < len; i += 64) ent[R0 + i] = s_e[i];
+            for (int i = lane; i < len; i += 64) pix[R0 + i] = s_e[i];
             __syncthreads();
         } else {
             for (int i = 1; i < n; ++i) {
-                const int k = ent[b + i];
+                const int k = pix[b + i];
                 int j = i - 1;
-                while (j >= 0 && ent[b + j] > k) { ent[b + j + 1] = ent[b + j]; --j; }
-                ent[b + j + 1] = k;
+                while (j >= 0 && pix[b + j] > k) { pix[b + j + 1] = pix[b + j]; --j; }
+                pix[b + j + 1] = k;
             }
         }
     }
+}
+// sorted position i -> fractions, targets + base texel
+__global__ void k_oc_records(const int* __restrict__ pix, const int* __restrict__ npix, const float* __restrict__ uv_map,
+                             const float* __restrict__ target, int res, int A, float2* __restrict__ fxy, float4* __restrict__ tgt4) {
+    const int n = *npix;
+    const size_t plane = (size_t)res * res;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = pix[i];
+        const int v = (int)(p / plane), idx = (int)(p - (size_t)v * plane);
+        const int y = idx / res, x = idx - y * res;
+        int tex; double fx, fy;
+        oc_base(uv_map, ((size_t)v * res + (res - 1 - y)) * res + x, A, &tex, &fx, &fy);
+        fxy[i] = make_float2((float)fx, (float)fy);
+        const size_t o = (size_t)v * 3 * plane + idx;
+        tgt4[i] = make_float4(target[o], target[o + plane], target[o + 2 * plane], __int_as_float(tex));
+    }
+}
+// texels that receive a contribution (tools / tests: counters[1])
+__global__ void k_oc_nactive(const int* __restrict__ boff, int A, int ntex, int* __restrict__ nact) {
+    int c = 0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntex; t += gridDim.x * blockDim.x) {
+        const int x = t % A, y = t / A;
+        bool on = boff[t + 1] > boff[t];
+        if (x >= 1) on = on || boff[t] > boff[t - 1];
+        if (y >= 1) on = on || boff[t - A + 1] > boff[t - A];
+        if (x >= 1 && y >= 1) on = on || boff[t - A] > boff[t - A - 1];
+        c += on ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(nact, c);
 }
 
 // interleaved copy of the atlas being optimised (x, y, z = the three planes): the forward pass fetches a corner with one 16-byte
@@ -239,29 +250,38 @@ __global__ void k_oc_pack(const float* __restrict__ atlas, int ntex, float4* __r
         at4[t] = make_float4(atlas[t], atlas[(size_t)ntex + t], atlas[2 * (size_t)ntex + t], 0.f);
 }
 
-// forward: bilinear lookup (f64), clamp, sign of the L1 residual per channel (0 where the clamp or the residual kills the gradient)
-__global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ at4, int A, OcRec* __restrict__ rec,
+// forward: bilinear lookup (f64), clamp, sign of the L1 residual per channel (0 where the clamp or the residual kills the gradient).
+// sign byte: 2 bits per channel, code = sign + 1.  A thread takes OC_FW_PX consecutive pixels (sorted by base texel: its gathers and
+// its neighbours' hit the same lines) and stores their sign bytes as one word.
+#define OC_FW_PX 4
+__global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ at4, int A, const float2* __restrict__ fxy,
                                                     const float4* __restrict__ tgt4, const int* __restrict__ npix,
-                                                    const int* __restrict__ pix_of, int res, float* __restrict__ images) {
+                                                    uint8_t* __restrict__ sgn, const int* __restrict__ pix_of, int res,
+                                                    float* __restrict__ images) {
     const int n = *npix;
-    const int stride = gridDim.x * blockDim.x;
-    // two records per thread and trip: both records' streams and all eight corner gathers are requested before the first is used
-    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 2 * stride) {
-        OcRec r[2]; float4 tg[2]; int tex[2][4]; double wt[2][4]; bool ok[2][4]; float4 cor[2][4];
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * OC_FW_PX; i0 < n; i0 += gridDim.x * blockDim.x * OC_FW_PX) {
+        float2 f[OC_FW_PX]; float4 tg[OC_FW_PX]; int tex[OC_FW_PX][4]; double wt[OC_FW_PX][4]; bool ok[OC_FW_PX][4]; float4 cor[OC_FW_PX][4];
+        // (the arrays are padded to a multiple of OC_FW_PX records: the vector loads below stay inside the allocation)
+        {
+            const float4 a = reinterpret_cast<const float4*>(fxy + i0)[0], b = reinterpret_cast<const float4*>(fxy + i0)[1];
+            f[0] = make_float2(a.x, a.y); f[1] = make_float2(a.z, a.w); f[2] = make_float2(b.x, b.y); f[3] = make_float2(b.z, b.w);
+        }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { const int i = min(i0 + q * stride, n - 1); r[q] = rec[i]; tg[q] = tgt4[i]; }
+        for (int q = 0; q < OC_FW_PX; ++q) tg[q] = tgt4[i0 + q];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < OC_FW_PX; ++q) {
+            const int tb = i0 + q < n ? __float_as_int(tg[q].w) : 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                ok[q][c] = oc_corner(r[q].tex, (double)r[q].fx, (double)r[q].fy, A, c, &tex[q][c], &wt[q][c]);
-                cor[q][c] = at4[ok[q][c] ? tex[q][c] : r[q].tex];
+                ok[q][c] = oc_corner(tb, (double)f[q].x, (double)f[q].y, A, c, &tex[q][c], &wt[q][c]);
+                cor[q][c] = at4[ok[q][c] ? tex[q][c] : tb];
             }
+        }
+        unsigned word = 0;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int i = i0 + q * stride;
-            if (i >= n) break;
-            char4 sg = make_char4(0, 0, 0, 0);
+        for (int q = 0; q < OC_FW_PX; ++q) {
+            const int i = i0 + q;
+            unsigned code = 0;
             float im[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -272,11 +292,11 @@ __global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ a
                 const double img = fmin(fmax(val, 0.0), 1.0);
                 im[c] = (float)img;
                 const double d = img - (double)(c == 0 ? tg[q].x : (c == 1 ? tg[q].y : tg[q].z));
-                const signed char sc = (!pass || d == 0.0) ? 0 : (d > 0.0 ? 1 : -1);
-                if (c == 0) sg.x = sc; else if (c == 1) sg.y = sc; else sg.z = sc;
+                const unsigned sc = (!pass || d == 0.0) ? 1u : (d > 0.0 ? 2u : 0u);
+                code |= sc << (2 * c);
             }
-            rec[i].sgn = sg;
-            if (images) {                                                   // last iteration: the final render (masked-out pixels stay 0)
+            word |= code << (8 * q);
+            if (images && i < n) {                                          // last iteration: the final render (masked-out pixels stay 0)
                 const int p = pix_of[i];
                 const size_t plane = (size_t)res * res;
                 const int v = (int)(p / plane);
@@ -284,65 +304,83 @@ __global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ a
                 images[o] = im[0]; images[o + plane] = im[1]; images[o + 2 * plane] = im[2];
             }
         }
+        *reinterpret_cast<unsigned*>(sgn + i0) = word;
     }
 }
 
-// backward + torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay; single-tensor update order), per ACTIVE texel.
-// One wave owns 64 consecutive active texels = one contiguous CSR range.  The range is streamed through LDS in chunks: 64 lanes load
-// entries coalesced and gather the pixels' records with 64 independent 16-byte requests in flight (sign + the fractions the f64
-// weight is recomputed from), then every lane adds the entries of its own list that fall into the chunk, in list order.
+// backward + torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay; single-tensor update order).  One wave owns the 64
+// consecutive texels [t0, t0 + 64).  Lane t sums, in this order: bucket t - A - 1 (corner 3), bucket t - A (corner 2) -- the TOP range,
+// buckets [t0 - A - 1, t0 - A + 63] of the wave -- then bucket t - 1 (corner 1) and bucket t (corner 0) -- the CURRENT range
+// [t0 - 1, t0 + 63]; a corner is skipped where the reference's border rule drops it (x0 + 1 == A, y0 + 1 == A).  Each range is one
+// contiguous run of the sorted pixel arrays, streamed through LDS in chunks: 64 lanes load fractions and sign bytes coalesced, then
+// every lane adds the pixels of its own two buckets that fall into the chunk, in sorted order.
 #define OC_BW_CHUNK 512
-#define OC_BW_U (OC_BW_CHUNK / 64)
-__global__ __launch_bounds__(64) void k_oc_backward_adam(const int4* __restrict__ act, const int* __restrict__ nact,
-                                                         const int* __restrict__ ent, const OcRec* __restrict__ rec, double inv_count,
-                                                         float* __restrict__ param, float* __restrict__ m, float* __restrict__ vv,
-                                                         int ntex, float step_size, float bc2_sqrt, float4* __restrict__ at4) {
-    __shared__ double sw[OC_BW_CHUNK];                         // one wave per workgroup: the barriers below are wave-local
-    __shared__ char4 ss[OC_BW_CHUNK];
-    const int lane = threadIdx.x, na = *nact;
-    for (int a0 = blockIdx.x * 64; a0 < na; a0 += gridDim.x * 64) {
-        const int a = a0 + lane;
-        const int4 me = act[min(a, na - 1)], first = act[a0], lastr = act[min(a0 + 63, na - 1)];
-        const int t = me.x, b = me.y, n = a < na ? me.z : 0;
-        const int R0 = first.y, R1 = lastr.y + lastr.z;
+__global__ __launch_bounds__(64) void k_oc_backward_adam(const int* __restrict__ boff, int A, int ntex, const float2* __restrict__ fxy,
+                                                         const uint8_t* __restrict__ sgn, double inv_count, float* __restrict__ param,
+                                                         float* __restrict__ m, float* __restrict__ vv, float step_size, float bc2_sqrt,
+                                                         float4* __restrict__ at4) {
+    __shared__ float2 sf[OC_BW_CHUNK];                         // one wave per workgroup: the barriers below are wave-local
+    __shared__ uint8_t ss[OC_BW_CHUNK];
+    const int lane = threadIdx.x;
+    for (int t0 = blockIdx.x * 64; t0 < ntex; t0 += gridDim.x * 64) {
+        const int t = t0 + lane;
+        const bool in = t < ntex;
+        const int tc = in ? t : ntex - 1;
+        const int x = tc % A, y = tc / A;
+        // lane spans [lo, hi) with a split: below the split the pixels contribute their odd corner (1 / 3: bucket one texel to the left)
+        int lo[2], sp[2], hi[2];                                // [0] = top range, [1] = current range
+        {
+            const int bt = boff[tc], bt1 = boff[tc + 1];
+            sp[1] = bt; hi[1] = in ? bt1 : bt; lo[1] = (in && x >= 1) ? boff[tc - 1] : bt;
+            if (in && y >= 1) {
+                const int u = tc - A;
+                const int bu = boff[u], bu1 = boff[u + 1];
+                sp[0] = bu; hi[0] = bu1; lo[0] = x >= 1 ? boff[u - 1] : bu;
+            } else { lo[0] = sp[0] = hi[0] = 0; }
+        }
+        const bool any = hi[0] > lo[0] || hi[1] > lo[1];
+        if (!__any(any)) continue;
         // the optimiser state of this lane's texel: requested now, used after the gradient is summed
-        float pm[3], pv[3], pp[3];
+        float pm[3] = {0.f, 0.f, 0.f}, pv[3] = {0.f, 0.f, 0.f}, pp[3] = {0.f, 0.f, 0.f};
+        if (any) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const size_t i = (size_t)c * ntex + t;
-            pm[c] = m[i]; pv[c] = vv[i]; pp[c] = param[i];
+            for (int c = 0; c < 3; ++c) {
+                const size_t i = (size_t)c * ntex + t;
+                pm[c] = m[i]; pv[c] = vv[i]; pp[c] = param[i];
+            }
         }
         double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-        int cur = b;
-        const int e = b + n;
-        for (int c0 = R0; c0 < R1; c0 += OC_BW_CHUNK) {
-            const int len = min(OC_BW_CHUNK, R1 - c0);
-            // a chunk = OC_BW_U entries per lane: all entry loads, then all record gathers in flight together (the staging loop used
-            // to be a chain of dependent round trips, one entry per lane at a time)
-            int en[OC_BW_U];
-            OcRec rr[OC_BW_U];
 #pragma unroll
-            for (int u = 0; u < OC_BW_U; ++u) { const int i = u * 64 + lane; en[u] = i < len ? ent[c0 + i] : 0; }
-#pragma unroll
-            for (int u = 0; u < OC_BW_U; ++u) rr[u] = rec[en[u] >> 2];
-#pragma unroll
-            for (int u = 0; u < OC_BW_U; ++u) {
-                const int i = u * 64 + lane;
-                const double fx = (double)rr[u].fx, fy = (double)rr[u].fy;
-                const int c = en[u] & 3;
-                sw[i] = (c & 1 ? fx : 1.0 - fx) * (c & 2 ? fy : 1.0 - fy);
-                ss[i] = rr[u].sgn;
+        for (int rg = 0; rg < 2; ++rg) {
+            // the wave's range: from the first lane's lower bound to the last lane's upper bound (uniform)
+            int R0, R1;
+            if (rg == 0) {
+                if (t0 + 63 < A) continue;                      // no lane has a row above
+                const int ua = max(t0 - A - 1, 0), ub = min(t0 - A + 64, ntex);
+                R0 = boff[ua]; R1 = boff[max(ub, 0)];
+            } else {
+                R0 = boff[max(t0 - 1, 0)]; R1 = boff[min(t0 + 64, ntex)];
             }
-            __syncthreads();
-            const int stop = min(e, c0 + len);
-            for (; cur < stop; ++cur) {
-                const char4 sg = ss[cur - c0];
-                const double wi = sw[cur - c0] * inv_count;                 // = w * (+-1/count), as the scatter form adds it
-                g0 += wi * (double)sg.x; g1 += wi * (double)sg.y; g2 += wi * (double)sg.z;
+            int cur = lo[rg];
+            const int e = hi[rg], split = sp[rg];
+            const int c_lo = rg == 0 ? 3 : 1, c_hi = rg == 0 ? 2 : 0;
+            for (int c0 = R0; c0 < R1; c0 += OC_BW_CHUNK) {
+                const int len = min(OC_BW_CHUNK, R1 - c0);
+                for (int i = lane; i < len; i += 64) { sf[i] = fxy[c0 + i]; ss[i] = sgn[c0 + i]; }
+                __syncthreads();
+                const int stop = min(e, c0 + len);
+                for (cur = max(cur, min(c0, e)); cur < stop; ++cur) {
+                    const float2 f = sf[cur - c0];
+                    const unsigned code = ss[cur - c0];
+                    const int c = cur < split ? c_lo : c_hi;
+                    const double fx = (double)f.x, fy = (double)f.y;
+                    const double wi = ((c & 1 ? fx : 1.0 - fx) * (c & 2 ? fy : 1.0 - fy)) * inv_count;   // = w * (+-1/count), as the scatter form adds it
+                    g0 += wi * (double)((int)(code & 3u) - 1); g1 += wi * (double)((int)((code >> 2) & 3u) - 1); g2 += wi * (double)((int)((code >> 4) & 3u) - 1);
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
-        if (a < na) {
+        if (any) {
             const double gs[3] = {g0, g1, g2};
             float np[3];
 #pragma unroll
@@ -364,9 +402,10 @@ __global__ __launch_bounds__(64) void k_oc_backward_adam(const int4* __restrict_
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t pdhip_optimize_color_ws_bytes(int V, int res, int A) {
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
-    return a256(px * 3 * 4) /*target*/ + a256(px) /*wmask*/ + 2 * a256(px * 4) /*flags -> cid_of, pix_of*/ + 2 * a256(px * 16) /*records, targets*/ +
-           2 * a256(tx * 3 * 4) /*m, v*/ + 5 * a256((tx + 4096) * 4) /*cnt, off, cursor, apos, flags*/ + a256((tx + 4096) * 16) /*active texels*/ + a256(16384 * 4) /*block sums*/ +
-           a256(px * 4 * 4) /*entries*/ + a256(tx * 16) /*interleaved atlas*/ + 256 /*counters*/;
+    return a256(px * 3 * 4) /*target*/ + a256(px) /*wmask*/ + a256((px + 64) * 4) /*sorted pixel ids*/ + a256((px + 64) * 8) /*fractions*/ +
+           a256((px + 64) * 16) /*targets + base texel*/ + a256(px + 64) /*sign bytes*/ + 2 * a256(tx * 3 * 4) /*m, v*/ +
+           3 * a256((tx + 4096) * 4) /*bucket counts, offsets, cursor*/ + a256(16384 * 4) /*block sums*/ + a256(tx * 16) /*interleaved atlas*/ +
+           256 /*counters*/;
 }
 
 extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, const float* uv_map, const int64_t* face_idxs, int V,
@@ -374,61 +413,59 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
                                     float* final_images /*[V,3,res,res] or NULL*/, void* ws, void* stream) {
     PD_REQUIRE(atlas && uv_map && face_idxs && inpainted && ws && A > 0 && V > 0 && res > 0 && r > 0 && iterations >= 0,
                "pdhip_optimize_color: bad arguments");
-    PD_REQUIRE((long long)A * A <= 4096LL * 1024 && (long long)V * res * res <= (long long)OC_SCAN_MAXB * OC_SCAN_BLK,
-               "pdhip_optimize_color: atlas / view size too large (A^2 <= 4 Mi texels, V res^2 <= 64 Mi pixels)");
+    PD_REQUIRE((long long)A * A <= 4096LL * 1024 && (long long)V * res * res <= (1LL << 30),
+               "pdhip_optimize_color: atlas / view size too large (A^2 <= 4 Mi texels, V res^2 <= 1 Gi pixels)");
     hipStream_t s = as_stream(stream);
     const size_t px = (size_t)V * res * res, tx = (size_t)A * A;
     char* p = reinterpret_cast<char*>(ws);
     float* target = reinterpret_cast<float*>(p); p += a256(px * 3 * 4);
     uint8_t* wmask = reinterpret_cast<uint8_t*>(p); p += a256(px);
-    int* cid_of = reinterpret_cast<int*>(p); p += a256(px * 4);
-    int* pix_of = reinterpret_cast<int*>(p); p += a256(px * 4);
-    OcRec* rec = reinterpret_cast<OcRec*>(p); p += a256(px * 16);
-    float4* tgt4 = reinterpret_cast<float4*>(p); p += a256(px * 16);
+    int* pix = reinterpret_cast<int*>(p); p += a256((px + 64) * 4);
+    float2* fxy = reinterpret_cast<float2*>(p); p += a256((px + 64) * 8);
+    float4* tgt4 = reinterpret_cast<float4*>(p); p += a256((px + 64) * 16);
+    uint8_t* sgn = reinterpret_cast<uint8_t*>(p); p += a256(px + 64);
     float* m = reinterpret_cast<float*>(p); p += a256(tx * 3 * 4);
     float* vv = reinterpret_cast<float*>(p); p += a256(tx * 3 * 4);
-    int* cnt = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
-    int* off = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
+    int* cntb = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
+    int* boff = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
     int* cursor = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
-    int* apos = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
-    int* aflag = reinterpret_cast<int*>(p); p += a256((tx + 4096) * 4);
-    int4* act = reinterpret_cast<int4*>(p); p += a256((tx + 4096) * 16);
     int* bsum = reinterpret_cast<int*>(p); p += a256(16384 * 4);
-    int* ent = reinterpret_cast<int*>(p); p += a256(px * 4 * 4);
     float4* at4 = reinterpret_cast<float4*>(p); p += a256(tx * 16);
-    int* npix = reinterpret_cast<int*>(p);                   // [0] masked pixels, [1] active texels
+    int* npix = reinterpret_cast<int*>(p);                   // [0] masked pixels, [1] texels that receive a contribution
     int* nact = npix + 1;
     const long long n = 3LL * A * A;
     PD_HIP(hipMemsetAsync(m, 0, n * 4, s));
     PD_HIP(hipMemsetAsync(vv, 0, n * 4, s));
-    PD_HIP(hipMemsetAsync(cnt, 0, tx * 4, s));
+    PD_HIP(hipMemsetAsync(cntb, 0, tx * 4, s));
     PD_HIP(hipMemsetAsync(cursor, 0, tx * 4, s));
+    PD_HIP(hipMemsetAsync(npix, 0, 8, s));
     if (final_images != nullptr) PD_HIP(hipMemsetAsync(final_images, 0, px * 3 * 4, s));
     dim3 g(min(cdiv((long long)res * res, 256), 2048), V);
     k_optcolor_target<<<g, 256, 0, s>>>(inpainted, r, uv_map, face_idxs, res, shrinked, A, target, wmask);
     const int gp = min(cdiv((long long)px, 256), 8192);
     const int gt = min(cdiv((long long)tx, 256), 4096);
-    // masked pixels -> compact records (pixel order); texel contribution counts -> CSR offsets; active texels
-    k_oc_flags<<<gp, 256, 0, s>>>(wmask, (long long)px, pix_of);
-    OC_TRY(oc_scan(pix_of, (int)px, cid_of, bsum, npix, s));
-    k_oc_records<<<gp, 256, 0, s>>>(uv_map, wmask, cid_of, target, V, res, A, rec, tgt4, pix_of, cnt);
-    OC_TRY(oc_scan(cnt, (int)tx, off, bsum, nullptr, s));
-    k_oc_flags_pos<<<gt, 256, 0, s>>>(cnt, (int)tx, aflag);
-    OC_TRY(oc_scan(aflag, (int)tx, apos, bsum, nact, s));
-    k_oc_active<<<gt, 256, 0, s>>>(cnt, off, apos, (int)tx, act);
-    k_oc_fill<<<gp, 256, 0, s>>>(rec, npix, A, off, cursor, ent);
+    // masked pixels -> buckets by base texel (counting sort, ascending pixel index inside a bucket) -> per-pixel arrays in that order
+    k_oc_count<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, cntb);
+    OC_TRY(oc_scan(cntb, (int)tx, boff, bsum, npix, s));
+    PD_HIP(hipMemcpyAsync(boff + tx, npix, 4, hipMemcpyDeviceToDevice, s));
+    k_oc_scatter<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, boff, cursor, pix);
     const int gw = min(cdiv((long long)tx, 64), 16384);
-    k_oc_sort<<<gw, 64, 0, s>>>(act, nact, ent);
+    k_oc_sortb<<<gw, 64, 0, s>>>(boff, (int)tx, pix);
+    // (the forward pass reads whole groups of OC_FW_PX records: the tail group's padding must be finite and in range)
+    PD_HIP(hipMemsetAsync(fxy, 0, (px + 64) * 8, s));
+    PD_HIP(hipMemsetAsync(tgt4, 0, (px + 64) * 16, s));
+    k_oc_records<<<gp, 256, 0, s>>>(pix, npix, uv_map, target, res, A, fxy, tgt4);
+    k_oc_nactive<<<gt, 256, 0, s>>>(boff, A, (int)tx, nact);
     k_oc_pack<<<gt, 256, 0, s>>>(atlas, (int)tx, at4);
     const double inv_count = 1.0 / ((double)V * 3.0 * res * res);
+    const int gf = min(cdiv((long long)px, 256 * OC_FW_PX), 8192);
     for (int it = 0; it < iterations; ++it) {
         const bool last = it == iterations - 1;
-        k_oc_forward<<<gp, 256, 0, s>>>(at4, A, rec, tgt4, npix, pix_of, res, last ? final_images : nullptr);
+        k_oc_forward<<<gf, 256, 0, s>>>(at4, A, fxy, tgt4, npix, sgn, pix, res, last ? final_images : nullptr);
         const int step = it + 1;
         const double cur_lr = lr * pow(0.5, (double)(it / 15));            // StepLR(step_size 15, gamma 0.5)
         const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
-        k_oc_backward_adam<<<gw, 64, 0, s>>>(act, nact, ent, rec, inv_count, atlas, m, vv, (int)tx, (float)(cur_lr / bc1),
-                                             (float)sqrt(bc2), at4);
+        k_oc_backward_adam<<<gw, 64, 0, s>>>(boff, A, (int)tx, fxy, sgn, inv_count, atlas, m, vv, (float)(cur_lr / bc1), (float)sqrt(bc2), at4);
     }
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

@@ -167,8 +167,13 @@ def refine_point_validation(cam_RTs, cam_K, res, hard_masks, point_validation, p
     pix_h, val_h, fg_h = pix.cpu().numpy(), point_validation.cpu().numpy().astype(bool), fg.cpu().numpy()
     sparse = np.full((V, res, res), -100.0, dtype=np.float32)
     for i in range(V):
-        rc = pix_h[i][val_h[i]]
-        sparse[i][rc[:, 0], rc[:, 1]] = zs_h[i][val_h[i]]                       # duplicates: last point wins
+        rc, zv = pix_h[i][val_h[i]], zs_h[i][val_h[i]]
+        # duplicates: the LAST point in point order wins, made explicit (numpy leaves the winner of a repeated fancy index unspecified):
+        # first occurrence in the reversed order = last occurrence
+        lin = rc[:, 0].astype(np.int64) * res + rc[:, 1]
+        _, first_rev = np.unique(lin[::-1], return_index=True)
+        keep = len(lin) - 1 - first_rev
+        sparse[i].reshape(-1)[lin[keep]] = zv[keep]
     sp = torch.from_numpy(sparse).to(dev)
     dense = nearest_fill(sp[:, None], sp != -100.0, 'CHW')[:, 0].cpu().numpy()  # naive_inpainting(method='nearest') per view
     new_val = val_h.copy()
@@ -230,6 +235,9 @@ def nearest_fill(img, site_mask, layout='CHW'):
         B, H, W, Cn = img.shape
         bs, cs, ps = H * W * Cn, 1, Cn
     site_mask = site_mask.contiguous()
+    # the mask is read plane 0 of image b at b * mstride: [B,H,W] or [B,K,H,W] only (a [B,H,W,1] mask would be read with the wrong stride)
+    if site_mask.dim() not in (3, 4) or site_mask.shape[0] != B or tuple(site_mask.shape[-2:]) != (H, W):
+        raise _lib.PdhipError(f"site mask must be [B,H,W] or [B,K,H,W] with B={B}, H={H}, W={W} (got {tuple(site_mask.shape)})")
     mstride = H * W * (site_mask.shape[1] if site_mask.dim() == 4 else 1)
     is_f32 = 1 if site_mask.dtype == torch.float32 else 0
     if not is_f32:

@@ -193,6 +193,40 @@ def test_attention_online_softmax_rescale_branch(nn):
     assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("T,peak", [(4096, 0.0), (4096, 5.0)])
+def test_attention_long_sequence_denominator(nn, T, peak):
+    """The T >= 128 kernel takes the softmax denominator from the matrix pipe over the f16-ROUNDED probabilities (the reference,
+    unet.py:336-352 QKVAttentionLegacy, normalises in fp32 and rounds afterwards).  A sequence four times the longest of the network,
+    flat logits (4 096 nearly equal weights of 2^-12: every rounding enters the normaliser) and sharply peaked ones (one key per
+    query carries most of the mass, the rest underflow towards f16 zero) against the f64 oracle, the short sequences' 5e-3 bound;
+    both kernels (LDS-transposed V with a workspace handle, and the generic one)."""
+    L = nn['L']
+    N, Cc, D = 1, 512, 64
+    heads = Cc // D
+    g = torch.Generator().manual_seed(T + int(peak * 10))
+    qkv = torch.randn((N, 3 * Cc, T), generator=g) * (0.05 if peak == 0.0 else 1.0)
+    if peak > 0:                                            # key (7 t + 3) % T is aligned with query t in every head
+        idx = (7 * torch.arange(T) + 3) % T
+        for h in range(heads):
+            qkv[0, h * 3 * D + D:h * 3 * D + 2 * D, idx] = qkv[0, h * 3 * D:h * 3 * D + D, :] * peak
+    qkv = qkv.half().float()
+    ref = torch.empty((N, Cc, T))
+    for h in range(heads):
+        q, k, v = qkv[0, h * 3 * D:(h + 1) * 3 * D].double().split(D, dim=0)
+        w = torch.softmax((q.t() @ k) / math.sqrt(D), dim=-1)
+        if peak >= 5.0:
+            assert w.max(-1).values.median() > 0.5
+        ref[0, h * D:(h + 1) * D] = (w @ v.t()).t().float()
+    qd = qkv.permute(0, 2, 1).contiguous().half().to(DEV)
+    vt = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
+    for ws in (vt, None):
+        out = torch.zeros((N, T, Cc), dtype=torch.float16, device=DEV)
+        assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _ptr(ws), _stream()) == 0, L.pdhip_last_error()
+        o = out.float().cpu().permute(0, 2, 1)
+        assert torch.isfinite(o).all()
+        assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
+
+
 def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).norm() / b.norm()).item()
 
