@@ -239,8 +239,11 @@ __global__ void k_oc_nactive(const int* __restrict__ boff, int A, int ntex, int*
         if (x >= 1 && y >= 1) on = on || boff[t - A] > boff[t - A - 1];
         c += on ? 1 : 0;
     }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(nact, c);
+    __shared__ int s_c[256];
+    s_c[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) s_c[threadIdx.x] += s_c[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && s_c[0]) atomicAdd(nact, s_c[0]);              // (one atomic per block; integer sum: any order)
 }
 
 // interleaved copy of the atlas being optimised (x, y, z = the three planes): the forward pass fetches a corner with one 16-byte
@@ -455,7 +458,7 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
     PD_HIP(hipMemsetAsync(fxy, 0, (px + 64) * 8, s));
     PD_HIP(hipMemsetAsync(tgt4, 0, (px + 64) * 16, s));
     k_oc_records<<<gp, 256, 0, s>>>(pix, npix, uv_map, target, res, A, fxy, tgt4);
-    k_oc_nactive<<<gt, 256, 0, s>>>(boff, A, (int)tx, nact);
+    k_oc_nactive<<<min(gt, 256), 256, 0, s>>>(boff, A, (int)tx, nact);
     k_oc_pack<<<gt, 256, 0, s>>>(atlas, (int)tx, at4);
     const double inv_count = 1.0 / ((double)V * 3.0 * res * res);
     const int gf = min(cdiv((long long)px, 256 * OC_FW_PX), 8192);

@@ -221,7 +221,7 @@ def test_attention_long_sequence_denominator(nn, T, peak):
     vt = torch.empty((N, T, Cc), dtype=torch.float16, device=DEV)
     for ws in (vt, None):
         out = torch.zeros((N, T, Cc), dtype=torch.float16, device=DEV)
-        assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, _ptr(ws), _stream()) == 0, L.pdhip_last_error()
+        assert L.pdhip_attention_f16(_ptr(qd), _ptr(out), N, T, Cc, D, None if ws is None else _ptr(ws), _stream()) == 0, L.pdhip_last_error()
         o = out.float().cpu().permute(0, 2, 1)
         assert torch.isfinite(o).all()
         assert (o - ref).abs().max().item() <= 5e-3 * max(1.0, ref.abs().max().item())
