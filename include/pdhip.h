@@ -271,6 +271,7 @@ int pdhip_gn_silu_conv3x3_nhwc_f16(const void* x, const float* gamma, const floa
                                    long long ws_floats, void* stream);
 int pdhip_debug_conv3x3_apply(const void* x, const float* table /*[N][Cin/8][16]*/, const void* w_packed, const float* bias, const void* residual,
                               void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, const void* zero_page, void* stream);   /* tuning hook */
+int pdhip_debug_set_fold_skip(int on);   /* 1 (default): in the small-M layers a channel-changing ResBlock's skip 1x1 conv (unet.py:206-209, 255) is appended to conv2's K loop (k_conv_sk<10>: out = W2 im2col(h) + Wskip x + (b2 + bskip), one launch and one rounding); 0: its own launch + a residual read; returns the previous value */
 int pdhip_debug_set_fold_resample(int on);   /* 1 (default): the resampled x branch of up / down ResBlocks is folded into its consumers; 0: k_resample passes */
 int pdhip_debug_set_fold_finalize(int max_batch);   /* largest UNet batch at which GroupNorm-apply reduces the conv epilogues' statistics partials itself (no k_gn_finalize_oct launch); default 8, 0 = never */
 int pdhip_debug_set_fold_finalize_chunks(int chunks);   /* above that batch the in-kernel statistics are kept for tensors whose producers left at most this many chunks per image (default 16; 0 = batch rule only); returns the previous value */

@@ -27,7 +27,7 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s);
 extern thread_local int g_force_bk, g_force_stages, g_force_wmw, g_force_splits;     // tuning hooks (nn_gemm.hip)
-extern thread_local int g_fuse_gn, g_fold_resample, g_fold_finalize, g_fuse_skip;                                                   // tuning hook (nn_unet.hip)
+extern thread_local int g_fuse_gn, g_fold_resample, g_fold_finalize, g_fuse_skip, g_fold_skip;                                                   // tuning hook (nn_unet.hip)
 extern thread_local float* g_dbg_splitk_ws; extern thread_local size_t g_dbg_splitk_floats;
 int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
                int W, int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s,
@@ -39,7 +39,14 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
 // ---- small-M convolution with in-launch split-K combine (nn_conv_sk.hip).  ws: [0, 4096) ticket words (zero at allocation,
 // self-resetting), slabs behind them.  conv_sk_plan decides whether / how a layer runs there (bm == 0: not this kernel's layer).
 struct SkPlan { int bm, bn, splits, tile_id; };
-SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, bool two_source, size_t ws_floats);
+SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, bool two_source, size_t ws_floats, int k_extra = 0);
+// 3x3 conv + the ResBlock's skip 1x1 over the block input xs = [XS (Cs1 channels) | XS2 (Cs - Cs1), may be null] as ONE K loop
+// (out = W2 * im2col(X) + Wskip * xs + (b2 + bskip): unet.py:255); Wt [Cout_pad][9 Cin + Cs] and bias from fuse_skip_weights
+int conv_sk_skip(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, half_t* Y, int N, int H, int W, int Cin, int Cout,
+                 int Cout_pad, const half_t* XS, const half_t* XS2, int Cs1, int Cs, const half_t* zero_page, hipStream_t s, float* ws,
+                 size_t ws_floats, float* gn_part, int* gn_fused);
+int fuse_skip_weights(const half_t* w3, int K9, const half_t* w1, int Cs, int Cout_pad, const float* b3, const float* b1, int Cout, half_t* dst,
+                      float* bdst, hipStream_t s);
 int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
             int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* ws, size_t ws_floats, float* gn_part,
             int* gn_fused, const half_t* X2, int Cin1);

@@ -69,7 +69,14 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
                                                       const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int W, int Cin,
                                                       int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
-                                                      const half_t* __restrict__ X2, int Cin1, int m_fast) {
+                                                      const half_t* __restrict__ X2, int Cin1, int m_fast,
+                                                      const half_t* __restrict__ XS, const half_t* __restrict__ XS2, int Cs1, int Cskip) {
+    // TAPS == 10 (round 4): a 3x3 conv with the ResBlock's skip 1x1 conv appended to its K loop -- out = W2 * im2col(h) + Wskip * x
+    // (unet.py:255 `return self.skip_connection(x) + h`): nine taps over X (Cin channels) and a tenth, centre-only "tap" over the
+    // block input x = [XS (Cs1 channels) | XS2 (Cskip - Cs1)] (a never-materialised concat, XS2 may be null); weights
+    // [Cout_pad][9 Cin + Cskip], bias = b2 + bskip.  One launch and one rounding instead of conv -> f16 -> + f16(skip conv).
+    constexpr bool SKIPK = TAPS == 10;
+    constexpr int XT = SKIPK ? 9 : TAPS;                // taps over X
     constexpr int ROWB = 128, RPI = 8;                 // bytes per tile row (K-step 64), rows per 1 KiB wave-instruction
     constexpr int LPO = BM / 32, LPB = BN / 32;        // LDS-DMA pieces per wave per K-step: activation rows, weight rows
     constexpr int OPS = LPO + LPB;
@@ -105,9 +112,9 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     const int m_tiles = total_tiles / n_tiles;
     const int m0 = (m_fast ? tile % m_tiles : tile / n_tiles) * BM, n0 = (m_fast ? tile / m_tiles : tile % n_tiles) * BN;
     const int M = N * H * W, HWp = H * W;              // (host: M < 2^31)
-    const int K = TAPS * Cin;
+    const int K = XT * Cin + (SKIPK ? Cskip : 0);
     const int kc = Cin >> 6;                           // K-steps per tap
-    const int KI = TAPS * kc;
+    const int KI = XT * kc + (SKIPK ? (Cskip >> 6) : 0);
 
     // ---- loader role: lane stages 16-byte slot (lane % 8) of row (lane / 8) of each of its pieces.  Source addresses are formed
     // from (tap, channel chunk) at every issue, branch-free: per piece a base pointer and a 9-bit "tap inside the image" mask,
@@ -117,6 +124,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     const half_t* abase[LPO];
     const half_t* abase2[LPO];
     unsigned amask[LPO];
+    unsigned apix[LPO];                                 // (SKIPK) pixel index of the row: the skip source's address is formed at issue
     const half_t* bp[LPB];
 #pragma unroll
     for (int i = 0; i < LPO; ++i) {
@@ -137,8 +145,10 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
                 const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
                 if (inm && yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << t;
             }
+            if (SKIPK && inm) msk |= 1u << 9;
         }
         amask[i] = msk;
+        apix[i] = mm;
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
@@ -154,13 +164,19 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     auto issue = [&](int stage, int it) {                 // all pieces of K-step `it` (wave-uniform) into `stage` of this group's ring
         const int tap = is_tap, nc = is_nc;
         is_nc += KG;
-        while (TAPS != 1 && is_nc >= kc) { is_nc -= kc; ++is_tap; }
+        while (TAPS != 1 && is_tap < XT && is_nc >= kc) { is_nc -= kc; ++is_tap; }
         const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
         const bool second = TAPS == 1 && X2 != nullptr && nc * 64 >= Cin1;
         const long long koff = second ? (long long)nc * 64 - Cin1 : ((long long)dy * W + dx) * Cin1 + (long long)nc * 64;
+        const bool skp = SKIPK && tap == 9;               // (wave-uniform) the appended 1x1 over the block input
+        const bool skp2 = skp && nc * 64 >= Cs1;
 #pragma unroll
         for (int p = 0; p < LPO; ++p) {
             const half_t* src = (second ? abase2[p] : abase[p]) + koff;
+            if (skp) {
+                const int cc = (lpos ^ sk_swz(w4 * (BM / 4) + p * RPI + lrow)) * 8;
+                src = skp2 ? XS2 + (size_t)apix[p] * (unsigned)(Cskip - Cs1) + (nc * 64 - Cs1) + cc : XS + (size_t)apix[p] * (unsigned)Cs1 + nc * 64 + cc;
+            }
             if (((amask[p] >> tap) & 1u) == 0u) src = zero_page + ((lpos ^ sk_swz(w4 * (BM / 4) + p * RPI + lrow)) * 8 & 63);
             sk_glds16(src, wave_dst_a + stage * STAGE_BYTES + p * 1024);
         }
@@ -180,7 +196,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
 
     // this group's K-steps: g0, g0 + KG, ...; `mine` of them.  Every group runs `iters` loop trips (the barrier counts must match).
     const int g0 = it0 + grp;
-    if (TAPS == 1) is_nc = g0; else { is_tap = g0 / kc; is_nc = g0 - is_tap * kc; }
+    if (TAPS == 1) is_nc = g0; else { is_tap = min(g0 / kc, XT); is_nc = g0 - is_tap * kc; }
     const int mine = g0 < it1 ? (it1 - g0 + KG - 1) / KG : 0;
     const int iters = (it1 - it0 + KG - 1) / KG;
     if (loader) {
@@ -427,12 +443,12 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
 template <int TAPS, int BM, int BN, int NST, int KG, bool LS = false>
 int launch_sk(int grid, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
               int W, int Cin, int Cout, int n_tiles, int total, const half_t* zero_page, int splits, float* slabs, unsigned* tickets,
-              float* gnp, const half_t* X2, int Cin1, int m_fast) {
+              float* gnp, const half_t* X2, int Cin1, int m_fast, const half_t* XS = nullptr, const half_t* XS2 = nullptr, int Cs1 = 0, int Cs = 0) {
     auto kern = k_conv_sk<TAPS, BM, BN, NST, KG, LS>;
     constexpr size_t smem = (size_t)KG * NST * (BM + BN) * 128 + 16;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast);
+    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast, XS, XS2, Cs1, Cs);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -456,12 +472,12 @@ thread_local int g_sk_order = 0;       // lab hook: tile order inside an XCD's r
 //   * otherwise 3x3 layers are split along K to ~256 workgroups: the largest tile that needs <= 4 slices, else the 64x32 tile with
 //     up to 8 (a tile's slabs are re-read by ONE workgroup: 16 x 8 KB slices cost more than the K loop they shorten);
 //   * 1x1 layers (K loops of 4-32 steps) never split: the combine costs more than their whole loop.
-SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, bool two_source, size_t ws_floats) {
+SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, bool two_source, size_t ws_floats, int k_extra) {
     SkPlan p{0, 0, 0, 0};
-    if (g_sk_mode == 0 || Cin % 64 != 0 || Cout % 8 != 0 || Cout_pad % 128 != 0) return p;
+    if (g_sk_mode == 0 || Cin % 64 != 0 || Cout % 8 != 0 || Cout_pad % 128 != 0 || k_extra % 64 != 0) return p;
     const long long M = (long long)N * H * W, hw = (long long)H * W;
     if (M >= (1LL << 31) / 2) return p;
-    const int KI = taps * (Cin / 64);
+    const int KI = taps * (Cin / 64) + k_extra / 64;      // (k_extra: channels of a skip 1x1 appended to the K loop, conv_sk_skip)
     static const int BMs[4] = {128, 128, 64, 64}, BNs[4] = {128, 64, 64, 32};
     long long tiles[4];
     bool ok[4];
@@ -481,7 +497,7 @@ SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
         if (taps == 9 && KI >= 128 && ok[0] && tiles[0] >= 112 && tiles[0] < 224) { pick = 0; ps = 2; }
         // (a weight-heavy layer re-reads its 19-38 MB of weights once per PIXEL tile: 64-row tiles double that traffic -- 39 us unsplit
         // on 64x32 tiles against 24 us on 128x64 tiles x 4 slices at the 8^2 level, batch 8)
-        const bool heavy = (size_t)Cout_pad * taps * Cin * 2 >= ((size_t)8 << 20) && M >= 256;
+        const bool heavy = (size_t)Cout_pad * ((size_t)taps * Cin + k_extra) * 2 >= ((size_t)8 << 20) && M >= 256;
         for (int t = 0; t < 4 && pick < 0; ++t)
             if (ok[t] && tiles[t] >= 224 && !(heavy && BMs[t] == 64 && (ok[0] || ok[1]))) { pick = t; ps = 1; }
         if (pick < 0 && taps == 9) {
@@ -560,6 +576,54 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
 #undef SK_L
 #undef SK_LS
 #undef SK_ARGS
+}
+
+// 3x3 conv (Cin -> Cout) + the ResBlock's skip 1x1 (Cs -> Cout over xs = [XS | XS2]) as ONE K loop; Wt [Cout_pad][9 Cin + Cs], bias summed.
+// The default tile configurations only (the lab hooks for stages / K-groups belong to conv_sk).
+int conv_sk_skip(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, half_t* Y, int N, int H, int W, int Cin, int Cout,
+                 int Cout_pad, const half_t* XS, const half_t* XS2, int Cs1, int Cs, const half_t* zero_page, hipStream_t s, float* ws,
+                 size_t ws_floats, float* gn_part, int* gn_fused) {
+    PD_REQUIRE(pl.bm > 0 && XS != nullptr && Cs > 0 && Cs % 64 == 0, "conv_sk_skip: no plan / bad skip source");
+    if (XS2 == nullptr) Cs1 = Cs;
+    PD_REQUIRE(XS2 == nullptr || (Cs1 % 64 == 0 && Cs1 > 0 && Cs1 < Cs), "conv_sk_skip: bad two-source split");
+    const long long M = (long long)N * H * W;
+    const int m_tiles = (int)((M + pl.bm - 1) / pl.bm), n_tiles = Cout_pad / pl.bn, total = m_tiles * n_tiles;
+    PD_REQUIRE(pl.splits == 1 || (ws != nullptr && (size_t)total * pl.splits * pl.bm * pl.bn + PD_SK_TICKET_FLOATS <= ws_floats && total <= 4096),
+               "conv_sk_skip: split-K workspace too small");
+    unsigned* tickets = reinterpret_cast<unsigned*>(ws);
+    float* slabs = ws ? ws + PD_SK_TICKET_FLOATS : nullptr;
+    if (gn_fused) *gn_fused = gn_part ? std::max((int)(((long long)H * W) / pl.bm), 1) : 0;
+    const int grid = total * pl.splits;
+    const int kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 8 : (pl.tile_id == 4 && (9 * (Cin / 64) + Cs / 64) / pl.splits >= 32) ? 4 : 2;
+#define SKS_ARGS grid, s, X, Wt, bias, nullptr, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, nullptr, Cin, 0, XS, XS2, Cs1, Cs
+    if (pl.tile_id == 1) return kg == 8 ? launch_sk<10, 128, 128, 3, 1, true>(SKS_ARGS) : kg == 1 ? launch_sk<10, 128, 128, 2, 1>(SKS_ARGS) : launch_sk<10, 128, 128, 2, 2>(SKS_ARGS);
+    if (pl.tile_id == 2) return kg == 1 ? launch_sk<10, 128, 64, 3, 1>(SKS_ARGS) : launch_sk<10, 128, 64, 3, 2>(SKS_ARGS);
+    if (pl.tile_id == 3) return kg == 1 ? launch_sk<10, 64, 64, 4, 1>(SKS_ARGS) : launch_sk<10, 64, 64, 4, 2>(SKS_ARGS);
+    return kg == 1 ? launch_sk<10, 64, 32, 4, 1>(SKS_ARGS) : kg == 4 ? launch_sk<10, 64, 32, 3, 4>(SKS_ARGS) : launch_sk<10, 64, 32, 4, 2>(SKS_ARGS);
+#undef SKS_ARGS
+}
+
+// fused weights of conv_sk_skip: dst [Cout_pad][K9 + Cs] = [w3 [Cout_pad][K9] | w1 [Cout_pad][Cs]], bias = b3 + b1
+__global__ void k_fuse_skip_weights(const half_t* __restrict__ w3, int K9, const half_t* __restrict__ w1, int Cs, int rows, half_t* __restrict__ dst) {
+    const int KT = (K9 + Cs) >> 3;
+    const long long total = (long long)rows * KT;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / KT), k8 = (int)(i - (long long)r * KT) * 8;
+        const half8 v = k8 < K9 ? *reinterpret_cast<const half8*>(w3 + (size_t)r * K9 + k8) : *reinterpret_cast<const half8*>(w1 + (size_t)r * Cs + (k8 - K9));
+        *reinterpret_cast<half8*>(dst + (size_t)r * (K9 + Cs) + k8) = v;
+    }
+}
+__global__ void k_add_bias(const float* __restrict__ a, const float* __restrict__ b, int n, float* __restrict__ o) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+int fuse_skip_weights(const half_t* w3, int K9, const half_t* w1, int Cs, int Cout_pad, const float* b3, const float* b1, int Cout, half_t* dst,
+                      float* bdst, hipStream_t s) {
+    PD_REQUIRE(K9 % 8 == 0 && Cs % 8 == 0, "fuse_skip_weights: K must be a multiple of 8");
+    k_fuse_skip_weights<<<(int)std::min<long long>(((long long)Cout_pad * ((K9 + Cs) >> 3) + 255) / 256, 8192), 256, 0, s>>>(w3, K9, w1, Cs, Cout_pad, dst);
+    k_add_bias<<<(Cout + 255) / 256, 256, 0, s>>>(b3, b1, Cout, bdst);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
 }
 
 }  // namespace pdnn

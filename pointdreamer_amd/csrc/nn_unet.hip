@@ -19,7 +19,8 @@ namespace {
 
 struct ConvW { half_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, cout_pad = 0, taps = 0; bool have_w = false, have_b = false; };
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; bool have_g = false, have_b = false; };
-struct ResB { std::string name; int cin, cout, mode; NormW n1, n2; ConvW c1, c2, skip; long long emb_off; bool has_skip; bool have_ew = false, have_eb = false; };
+struct ResB { std::string name; int cin, cout, mode; NormW n1, n2; ConvW c1, c2, skip; long long emb_off; bool has_skip; bool have_ew = false, have_eb = false;
+              half_t* c2s_w = nullptr; float* c2s_b = nullptr; bool c2s_ready = false; };   // conv2 with the skip 1x1 appended to its K loop (conv_sk_skip), built on first use
 struct AttB { std::string name; int c; NormW n; ConvW qkv, proj; };
 struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 
@@ -38,6 +39,9 @@ namespace pdnn { thread_local int g_fuse_gn = 0; }
 // k_resample pass: AvgPool2d(2) of the raw input comes out of the GroupNorm-apply kernel that reads the same pixels anyway, the
 // nearest x2 copy is replaced by index arithmetic in the residual read of the consuming conv (unsplit halo layers)
 namespace pdnn { thread_local int g_fold_resample = 1; }
+// tuning / test hook (pdhip_debug_set_fold_skip): 1 (default) = where a channel-changing ResBlock's conv2 runs in k_conv_sk (the small-M
+// layers) the block's skip 1x1 conv is appended to conv2's K loop (one launch, one rounding) instead of a launch of its own + a residual read
+namespace pdnn { thread_local int g_fold_skip = 1; }
 // tuning / test hook (pdhip_debug_set_fold_finalize): largest batch at which GroupNorm-apply reduces the conv epilogues' octet
 // partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never); above that batch the fold is kept for the
 // tensors whose producers left at most g_fold_finalize_chunks chunks per image (the 32^2 ... 8^2 levels: the re-reduction is a few
@@ -298,6 +302,30 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     }
     if (rb.mode != 0 && !c.dry && !fold_down && !fold_up) PD_TRY(resample2x(x.p, c.N, x.H, x.W, x.C, rb.mode, xr.p, c.s));
     if (!fuse_skip) sk = fold_up ? x : xr;
+    // small-M layers: the skip 1x1 rides in conv2's K loop (k_conv_sk<10, ..>): no launch of its own, no skip tensor, no residual read
+    if (rb.has_skip && !fuse_skip && !c.dry && g_fold_skip != 0 && rb.mode == 0 && rb.c2s_w != nullptr && rb.skip.taps == 1 &&
+        (x.p2 == nullptr || (x.Ca % 64 == 0 && (x.C - x.Ca) % 64 == 0)) &&
+        !conv_uses_halo(c.N, h1.H, h1.W, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) && !can_fuse_gn(c, h1, rb.c2)) {
+        const SkPlan pl = conv_sk_plan(c.N, h1.H, h1.W, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, false, c.u->splitk_floats, rb.skip.cin);
+        if (pl.bm > 0) {
+            PD_REQUIRE(rb.c2.have_w && rb.c2.have_b && rb.skip.have_w && rb.skip.have_b, "unet: conv2 / skip weights of %s not loaded", rb.name.c_str());
+            if (!rb.c2s_ready) {
+                PD_TRY(fuse_skip_weights(rb.c2.w, 9 * rb.c2.cin, rb.skip.w, rb.skip.cin, rb.c2.cout_pad, rb.c2.b, rb.skip.b, rb.cout, rb.c2s_w, rb.c2s_b, c.s));
+                rb.c2s_ready = true;
+            }
+            PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
+            *out = Act{nullptr, rb.cout, h1.H, h1.W};
+            out->p = arena_take(c.u, (size_t)c.N * h1.H * h1.W * rb.cout);
+            float* part = reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((h1.H * h1.W + 15) / 16) * (rb.cout / 8) * 2 * 2));
+            const long long hw = (long long)h1.H * h1.W;
+            float* gnp = (hw % pl.bm == 0 || pl.bm == 2 * hw) ? part : nullptr;
+            int fused = 0;
+            PD_TRY(conv_sk_skip(pl, h2.p, rb.c2s_w, rb.c2s_b, out->p, c.N, h1.H, h1.W, rb.c2.cin, rb.cout, rb.c2.cout_pad, x.p, x.p2,
+                                x.p2 ? x.Ca : x.C, x.C, c.u->zero_page, c.s, c.u->splitk_ws, c.u->splitk_floats, gnp, &fused));
+            if (fused) { out->gn_part = part; out->gn_chunks = fused; out->Ca = rb.cout; }
+            return PDHIP_OK;
+        }
+    }
     if (rb.has_skip && !fuse_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
     if (can_fuse_gn(c, h1, rb.c2)) return run_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, out, fold_up ? 1 : 0);
     PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
@@ -483,6 +511,10 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
         chk(alloc_norm(u, rb.n1, rb.cin)); chk(alloc_norm(u, rb.n2, rb.cout));
         chk(alloc_conv(u, rb.c1, rb.cin, rb.cout, 9)); chk(alloc_conv(u, rb.c2, rb.cout, rb.cout, 9));
         if (rb.has_skip) chk(alloc_conv(u, rb.skip, rb.cin, rb.cout, 1));
+        if (rb.has_skip && rb.mode == 0 && rb.cin % 64 == 0 && rb.cout % 64 == 0) {       // fused [conv2 | skip] weights (built at the first forward that routes there)
+            chk(dalloc(u, &rb.c2s_w, (size_t)rb.c2.cout_pad * (9 * (size_t)rb.cout + rb.cin)));
+            chk(dalloc(u, &rb.c2s_b, (size_t)rb.cout));
+        }
         if (rc) return fail(rc);
     }
     for (AttB& ab : u->att) {
@@ -579,6 +611,7 @@ extern "C" int pdhip_unet_num_tensors(const pdhip_unet* u) {
 
 extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const void* data, int is_f16, const int64_t* shape,
                                       int ndim, void* stream) {
+    if (u) for (ResB& rb : u->res) rb.c2s_ready = false;      // (fused [conv2 | skip] copies are rebuilt on the next forward)
     PD_REQUIRE(u && name_c && data && shape && ndim >= 1 && ndim <= 4, "pdhip_unet_load_tensor: bad arguments");
     u->steps_cached = 0;                         // any weight change invalidates the sampler's per-step embedding table
     hipStream_t s = as_stream(stream);
@@ -833,6 +866,7 @@ extern "C" int pdhip_debug_set_attn(int nbuf, int vt_form, int qtiles) {
 extern "C" int pdhip_debug_set_conv_sk_order(int order) { int old = pdnn::g_sk_order; pdnn::g_sk_order = order; return old; }
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
+extern "C" int pdhip_debug_set_fold_skip(int on) { int old = pdnn::g_fold_skip; pdnn::g_fold_skip = on; return old; }
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }
 extern "C" int pdhip_debug_set_fold_finalize_chunks(int chunks) { int old = pdnn::g_fold_finalize_chunks; pdnn::g_fold_finalize_chunks = chunks; return old; }
 extern "C" int pdhip_debug_set_fold_finalize(int max_batch) { int old = pdnn::g_fold_finalize; pdnn::g_fold_finalize = max_batch; return old; }

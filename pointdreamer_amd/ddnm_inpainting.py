@@ -53,6 +53,7 @@ _reg('pdhip_debug_set_gn_skip_variant', C.c_int, [i32])
 _reg('pdhip_debug_set_fold_resample', C.c_int, [i32])
 _reg('pdhip_debug_set_fold_finalize', C.c_int, [i32])
 _reg('pdhip_debug_set_fold_finalize_chunks', C.c_int, [i32])
+_reg('pdhip_debug_set_fold_skip', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk', C.c_int, [i32, i32, i32])
 _reg('pdhip_debug_set_conv_sk_stages', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk_kgroups', C.c_int, [i32])

@@ -195,3 +195,31 @@ def test_twenty_views_with_optimize_from_ours_at_the_default_size():
     assert torch.equal(a1, a2)
     d = (a1 - base).abs()
     assert float(d.max()) > 1e-3 and float((d > 0).float().mean()) > 0.2          # the 100 Adam steps moved the sampled texels
+
+
+@pytest.mark.parametrize("N", [1, 2, 8])
+def test_skip_conv_folded_into_conv2_k_loop(nn, full_model, N):
+    """Round 4: in the small-M layers a channel-changing ResBlock's skip 1x1 (unet.py:206-209, `self.skip_connection(x) + h` at :255) is
+    appended to conv2's K loop (k_conv_sk<10>: W2 im2col(h) + Wskip x + (b2 + bskip), single- and two-source block inputs) instead of
+    running as a launch of its own whose f16 output conv2 then adds.  Same products, one rounding fewer: both forms against the imported
+    reference's fp32 golden, and against each other inside the routing-variant budget; repeats are bit-identical."""
+    L = nn['L']
+    g = load_golden('unet_full.npz')
+    x = torch.from_numpy(g['x']).to(DEV).repeat(N, 1, 1, 1).contiguous()
+    t = torch.from_numpy(g['t']).to(DEV).repeat(N).contiguous()
+    st = int(g['stride'])
+    outs = {}
+    for on in (1, 0):
+        old = L.pdhip_debug_set_fold_skip(on)
+        try:
+            outs[on] = full_model(x, t).cpu()
+            again = full_model(x, t).cpu()
+        finally:
+            L.pdhip_debug_set_fold_skip(old)
+        assert torch.equal(outs[on], again)
+        for b in range(N):
+            linf, l2 = _rel(outs[on][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+            assert linf <= 2e-2 and l2 <= 5e-3, (N, on, b, linf, l2)
+    assert not torch.equal(outs[1], outs[0]), "the fold is taken somewhere at this batch (otherwise the test tests nothing)"
+    linf, l2 = _rel(outs[1], outs[0])
+    assert linf <= 4e-3 and l2 <= 2.5e-3, (N, linf, l2)
