@@ -49,7 +49,9 @@ int fuse_skip_weights(const half_t* w3, int K9, const half_t* w1, int Cs, int Co
                       float* bdst, hipStream_t s);
 int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
             int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* ws, size_t ws_floats, float* gn_part,
-            int* gn_fused, const half_t* X2, int Cin1);
+            int* gn_fused, const half_t* X2, int Cin1, int res_up = 0);      // res_up: residual = half-resolution tensor read with nearest x2
+// conv_igemm's routing decision for a single-source layer without input transform: does it go to k_conv_sk? (nn_gemm.hip)
+bool conv_routes_sk(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats);
 extern thread_local int g_sk_mode, g_sk_tile, g_sk_splits, g_sk_stages, g_sk_kg, g_sk_order;                         // tuning / test hooks (pdhip_debug_set_conv_sk)
 #define PD_SK_TICKET_FLOATS 4096
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of

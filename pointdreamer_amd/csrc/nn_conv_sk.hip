@@ -70,7 +70,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
                                                       int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
                                                       const half_t* __restrict__ X2, int Cin1, int m_fast,
-                                                      const half_t* __restrict__ XS, const half_t* __restrict__ XS2, int Cs1, int Cskip) {
+                                                      const half_t* __restrict__ XS, const half_t* __restrict__ XS2, int Cs1, int Cskip, int res_up) {
     // TAPS == 10 (round 4): a 3x3 conv with the ResBlock's skip 1x1 conv appended to its K loop -- out = W2 * im2col(h) + Wskip * x
     // (unet.py:255 `return self.skip_connection(x) + h`): nine taps over X (Cin channels) and a tenth, centre-only "tap" over the
     // block input x = [XS (Cs1 channels) | XS2 (Cskip - Cs1)] (a never-materialised concat, XS2 may be null); weights
@@ -405,7 +405,14 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
             half8 v = *reinterpret_cast<const half8*>(&Cs[row * CS_LD + col8]);
             const size_t o = (size_t)m * Cout + n0 + col8;
             if (residual != nullptr) {
-                const half8 rv = *reinterpret_cast<const half8*>(residual + o);
+                // res_up: the residual is the half-resolution tensor [N, H/2, W/2, Cout] read with nearest x2 (the x branch of an up-ResBlock,
+                // unet.py:190-195: no k_resample pass, no up-sampled copy)
+                size_t ro = o;
+                if (res_up) {
+                    const int img = m / HWp, rem = m - img * HWp, yy = rem / W, xx = rem - yy * W;
+                    ro = ((size_t)(img * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * Cout + n0 + col8;
+                }
+                const half8 rv = *reinterpret_cast<const half8*>(residual + ro);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
@@ -443,12 +450,12 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
 template <int TAPS, int BM, int BN, int NST, int KG, bool LS = false>
 int launch_sk(int grid, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
               int W, int Cin, int Cout, int n_tiles, int total, const half_t* zero_page, int splits, float* slabs, unsigned* tickets,
-              float* gnp, const half_t* X2, int Cin1, int m_fast, const half_t* XS = nullptr, const half_t* XS2 = nullptr, int Cs1 = 0, int Cs = 0) {
+              float* gnp, const half_t* X2, int Cin1, int m_fast, const half_t* XS = nullptr, const half_t* XS2 = nullptr, int Cs1 = 0, int Cs = 0, int res_up = 0) {
     auto kern = k_conv_sk<TAPS, BM, BN, NST, KG, LS>;
     constexpr size_t smem = (size_t)KG * NST * (BM + BN) * 128 + 16;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast, XS, XS2, Cs1, Cs);
+    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast, XS, XS2, Cs1, Cs, res_up);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -524,8 +531,9 @@ SkPlan conv_sk_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
 
 int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W,
             int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* ws, size_t ws_floats, float* gn_part,
-            int* gn_fused, const half_t* X2, int Cin1) {
+            int* gn_fused, const half_t* X2, int Cin1, int res_up) {
     PD_REQUIRE(pl.bm > 0 && (taps == 1 || taps == 9), "conv_sk: no plan / bad taps");
+    PD_REQUIRE(res_up == 0 || (residual != nullptr && H % 2 == 0 && W % 2 == 0), "conv_sk: an up-sampled residual needs even H, W");
     if (X2 == nullptr) Cin1 = Cin;
     PD_REQUIRE(X2 == nullptr || (taps == 1 && Cin1 % 64 == 0 && (Cin - Cin1) % 64 == 0 && Cin1 > 0 && Cin1 < Cin), "conv_sk: bad two-source split");
     const long long M = (long long)N * H * W;
@@ -540,7 +548,7 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     // (lab hook only: sharing the weight slices of the weight-heavy 16^2 / 8^2 layers through one L2 measured no better than the
     // default order -- the 256 MB Infinity Cache already absorbs the re-reads -- and 18 % worse at 512 tiles; profiles/r03_sk_bench.txt)
     const int m_fast = g_sk_order == 1 && m_tiles > 1 ? 1 : 0;
-#define SK_ARGS grid, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, X2, Cin1, m_fast
+#define SK_ARGS grid, s, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, X2, Cin1, m_fast, nullptr, nullptr, 0, 0, res_up
     // (lab hooks: K-groups g_sk_kg, stages g_sk_stages; 0 = the tile's default)
     int kg = g_sk_kg;
     const int st = g_sk_stages;

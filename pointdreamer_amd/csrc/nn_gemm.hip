@@ -570,6 +570,12 @@ bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
            conv3x3_halo_splits(N, H, W, Cin, Cout, Cout_pad, 0) == 1;
 }
 
+bool conv_routes_sk(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats) {
+    if (conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats)) return false;
+    if (g_force_wmw != 0 || g_force_bk != 0 || g_force_stages != 0 || g_force_splits != 0) return false;
+    return conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, false, splitk_ws_floats).bm > 0;
+}
+
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
                   float* gn_part, int hw, hipStream_t s) {
     dim3 gr((unsigned)((M + SK_ROWS - 1) / SK_ROWS), (unsigned)(((Cout >> 3) + 63) / 64));
@@ -600,12 +606,12 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
                             res_up, in_up);
     }
     // small-M layers (output tiles do not fill the chip): small tiles, deep staging, split-K combined inside the launch
-    if (in_up == 0 && res_up == 0 && apply_table == nullptr && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
+    if (in_up == 0 && apply_table == nullptr && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
         const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, X2 != nullptr, splitk_ws ? splitk_ws_floats : 0);
         if (pl.bm > 0) {
             float* gnp = (gn_part != nullptr && (((long long)H * W) % pl.bm == 0 || pl.bm == 2 * H * W)) ? gn_part : nullptr;
             return conv_sk(pl, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, taps, zero_page, s, splitk_ws, splitk_ws_floats, gnp,
-                           gn_fused, X2, Cin1);
+                           gn_fused, X2, Cin1, res_up);
         }
     }
     // (the first PD_SK_TICKET_FLOATS words of the split-K workspace are k_conv_sk's ticket counters)
@@ -614,7 +620,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
         else { splitk_ws = nullptr; splitk_ws_floats = 0; }
     }
     PD_REQUIRE(in_up == 0, "conv_igemm: an up-sampled input needs a layer the halo-resident kernel takes");
-    PD_REQUIRE(res_up == 0, "conv_igemm: an up-sampled residual needs a layer the halo-resident kernel takes unsplit");
+    PD_REQUIRE(res_up == 0, "conv_igemm: an up-sampled residual needs a layer the halo-resident kernel (unsplit) or k_conv_sk takes");
     PD_REQUIRE(apply_table == nullptr, "conv_igemm: an input transform needs a layer the halo-resident kernel takes");
     const int bk = (g_force_bk == 32 || Cin % 64 != 0) ? 32 : 64;
     // tile geometry: 256x256 (wave tile 128x64: 25 % fewer LDS reads per MFMA, half the L2 traffic) once it still yields

@@ -265,9 +265,11 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     // x branch of an up / down block (unet.py:190-195, 237-242: h and x go through the same Upsample / Downsample)
     const bool fold = g_fold_resample != 0 && !c.dry && x.p2 == nullptr && !rb.has_skip;
     const bool fold_down = fold && rb.mode == 1;                     // AvgPool2d(2)(x): second output of the GroupNorm-apply pass
-    const bool fold_up = fold && rb.mode == 2 && Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&      // nearest x2: index arithmetic in conv2's
-                         conv_uses_halo(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) &&   // residual read
-                         conv3x3_halo_splits(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, c.u->splitk_floats) == 1;
+    const bool fold_up = fold && rb.mode == 2 &&
+                         ((Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&      // nearest x2: index arithmetic in conv2's
+                           conv_uses_halo(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) &&   // residual read
+                           conv3x3_halo_splits(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, c.u->splitk_floats) == 1) ||
+                          (g_fuse_gn == 0 && conv_routes_sk(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats)));   // (round 4: k_conv_sk's epilogue too)
     if (rb.mode != 0) {
         xr.H = Ho; xr.W = Wo;
         xr.p = arena_take(c.u, (size_t)c.N * Ho * Wo * x.C);     // (the sizing pass always reserves it: routing may differ later)
