@@ -394,6 +394,37 @@ def main():
                 del sg
             except Exception as e:                      # noqa: BLE001 -- a side figure must not take the headline line down
                 extras['nearest_graphs'] = dict(error=str(e)[:200])
+            # the same 8 shapes with ONE launch per stage for all of them (round 4: pdhip_*_shapes, pointdreamer_amd/shapes.py): per-shape
+            # inputs stacked [S, ...] -- the stacking of the 8 shape dicts (clouds, mesh and atlas maps: one copy each) is inside the timed
+            # region, as colorize_meshes_batched does it for a directory run; `geometry_kept` re-stacks only the clouds
+            try:
+                from pointdreamer_amd import shapes as shp
+                b8 = [dict(coords=c_[0], colors=c_[1], vertices=g['vertices'], faces=g['faces'], f_normals=g['f_normals'], xatlas=xatlas) for c_ in cl]
+                skw = dict(texture_gen_method='nearest', point_size=1, edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82,
+                           edge_dilate_kernels=[21], point_validation_by_o3d=True)
+                run8 = lambda: shp.colorize_shapes(shp.stack(b8), camera_info, V, RES, CAM_RES, **skw)
+                for _ in range(3):
+                    run8()
+                sync(); t1 = time.perf_counter()
+                for _ in range(30):
+                    run8()
+                sync(); ds8 = (time.perf_counter() - t1) / 30 / 8
+                st8 = shp.stack(b8)
+                def run8k():
+                    st8['coords'] = torch.stack([c_[0] for c_ in cl], 0); st8['colors'] = torch.stack([c_[1] for c_ in cl], 0)
+                    return shp.colorize_shapes(st8, camera_info, V, RES, CAM_RES, **skw)
+                for _ in range(3):
+                    run8k()
+                sync(); t1 = time.perf_counter()
+                for _ in range(30):
+                    run8k()
+                sync(); dk8 = (time.perf_counter() - t1) / 30 / 8
+                extras['nearest_stacked'] = dict(metric="shapes/hour (configs[1] workload, 8 independent shapes per step, ONE launch per stage for all 64 "
+                                                        "views (pdhip_*_shapes), hidden-point removal on)", value=3600.0 / ds8, ms_per_shape=ds8 * 1e3,
+                                                 ms_per_shape_geometry_kept=dk8 * 1e3)
+                del st8
+            except Exception as e:                      # noqa: BLE001
+                extras['nearest_stacked'] = dict(error=str(e)[:200])
             one(cfg)
             d1s = []
             for _ in range(3):

@@ -72,6 +72,36 @@ int pdhip_raster_barycentrics(const float* pos /*[V,Vn,4]*/, int V, int Vn, cons
 int pdhip_interpolate(const float* attr /*[Na,C]*/, int C, const int32_t* tri /*[F,3]*/, const int64_t* face_idxs,
                       const float* bary, long long pixels, float* out /*[pixels,C]*/, void* stream);
 
+/* ---- SURVEY 8(e) configs[4], round 4: S independent shapes of EQUAL sizes (Vn vertices, F faces, N points, atlas A) through the same V
+ *      cameras in ONE launch per stage.  Per-shape inputs are stacked ([S, ...]); every per-view array has S*V leading entries, view
+ *      g = s * V + v; results equal the per-shape entry points bit for bit (tests/test_gpu_round4.py).  The per-view-independent stages
+ *      (pdhip_resize_mask, pdhip_point_visibility*, pdhip_nearest_fill) already take any number of images: call them with S*V. */
+int pdhip_project_points_shapes(const float* cam_params /*[V,16]*/, int V, int S, const float* vertices /*[S,Vn,3]*/, int Vn,
+                                const float* points /*[S,N,3]*/, int N, int rescale, double padding, float* pos /*[S*V,Vn,4]*/,
+                                float* vertice_uvs, float* uv_centers /*[S*V,2]*/, float* uv_scales /*[S*V]*/, float* point_uvs /*[S*V,N,2]*/,
+                                float* point_depths /*[S*V,N]*/, uint32_t* minmax_ws /*[4*S*V]*/, void* stream);
+int pdhip_raster_mesh_shapes(const float* pos /*[S*V,Vn,4]*/, int V, int S, int Vn, const int32_t* faces /*[S,F,3]*/, int F, int R,
+                             uint64_t* zkey_ws, size_t ws_bytes /* pdhip_raster_mesh_ws_bytes(S*V, F, R) */, uint8_t* hard_masks,
+                             int64_t* face_idxs, float* depths, void* stream);
+int pdhip_hidden_point_removal_shapes(const float* points /*[S,N,3]*/, int N, const double* eyes /*[S*V,3]*/, int V, int S, double radius,
+                                      const uint8_t* skip /*[S*V,N] or NULL*/, uint8_t* visibility /*[S*V,N]*/,
+                                      void* ws /* pdhip_hpr_ws_bytes(S*V, N); S*V <= 64 */, void* stream);
+int pdhip_sparse_views_shapes(const int64_t* point_pixels /*[S*V,N,2]*/, const float* colors /*[S,N,3]*/, const uint8_t* validation,
+                              const uint8_t* hard_masks, int V, int S, int N, int res, int point_size, int edge_point_size,
+                              double mask_ratio_thresh, float* sparse, float* mask0, float* mask2, float* scale_factors /*[S*V]*/,
+                              float* mask_ratios, void* ws /* pdhip_sparse_views_ws_bytes(S*V, N, res) */, void* stream);
+int pdhip_texel_visibility_shapes(const float* cam_params, int V, int S, const float* gb_pos /*[S,A,A,3]*/, const uint8_t* mask /*[S,A,A]*/,
+                                  int A, const float* uv_centers, const float* uv_scales, double padding, const float* mesh_depths /*[S*V,R,R]*/,
+                                  int R, float offset, uint8_t* visibility /*[S*V,A,A]*/, void* stream);
+int pdhip_nbf_shrink_shapes(const uint8_t* mask /*[S,A,A]*/, const uint8_t* visibility /*[S*V,A,A]*/, int V, int S, int A,
+                            const int32_t* kernels, int K, uint8_t* out /*[K][S*V][A][A]*/, uint8_t* ws /*2*S*V*A*A bytes*/, void* stream);
+int pdhip_view_select_blend_shapes(const float* cam_params, int V, int S, const float* gb_pos, const uint8_t* mask, const int64_t* face_id,
+                                   int A, const float* f_normals /*[S,F,3]*/, int F, const float* base_dirs /*[V,3]*/, const float* uv_centers,
+                                   const float* uv_scales, double padding, const float* scale_factors, const uint8_t* shrinked /*[K][S*V][A][A]*/,
+                                   int K, const uint8_t* visibility, int complete_unseen_by_projection, const float* inpainted /*[S*V,3,r,r]*/,
+                                   int r, float* atlas /*[S,A,A,3]*/, uint8_t* painted /*[S,A,A]*/, int32_t* view_ids /*[S,A,A], local to the shape*/,
+                                   void* stream);
+
 /* ---- ours_utils.optimize_color (pointdreamer/ours_utils.py:1583-1785).
  *      pdhip_rescale_vertices: pos.xy <- clip((((xy-c)/s)*(1-2pad))*factor_v + 0.5, 0, 1)*2-1  (:1688-1695), in place.
  *      pdhip_optimize_color: `iterations` Adam steps (lr, StepLR(15, 0.5)) of the masked L1 texture loss, atlas[3,A,A] f32

@@ -20,6 +20,14 @@ _SIGS = {
     'pdhip_version': (C.c_int, []),
     'pdhip_last_error': (C.c_char_p, []),
     'pdhip_project_points': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_project_points_shapes': (C.c_int, [vp, i32, i32, vp, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_raster_mesh_shapes': (C.c_int, [vp, i32, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, vp]),
+    'pdhip_hidden_point_removal_shapes': (C.c_int, [vp, i32, vp, i32, i32, f64, vp, vp, vp, vp]),
+    'pdhip_sparse_views_shapes': (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp]),
+    'pdhip_texel_visibility_shapes': (C.c_int, [vp, i32, i32, vp, vp, i32, vp, vp, f64, vp, i32, f32, vp, vp]),
+    'pdhip_nbf_shrink_shapes': (C.c_int, [vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]),
+    'pdhip_view_select_blend_shapes': (C.c_int, [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, f64, vp, vp, i32, vp, i32, vp, i32,
+                                                 vp, vp, vp, vp]),
     'pdhip_raster_mesh': (C.c_int, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
     'pdhip_raster_mesh_ws_bytes': (sz, [i32, i32, i32]),
     'pdhip_raster_mesh_ws': (C.c_int, [vp, i32, i32, vp, i32, i32, vp, sz, vp, vp, vp, vp]),

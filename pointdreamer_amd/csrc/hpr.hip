@@ -201,15 +201,16 @@ __global__ __launch_bounds__(1024) void k_hpr_flip(const float* __restrict__ pts
                            double* __restrict__ flipped /*[V][3][N]*/, unsigned long long* __restrict__ maxabs /*[V] f64 bits*/,
                            unsigned long long* __restrict__ bbox /*[V][6] order keys of max(-x), max(-y), max(-z), max(x), max(y), max(z)*/,
                            const uint8_t* __restrict__ skip, int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis,
-                           int collect, float4* __restrict__ f32pts /*[V][N] (x, y, z, 0) rounded to f32, or null*/) {
+                           int collect, float4* __restrict__ f32pts /*[V][N] (x, y, z, 0) rounded to f32, or null*/, int vps /*views per shape*/) {
     // open3d PointCloud::HiddenPointRemoval: p' = q + 2 (radius - |q|) q / |q| evaluated as q + ((2 (radius - n)) q) / n
     // Also here: the queries that still need the hull test -- all points, or only those a cheaper test (`skip`) has not already
     // accepted (those are marked visible) -- compacted into `list` with one returning atomic per 256-thread block and step.
     __shared__ int s_wcnt[16], s_base;
-    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    pts += (size_t)(v / vps) * 3 * (size_t)N;            // several shapes in one call: view v looks at the cloud of shape v / vps
     const double ex = eyes[3 * v], ey = eyes[3 * v + 1], ez = eyes[3 * v + 2];
     double m = 0.0, b[6] = {-1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300, -1.0e300};
-    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+    for (int i0 = blockIdx.y * blockDim.x; i0 < N; i0 += gridDim.y * blockDim.x) {
         const int i = i0 + threadIdx.x;
         const bool in = i < N;
         if (in) {
@@ -296,9 +297,9 @@ __device__ __forceinline__ void grid_cell(const GridMap& g, const double x, cons
 __global__ void k_hpr_grid(const double* __restrict__ flipped, int N, const unsigned long long* __restrict__ bbox,
                            unsigned long long* __restrict__ grid /*[V][G*G], zeroed: (f32 bits of |p'|^2, index + 1)*/,
                            double* __restrict__ fdir /*[KC][4]: the Fibonacci directions of level 1, computed here on the side*/) {
-    const int v = blockIdx.y;
+    const int v = blockIdx.x;
     if (v == 0) {
-        const int k = blockIdx.x * blockDim.x + threadIdx.x;
+        const int k = blockIdx.y * blockDim.x + threadIdx.x;
         if (k < HPR_KC) {
             const double zk = 1.0 - (2.0 * k + 1.0) / HPR_KC, rk = sqrt(fmax(0.0, 1.0 - zk * zk)), pk = k * 2.399963229728653;
             fdir[4 * k] = rk * cos(pk); fdir[4 * k + 1] = rk * sin(pk); fdir[4 * k + 2] = zk; fdir[4 * k + 3] = 0.0;
@@ -307,7 +308,7 @@ __global__ void k_hpr_grid(const double* __restrict__ flipped, int N, const unsi
     const GridMap g = grid_map(bbox, v);
     if (!g.ok) return;
     const double* f = flipped + (size_t)v * 3 * N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < N; i += gridDim.y * blockDim.x) {
         const double x = f[i], y = f[N + i], z = f[2 * (size_t)N + i];
         int iu, iw;
         grid_cell(g, x, y, z, iu, iw);
@@ -321,11 +322,11 @@ __global__ __launch_bounds__(1024) void k_hpr_shield(const double* __restrict__ 
                                                      int* __restrict__ count, int* __restrict__ list, uint8_t* __restrict__ vis,
                                                      int* __restrict__ counters) {
     __shared__ int s_wcnt[16], s_base;
-    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridMap g = grid_map(bbox, v);
     const double* f = flipped + (size_t)v * 3 * N;
     const unsigned long long* gv = grid + (size_t)v * HPR_GRID * HPR_GRID;
-    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+    for (int i0 = blockIdx.y * blockDim.x; i0 < N; i0 += gridDim.y * blockDim.x) {
         const int i = i0 + threadIdx.x;
         const bool in = i < N;
         const bool sk = in && skip != nullptr && skip[(size_t)v * N + i];
@@ -414,12 +415,12 @@ __global__ __launch_bounds__(256) void k_hpr_coarse(const double* __restrict__ f
                                                     const double* __restrict__ csd /*[V][KC][4]*/, const int* __restrict__ cidx /*[V][KC]*/,
                                                     const int* __restrict__ kcount, uint8_t* __restrict__ outside, uint8_t* __restrict__ vis,
                                                     const unsigned long long* __restrict__ maxabs, double* __restrict__ qdir /*[V][N][3]*/) {
-    const int v = blockIdx.y;
+    const int v = blockIdx.x;
     const int nq = count[v];
     const int lane = threadIdx.x & 63, l31 = lane & 31;
     const bool hi = lane >= 32;
-    const int qi = COLS == 2 ? blockIdx.x * 256 + threadIdx.x : blockIdx.x * 128 + (threadIdx.x >> 6) * 32 + l31;
-    if (blockIdx.x * (COLS == 2 ? 256 : 128) >= nq) return;           // (the whole block: before the barrier below)
+    const int qi = COLS == 2 ? blockIdx.y * 256 + threadIdx.x : blockIdx.y * 128 + (threadIdx.x >> 6) * 32 + l31;
+    if (blockIdx.y * (COLS == 2 ? 256 : 128) >= nq) return;           // (the whole block: before the barrier below)
     const int KS = min(kcount[v], HPR_KC), KT = (KS + 31) >> 5;       // (the set is padded with the eye (0, 0, 0) to whole tiles)
     // the view's coarse set lives in LDS for the block's lifetime (f32 records for the scans, f64 records + cloud indices for the
     // GJK step): every round ends with two dependent look-ups into it, which from L2 were a third of the round's latency
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(256, HPR_FINE_WPE) void k_hpr_fine_dist(const doubl
                                                        const unsigned long long* __restrict__ maxabs, int* __restrict__ unc_count,
                                                        int* __restrict__ unc_list, int* __restrict__ unc_seed) {
     __shared__ int s_cand[4][256];
-    const int v = blockIdx.y;
+    const int v = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nq = count[v];
     const double* qf = flipped + (size_t)v * 3 * N;
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(256, HPR_FINE_WPE) void k_hpr_fine_dist(const doubl
     const double rb = ma * (8.0 * 1.1102230246251565e-16);
     // (a fixed grid that strides over the list: a grid sized for N queries would be mostly empty blocks, and dispatching those costs
     // more than the work -- 58 k of 60 k in the pipeline's case)
-    for (int qi = blockIdx.x * 4 + wave; qi < nq; qi += gridDim.x * 4) {
+    for (int qi = blockIdx.y * 4 + wave; qi < nq; qi += gridDim.y * 4) {
     const int q = list[(size_t)v * N + qi];
 #ifdef PD_HPR_STATS
     const unsigned long long t_begin = wall_clock64();
@@ -1254,7 +1255,7 @@ __global__ __launch_bounds__(1024) void k_hpr_bin(const double* __restrict__ fli
                           const unsigned long long* __restrict__ bbox /*[V][6] keys of max(-x,-y,-z), max(x,y,z)*/, int* __restrict__ cellkey,
                           int* __restrict__ hist, int* __restrict__ count2, int* __restrict__ list2, uint8_t* __restrict__ vis) {
     __shared__ int s_wcnt[16], s_base;                            // (1024-lane blocks: the returning atomic below is ~0.2 us per block)
-    const int v = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double* f = flipped + (size_t)v * 3 * N;
     double lo[3], sc[3];
 #pragma unroll
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(1024) void k_hpr_bin(const double* __restrict__ fli
         const double ext = key_f64(bbox[6 * v + 3 + k]) - lo[k];
         sc[k] = ext > 0.0 ? (double)(1 << HPR_CELL_BITS) / ext : 0.0;
     }
-    for (int i0 = blockIdx.x * blockDim.x; i0 < N; i0 += gridDim.x * blockDim.x) {
+    for (int i0 = blockIdx.y * blockDim.x; i0 < N; i0 += gridDim.y * blockDim.x) {
         const int i = i0 + threadIdx.x;
         const bool in = i < N;
         const uint8_t o = in ? (outside ? outside[(size_t)v * N + i] : 1) : 0;
@@ -1316,10 +1317,10 @@ __global__ __launch_bounds__(1024) void k_hpr_cellscan(int* __restrict__ hist, i
 }
 __global__ void k_hpr_scatter(const double* __restrict__ flipped, int N, const int* __restrict__ cellkey, int* __restrict__ cellpos,
                               double* __restrict__ ss, int* __restrict__ sidx, int* __restrict__ pos_of) {
-    const int v = blockIdx.y;
+    const int v = blockIdx.x;
     const double* f = flipped + (size_t)v * 3 * N;
     double* so = ss + (size_t)v * 3 * N;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < N; i += gridDim.y * blockDim.x) {
         const int key = cellkey[(size_t)v * N + i];
         if (key < 0) continue;
         const int pos = atomicAdd(&cellpos[(size_t)v * HPR_NCELL + key], 1);
@@ -1513,8 +1514,21 @@ extern "C" size_t pdhip_hpr_ws_bytes(int V, int N) {
            a256((size_t)V * HPR_GRID * HPR_GRID * sizeof(unsigned long long));
 }
 
+static int hpr_impl(const float* points, int N, const double* eyes_dev, int V, int vps, double radius, const uint8_t* skip, uint8_t* visibility,
+                    void* ws, void* stream);
 extern "C" int pdhip_hidden_point_removal(const float* points, int N, const double* eyes_dev, int V, double radius,
                                           const uint8_t* skip, uint8_t* visibility, void* ws, void* stream) {
+    return hpr_impl(points, N, eyes_dev, V, V > 0 ? V : 1, radius, skip, visibility, ws, stream);
+}
+// S shapes of N points each in ONE set of launches: points [S,N,3], eyes [S*V,3] (the shape's V eye positions, repeated per shape),
+// skip / visibility [S*V,N]; view g = s * V + v looks at the cloud of shape s.  S * V <= 64; workspace pdhip_hpr_ws_bytes(S * V, N).
+extern "C" int pdhip_hidden_point_removal_shapes(const float* points, int N, const double* eyes_dev, int V, int S, double radius,
+                                                 const uint8_t* skip, uint8_t* visibility, void* ws, void* stream) {
+    PD_REQUIRE(S >= 1 && V >= 1, "pdhip_hidden_point_removal_shapes: bad sizes");
+    return hpr_impl(points, N, eyes_dev, S * V, V, radius, skip, visibility, ws, stream);
+}
+static int hpr_impl(const float* points, int N, const double* eyes_dev, int V, int vps, double radius, const uint8_t* skip, uint8_t* visibility,
+                    void* ws, void* stream) {
     PD_REQUIRE(V > 0 && N >= 0, "pdhip_hidden_point_removal: bad sizes");
     if (N == 0) return PDHIP_OK;
     PD_REQUIRE(points && eyes_dev && visibility && ws, "pdhip_hidden_point_removal: null pointer");
@@ -1552,25 +1566,25 @@ extern "C" int pdhip_hidden_point_removal(const float* points, int N, const doub
     double* qdir = reinterpret_cast<double*>(p); p += flipped_bytes(V, N);
     unsigned long long* ekeys = reinterpret_cast<unsigned long long*>(p); p += a256((size_t)HPR_EXT_SLABS * V * HPR_KC * sizeof(unsigned long long));   // [slab][V][KC]
     float4* f32pts = reinterpret_cast<float4*>(p); p += a256((size_t)V * (size_t)(N > 0 ? N : 1) * sizeof(float4));
-    dim3 gf(min(cdiv(N, 256), 256), V);
+    dim3 gf(V, min(cdiv(N, 256), 256));      // (the view is the FASTEST grid index in these kernels: workgroup b runs on XCD b % 8, so with 8 views an XCD's L2 holds ONE view's flipped cloud / grid / support set -- k_hpr_shield fetched 12x its input when every XCD touched every view)
     const bool two_level = N > 4 * HPR_KC;   // the coarse level pays off only when the cloud is much larger than the coarse set
     PD_HIP(hipMemsetAsync(ws, 0, zero_bytes, s));
-    k_hpr_flip<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>
-       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility, two_level ? 0 : 1, two_level ? f32pts : nullptr);      // (one level: + marks the skipped points visible; `list` = the queries)
+    k_hpr_flip<<<dim3(V, min(cdiv(N, 1024), 64)), 1024, 0, s>>>
+       (points, N, eyes_dev, radius, flipped, maxabs, bbox, skip, count, list, visibility, two_level ? 0 : 1, two_level ? f32pts : nullptr, vps);      // (one level: + marks the skipped points visible; `list` = the queries)
     constexpr int KC = HPR_KC;
     if (two_level) {
         k_hpr_grid<<<gf, 256, 0, s>>>(flipped, N, bbox, sgrid, fdir);
-        k_hpr_shield<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, bbox, sgrid, skip, count, list, visibility, counters);
+        k_hpr_shield<<<dim3(V, min(cdiv(N, 1024), 64)), 1024, 0, s>>>(flipped, N, bbox, sgrid, skip, count, list, visibility, counters);
         const int slab_points = ext_slab_points(N), slabs = cdiv(N, slab_points);
         k_hpr_extremes<<<dim3(slabs, KC / 256, V), 256, 0, s>>>(f32pts, N, fdir, slab_points, ekeys);
         k_hpr_extremes_fin<<<dim3(KC / 256, V), 256, 0, s>>>(flipped, N, ekeys, slabs, csf, csd, cidx, kcount, pos_of, mdir);
-        k_hpr_coarse<2><<<dim3(cdiv(N, 256), V), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, visibility, maxabs, qdir);
+        k_hpr_coarse<2><<<dim3(V, cdiv(N, 256)), 256, 0, s>>>(flipped, N, count, list, csf, csd, cidx, kcount, outside, visibility, maxabs, qdir);
     }
-    k_hpr_bin<<<dim3(min(cdiv(N, 1024), 64), V), 1024, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
+    k_hpr_bin<<<dim3(V, min(cdiv(N, 1024), 64)), 1024, 0, s>>>(flipped, N, two_level ? outside : nullptr, skip, bbox, cellkey, hist, count2, list2, visibility);
     k_hpr_cellscan<<<V, 1024, 0, s>>>(hist, scount);
     k_hpr_scatter<<<gf, 256, 0, s>>>(flipped, N, cellkey, hist, ss, sidx, pos_of);
     k_hpr_boxes<<<dim3(cdiv(cdiv(N, 64), 4), V), 256, 0, s>>>(ss, N, scount, boxes);
-    k_hpr_fine_dist<<<dim3(min(cdiv(N, 4), 512), V), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, two_level ? mdir : nullptr, fdir, two_level ? qdir : nullptr, maxabs, ucount, ulist, useed);
+    k_hpr_fine_dist<<<dim3(V, min(cdiv(N, 4), 512)), 256, 0, s>>>(flipped, N, count2, list2, visibility, ss, sidx, scount, boxes, pos_of, two_level ? mdir : nullptr, fdir, two_level ? qdir : nullptr, maxabs, ucount, ulist, useed);
     k_hpr_exact<double><<<dim3(64, V), 64, 0, s>>>(flipped, N, ucount, ulist, useed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, u2count, u2list, u2seed, counters);
     k_hpr_exact<dd><<<dim3(32, V), 512, 0, s>>>(flipped, N, u2count, u2list, u2seed, visibility, ss, sidx, N, scount, boxes, pos_of, maxabs, nullptr, nullptr, nullptr, counters);
     PD_LAUNCH_CHECK();

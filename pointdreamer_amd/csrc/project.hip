@@ -7,10 +7,12 @@ using namespace pdhip;
 
 // ---------------------------------------------------------------------------------------------
 // P1 pass A: transform mesh vertices for every view, write pos = (x,y,z,1), reduce xy min/max.
+// (vps = views per shape: view g = blockIdx.y belongs to shape g / vps and uses camera g % vps; one shape: vps = V)
 __global__ void k_project_verts(const float* __restrict__ cams, const float* __restrict__ verts, int Vn,
-                                float* __restrict__ pos, uint32_t* __restrict__ minmax, int single) {
+                                float* __restrict__ pos, uint32_t* __restrict__ minmax, int single, int vps) {
     const int v = blockIdx.y;
-    const Cam c = load_cam(cams + 16 * v);
+    const Cam c = load_cam(cams + 16 * (v % vps));
+    verts += (size_t)(v / vps) * 3 * (size_t)Vn;
     float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Vn; i += gridDim.x * blockDim.x) {
         float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
@@ -49,8 +51,9 @@ __global__ void k_init_minmax(uint32_t* minmax, int V) {
 __global__ void k_project_finish(const float* __restrict__ cams, const uint32_t* __restrict__ minmax,
                                  const float* __restrict__ points, int N, int Vn, int rescale, float pad9,
                                  float* __restrict__ pos, float* __restrict__ vuv, float* __restrict__ uv_centers,
-                                 float* __restrict__ uv_scales, float* __restrict__ puv, float* __restrict__ pdep) {
+                                 float* __restrict__ uv_scales, float* __restrict__ puv, float* __restrict__ pdep, int vps) {
     const int v = blockIdx.y;
+    points += (size_t)(v / vps) * 3 * (size_t)N;
     float cx = 0.f, cy = 0.f, sc = 2.f;
     if (rescale) {
         float mnx = ord2f(minmax[4 * v + 0]), mny = ord2f(minmax[4 * v + 1]);
@@ -62,7 +65,7 @@ __global__ void k_project_finish(const float* __restrict__ cams, const uint32_t*
             uv_centers[2 * v] = cx; uv_centers[2 * v + 1] = cy; uv_scales[v] = sc;
         }
     }
-    const Cam c = load_cam(cams + 16 * v);
+    const Cam c = load_cam(cams + 16 * (v % vps));
     const int total = Vn + N;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < Vn) {
@@ -101,26 +104,45 @@ __global__ void k_project_finish(const float* __restrict__ cams, const uint32_t*
     }
 }
 
+static int project_impl(const float* cam_params, int V, int vps, const float* vertices, int Vn, const float* points, int N, int rescale,
+                        double padding, float* pos, float* vertice_uvs, float* uv_centers, float* uv_scales, float* point_uvs,
+                        float* point_depths, uint32_t* minmax_ws, void* stream);
 extern "C" int pdhip_project_points(const float* cam_params, int V, const float* vertices, int Vn,
                                     const float* points, int N, int rescale, double padding, float* pos,
                                     float* vertice_uvs, float* uv_centers, float* uv_scales, float* point_uvs,
                                     float* point_depths, uint32_t* minmax_ws, void* stream) {
+    return project_impl(cam_params, V, V > 0 ? V : 1, vertices, Vn, points, N, rescale, padding, pos, vertice_uvs, uv_centers, uv_scales, point_uvs,
+                        point_depths, minmax_ws, stream);
+}
+// S shapes through the same V cameras in ONE set of launches: vertices [S,Vn,3], points [S,N,3]; every per-view output has S*V
+// leading entries (view g = s * V + v), minmax_ws 4 * S * V words.
+extern "C" int pdhip_project_points_shapes(const float* cam_params, int V, int S, const float* vertices, int Vn,
+                                           const float* points, int N, int rescale, double padding, float* pos,
+                                           float* vertice_uvs, float* uv_centers, float* uv_scales, float* point_uvs,
+                                           float* point_depths, uint32_t* minmax_ws, void* stream) {
+    PD_REQUIRE(S >= 1 && V >= 1, "pdhip_project_points_shapes: bad sizes");
+    return project_impl(cam_params, S * V, V, vertices, Vn, points, N, rescale, padding, pos, vertice_uvs, uv_centers, uv_scales, point_uvs,
+                        point_depths, minmax_ws, stream);
+}
+static int project_impl(const float* cam_params, int V, int vps, const float* vertices, int Vn, const float* points, int N, int rescale,
+                        double padding, float* pos, float* vertice_uvs, float* uv_centers, float* uv_scales, float* point_uvs,
+                        float* point_depths, uint32_t* minmax_ws, void* stream) {
     PD_REQUIRE(V > 0 && Vn > 0 && N >= 0, "pdhip_project_points: bad sizes V=%d Vn=%d N=%d", V, Vn, N);
     PD_REQUIRE(cam_params && vertices && pos && vertice_uvs && minmax_ws && (N == 0 || (points && point_uvs && point_depths)),
                "pdhip_project_points: null pointer");
     PD_REQUIRE(!rescale || (uv_centers && uv_scales), "pdhip_project_points: rescale needs uv_centers/uv_scales");
     hipStream_t s = as_stream(stream);
     if (Vn <= 65536) {                                     // one 1024-lane workgroup per view reduces its own extrema
-        k_project_verts<<<dim3(1, V), 1024, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws, 1);
+        k_project_verts<<<dim3(1, V), 1024, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws, 1, vps);
     } else {
         k_init_minmax<<<cdiv(4 * V, 64), 64, 0, s>>>(minmax_ws, V);
         dim3 ga(min(cdiv(Vn, 256), 64), V);
-        k_project_verts<<<ga, 256, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws, 0);
+        k_project_verts<<<ga, 256, 0, s>>>(cam_params, vertices, Vn, pos, minmax_ws, 0, vps);
     }
     dim3 gb(min(cdiv(Vn + N, 256), 256), V);
     const float pad9 = (float)(1.0 - 2.0 * padding);
     k_project_finish<<<gb, 256, 0, s>>>(cam_params, minmax_ws, points, N, Vn, rescale, pad9, pos, vertice_uvs,
-                                        uv_centers, uv_scales, point_uvs, point_depths);
+                                        uv_centers, uv_scales, point_uvs, point_depths, vps);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -33,8 +33,9 @@ __global__ void k_raster_init(uint64_t* zkey, long long n) {
 
 // one thread per (view, face); bbox loop with 64-bit atomicMin.
 __global__ void k_raster_faces(const float* __restrict__ pos, int Vn, const int32_t* __restrict__ faces, int F, int R,
-                               uint64_t* __restrict__ zkey) {
+                               uint64_t* __restrict__ zkey, int vps) {
     const int v = blockIdx.y;
+    faces += (size_t)(v / vps) * 3 * (size_t)F;            // several shapes per call: view v draws the mesh of shape v / vps
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)v * Vn;
@@ -99,8 +100,9 @@ struct __attribute__((aligned(16))) FaceSetup {     // edge functions as exact d
 };
 
 __global__ void k_raster_setup(const float* __restrict__ pos, int Vn, const int32_t* __restrict__ faces, int F, int R,
-                               FaceSetup* __restrict__ setup, short4* __restrict__ bbox) {
+                               FaceSetup* __restrict__ setup, short4* __restrict__ bbox, int vps) {
     const int v = blockIdx.y;
+    faces += (size_t)(v / vps) * 3 * (size_t)F;            // several shapes per call: view v draws the mesh of shape v / vps
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     FaceSetup fs;
@@ -325,8 +327,21 @@ extern "C" int pdhip_raster_mesh(const float* pos, int V, int Vn, const int32_t*
                                  void* stream) {
     return pdhip_raster_mesh_ws(pos, V, Vn, faces, F, R, zkey_ws, (size_t)V * R * R * sizeof(uint64_t), hard_masks, face_idxs, depths, stream);
 }
+static int raster_impl(const float* pos, int V, int vps, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws, size_t ws_bytes,
+                       uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream);
 extern "C" int pdhip_raster_mesh_ws(const float* pos, int V, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws, size_t ws_bytes,
                                     uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream) {
+    return raster_impl(pos, V, V > 0 ? V : 1, Vn, faces, F, R, zkey_ws, ws_bytes, hard_masks, face_idxs, depths, stream);
+}
+// S meshes of Vn vertices / F faces each, V views per mesh, in ONE set of launches: pos [S*V,Vn,4] (pdhip_project_points_shapes),
+// faces [S,F,3]; outputs [S*V,R,R]; workspace pdhip_raster_mesh_ws_bytes(S * V, F, R).
+extern "C" int pdhip_raster_mesh_shapes(const float* pos, int V, int S, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws,
+                                        size_t ws_bytes, uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream) {
+    PD_REQUIRE(S >= 1 && V >= 1, "pdhip_raster_mesh_shapes: bad sizes");
+    return raster_impl(pos, S * V, V, Vn, faces, F, R, zkey_ws, ws_bytes, hard_masks, face_idxs, depths, stream);
+}
+static int raster_impl(const float* pos, int V, int vps, int Vn, const int32_t* faces, int F, int R, uint64_t* zkey_ws, size_t ws_bytes,
+                       uint8_t* hard_masks, int64_t* face_idxs, float* depths, void* stream) {
     PD_REQUIRE(V > 0 && Vn > 0 && F >= 0 && R > 0 && R <= 16384, "pdhip_raster_mesh: bad sizes V=%d Vn=%d F=%d R=%d", V, Vn, F, R);
     PD_REQUIRE(pos && (F == 0 || faces) && zkey_ws && hard_masks && face_idxs && depths, "pdhip_raster_mesh: null pointer");
     hipStream_t s = as_stream(stream);
@@ -336,7 +351,7 @@ extern "C" int pdhip_raster_mesh_ws(const float* pos, int V, int Vn, const int32
     if (g_raster_path != 1 && F > 0 && F <= 65536 && R <= 32767 && (size_t)V * F * (sizeof(FaceSetup) + sizeof(short4)) <= ws_bytes) {
         FaceSetup* setup = reinterpret_cast<FaceSetup*>(zkey_ws);
         short4* bbox = reinterpret_cast<short4*>(setup + (size_t)V * F);
-        k_raster_setup<<<dim3(cdiv(F, 256), V), 256, 0, s>>>(pos, Vn, faces, F, R, setup, bbox);
+        k_raster_setup<<<dim3(cdiv(F, 256), V), 256, 0, s>>>(pos, Vn, faces, F, R, setup, bbox, vps);
         const int tiles = cdiv(R, RT) * cdiv(R, RT);
         k_raster_tiles<<<tiles * V, RNT, 0, s>>>(setup, bbox, F, V, R, hard_masks, face_idxs, depths);
         PD_LAUNCH_CHECK();
@@ -345,7 +360,7 @@ extern "C" int pdhip_raster_mesh_ws(const float* pos, int V, int Vn, const int32
     k_raster_init<<<min(cdiv(n, 256), 4096), 256, 0, s>>>(zkey_ws, n);
     if (F > 0) {
         dim3 g(cdiv(F, 64), V);
-        k_raster_faces<<<g, 64, 0, s>>>(pos, Vn, faces, F, R, zkey_ws);
+        k_raster_faces<<<g, 64, 0, s>>>(pos, Vn, faces, F, R, zkey_ws, vps);
     }
     k_raster_resolve<<<min(cdiv(n, 256), 4096), 256, 0, s>>>(zkey_ws, n, hard_masks, face_idxs, depths);
     PD_LAUNCH_CHECK();

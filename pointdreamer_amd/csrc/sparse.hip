@@ -332,8 +332,9 @@ __global__ void k_sparse_compose(const float* __restrict__ colors, int res, int 
                                  const ViewParams* __restrict__ params, const uint8_t* __restrict__ mask_new,
                                  const uint32_t* __restrict__ winA, const uint32_t* __restrict__ winB,
                                  const int32_t* __restrict__ nn_idx, float* __restrict__ sparse,
-                                 float* __restrict__ mask0, float* __restrict__ mask2, float* __restrict__ scale_factors) {
+                                 float* __restrict__ mask0, float* __restrict__ mask2, float* __restrict__ scale_factors, int vps, int N) {
     const int v = blockIdx.y;
+    colors += (size_t)(v / vps) * 3 * (size_t)N;           // several shapes per call: view v shows the cloud of shape v / vps
     const int g2 = (2 * point_size - 1) * (2 * point_size - 1);
     const int ge2 = (2 * edge_point_size - 1) * (2 * edge_point_size - 1);
     if (blockIdx.x == 0 && threadIdx.x == 0) scale_factors[v] = params[v].scale;
@@ -358,10 +359,29 @@ __global__ void k_sparse_compose(const float* __restrict__ colors, int res, int 
     }
 }
 
+static int sparse_impl(const int64_t* point_pixels, const float* colors, const uint8_t* validation, const uint8_t* hard_masks, int V, int vps,
+                       int N, int res, int point_size, int edge_point_size, double mask_ratio_thresh, float* sparse, float* mask0,
+                       float* mask2, float* scale_factors, float* mask_ratios, void* ws, void* stream);
 extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colors, const uint8_t* validation,
                                   const uint8_t* hard_masks, int V, int N, int res, int point_size,
                                   int edge_point_size, double mask_ratio_thresh, float* sparse, float* mask0,
                                   float* mask2, float* scale_factors, float* mask_ratios, void* ws, void* stream) {
+    return sparse_impl(point_pixels, colors, validation, hard_masks, V, V > 0 ? V : 1, N, res, point_size, edge_point_size, mask_ratio_thresh, sparse,
+                       mask0, mask2, scale_factors, mask_ratios, ws, stream);
+}
+// S clouds of N points each, V views per cloud, in ONE set of launches: colors [S,N,3]; every per-view array has S*V leading entries
+// (view g = s * V + v); workspace pdhip_sparse_views_ws_bytes(S * V, N, res).
+extern "C" int pdhip_sparse_views_shapes(const int64_t* point_pixels, const float* colors, const uint8_t* validation,
+                                         const uint8_t* hard_masks, int V, int S, int N, int res, int point_size,
+                                         int edge_point_size, double mask_ratio_thresh, float* sparse, float* mask0,
+                                         float* mask2, float* scale_factors, float* mask_ratios, void* ws, void* stream) {
+    PD_REQUIRE(S >= 1 && V >= 1, "pdhip_sparse_views_shapes: bad sizes");
+    return sparse_impl(point_pixels, colors, validation, hard_masks, S * V, V, N, res, point_size, edge_point_size, mask_ratio_thresh, sparse,
+                       mask0, mask2, scale_factors, mask_ratios, ws, stream);
+}
+static int sparse_impl(const int64_t* point_pixels, const float* colors, const uint8_t* validation, const uint8_t* hard_masks, int V, int vps,
+                       int N, int res, int point_size, int edge_point_size, double mask_ratio_thresh, float* sparse, float* mask0,
+                       float* mask2, float* scale_factors, float* mask_ratios, void* ws, void* stream) {
     (void)mask_ratios;
     PD_REQUIRE(V > 0 && N >= 0 && res > 0 && res <= 32768, "pdhip_sparse_views: bad sizes V=%d N=%d res=%d", V, N, res);
     PD_REQUIRE(point_size >= 1 && edge_point_size >= 1 && point_size <= 8 && edge_point_size <= 8,
@@ -384,7 +404,7 @@ extern "C" int pdhip_sparse_views(const int64_t* point_pixels, const float* colo
         k_sparse_edges<<<dim3(256, V), 256, 0, s>>>(w.edge_list, w.edge_cnt, res, edge_point_size, w.params, w.minidx, w.winB, w.nn_idx);
     }
     k_sparse_compose<<<gm, 256, 0, s>>>(colors, res, point_size, edge_point_size, w.params, w.mask_new, w.winA, w.winB,
-                                        w.nn_idx, sparse, mask0, mask2, scale_factors);
+                                        w.nn_idx, sparse, mask0, mask2, scale_factors, vps, N);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -14,41 +14,51 @@ using namespace pdhip;
 __global__ void k_texel_visibility(const float* __restrict__ cams, int V, const float* __restrict__ gb_pos,
                                      const uint8_t* __restrict__ mask, int A, const float* __restrict__ uv_centers,
                                      const float* __restrict__ uv_scales, float pad9, const float* __restrict__ mesh,
-                                     int R, float offset, uint8_t* __restrict__ vis) {
-    const size_t n = (size_t)A * A;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const bool m = mask[idx];
+                                     int R, float offset, uint8_t* __restrict__ vis, int S) {
+    // S atlases (shapes) in one launch: texel idx of shape s = gidx / A^2; its views are g = s * V + v (cameras shared by the shapes)
+    const size_t n = (size_t)A * A, total = n * (size_t)S;
+    for (size_t gidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t sh = gidx / n, idx = gidx - sh * n;
+        const bool m = mask[gidx];
         float x = 0.f, y = 0.f, z = 0.f;
-        if (m) { x = gb_pos[3 * idx]; y = gb_pos[3 * idx + 1]; z = gb_pos[3 * idx + 2]; }
+        if (m) { x = gb_pos[3 * gidx]; y = gb_pos[3 * gidx + 1]; z = gb_pos[3 * gidx + 2]; }
         for (int v = 0; v < V; ++v) {
+            const size_t g = sh * V + v;
             uint8_t o = 0;
             if (m) {
                 const Cam c = load_cam(cams + 16 * v);
                 float xn, yn, zn;
                 cam_transform(c, x, y, z, xn, yn, zn);
-                float u = ((xn - uv_centers[2 * v]) / uv_scales[v]) * pad9 + 0.5f;
-                float w = ((yn - uv_centers[2 * v + 1]) / uv_scales[v]) * pad9 + 0.5f;
+                float u = ((xn - uv_centers[2 * g]) / uv_scales[g]) * pad9 + 0.5f;
+                float w = ((yn - uv_centers[2 * g + 1]) / uv_scales[g]) * pad9 + 0.5f;
                 int col = clip_to_int(u * (float)R, R - 1);
                 int row = clip_to_int(w * (float)R, R - 1);
-                float ref = mesh[((size_t)v * R + row) * R + col];
+                float ref = mesh[(g * R + row) * R + col];
                 o = ((zn - ref) <= offset) ? 1 : 0;
             }
-            vis[(size_t)v * n + idx] = o;
+            vis[g * n + idx] = o;
         }
     }
 }
 
-extern "C" int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos, const uint8_t* mask, int A,
-                                      const float* uv_centers, const float* uv_scales, double padding,
-                                      const float* mesh_depths, int R, float offset, uint8_t* visibility, void* stream) {
-    PD_REQUIRE(V > 0 && V <= MAXV && A > 0 && R > 0, "pdhip_texel_visibility: bad sizes V=%d A=%d R=%d", V, A, R);
+// S atlases with V views each in ONE launch: gb_pos [S,A,A,3], mask [S,A,A]; cam_params [V] shared by the shapes; uv_centers / uv_scales /
+// mesh_depths / visibility have S*V leading entries (view g = s * V + v).  S = 1: pdhip_texel_visibility.
+extern "C" int pdhip_texel_visibility_shapes(const float* cam_params, int V, int S, const float* gb_pos, const uint8_t* mask, int A,
+                                             const float* uv_centers, const float* uv_scales, double padding,
+                                             const float* mesh_depths, int R, float offset, uint8_t* visibility, void* stream) {
+    PD_REQUIRE(V > 0 && V <= MAXV && A > 0 && R > 0 && S >= 1, "pdhip_texel_visibility: bad sizes V=%d A=%d R=%d S=%d", V, A, R, S);
     PD_REQUIRE(cam_params && gb_pos && mask && uv_centers && uv_scales && mesh_depths && visibility,
                "pdhip_texel_visibility: null pointer");
     const float pad9 = (float)(1.0 - 2.0 * padding);
-    k_texel_visibility<<<min(cdiv((long long)A * A, 256), 4096), 256, 0, as_stream(stream)>>>(
-        cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility);
+    k_texel_visibility<<<min(cdiv((long long)A * A * S, 256), 4096 * min(S, 8)), 256, 0, as_stream(stream)>>>(
+        cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility, S);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
+}
+extern "C" int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos, const uint8_t* mask, int A,
+                                      const float* uv_centers, const float* uv_scales, double padding,
+                                      const float* mesh_depths, int R, float offset, uint8_t* visibility, void* stream) {
+    return pdhip_texel_visibility_shapes(cam_params, V, 1, gb_pos, mask, A, uv_centers, uv_scales, padding, mesh_depths, R, offset, visibility, stream);
 }
 
 // ------------------------------------------------------------------------------ N1-N3
@@ -65,9 +75,10 @@ __device__ __forceinline__ bool scharr_edge(const uint8_t* img, int A, int y, in
 
 // N1: edges_v = scharr(vis_v) & ~scharr(chart mask)
 __global__ void k_nbf_edges(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ vis, int A,
-                            uint8_t* __restrict__ edges) {
+                            uint8_t* __restrict__ edges, int vps) {
     const int v = blockIdx.y;
     const size_t n = (size_t)A * A;
+    mask += (size_t)(v / vps) * n;                          // several atlases per call: view v belongs to shape v / vps
     const uint8_t* vv = vis + (size_t)v * n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         int y = (int)(idx / A), x = (int)(idx - (size_t)y * A);
@@ -163,9 +174,10 @@ __device__ __forceinline__ unsigned long long nbf_edge_word(const unsigned long 
 }
 
 __global__ __launch_bounds__(256) void k_nbf_bits(const unsigned long long* __restrict__ visb, const unsigned long long* __restrict__ maskb,
-                                                  int A, int r, uint8_t* __restrict__ out) {
+                                                  int A, int r, uint8_t* __restrict__ out, int vps) {
     extern __shared__ unsigned long long s_nbf[];           // [rows][W64] edges, then [rows][W64] horizontally dilated
     const int W64 = A >> 6, v = blockIdx.y, y0 = blockIdx.x * NBF_RB;
+    maskb += (size_t)(v / vps) * A * W64;                   // several atlases per call: view v belongs to shape v / vps
     const int rows = NBF_RB + 2 * r;
     unsigned long long* e = s_nbf;
     unsigned long long* h = s_nbf + (size_t)rows * W64;
@@ -199,8 +211,22 @@ __global__ __launch_bounds__(256) void k_nbf_bits(const unsigned long long* __re
     }
 }
 
+static int nbf_impl(const uint8_t* mask, const uint8_t* visibility, int V, int vps, int A, const int32_t* kernels, int K, uint8_t* out,
+                    uint8_t* ws, void* stream);
 extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, int V, int A, const int32_t* kernels,
                                 int K, uint8_t* out, uint8_t* ws, void* stream) {
+    return nbf_impl(mask, visibility, V, V > 0 ? V : 1, A, kernels, K, out, ws, stream);
+}
+// S atlases with V views each in ONE set of launches: mask [S,A,A], visibility [S*V,A,A], out [K][S*V][A][A] (level-major over ALL
+// views), workspace 2 * S * V * A * A bytes.
+extern "C" int pdhip_nbf_shrink_shapes(const uint8_t* mask, const uint8_t* visibility, int V, int S, int A, const int32_t* kernels,
+                                       int K, uint8_t* out, uint8_t* ws, void* stream) {
+    PD_REQUIRE(S >= 1 && V >= 1, "pdhip_nbf_shrink_shapes: bad sizes");
+    return nbf_impl(mask, visibility, S * V, V, A, kernels, K, out, ws, stream);
+}
+static int nbf_impl(const uint8_t* mask, const uint8_t* visibility, int V, int vps, int A, const int32_t* kernels, int K, uint8_t* out,
+                    uint8_t* ws, void* stream) {
+    const int S = V / vps;
     PD_REQUIRE(V > 0 && A > 0 && K > 0 && kernels, "pdhip_nbf_shrink: bad sizes");
     PD_REQUIRE(mask && visibility && out, "pdhip_nbf_shrink: null pointer");
     hipStream_t s = as_stream(stream);
@@ -220,7 +246,7 @@ extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, 
     if (bits_ok) {
         unsigned long long* visb = reinterpret_cast<unsigned long long*>(ws);
         unsigned long long* maskb = visb + (size_t)V * A * (A / 64);
-        const long long vw = (long long)V * A * (A / 64), mw = (long long)A * (A / 64);
+        const long long vw = (long long)V * A * (A / 64), mw = (long long)S * A * (A / 64);
         if ((((uintptr_t)visibility | (uintptr_t)mask) & 15) == 0 && vw % 16 == 0 && mw % 16 == 0) {
             k_pack_bits16<<<min(cdiv((vw + mw) * 4, 256), 4096), 256, 0, s>>>(visibility, vw * 4, visb, mask, mw * 4, maskb);
         } else {
@@ -236,12 +262,12 @@ extern "C" int pdhip_nbf_shrink(const uint8_t* mask, const uint8_t* visibility, 
             }
             const int r = (kernels[k] - 1) / 2;
             const size_t smem = (size_t)2 * (NBF_RB + 2 * r) * (A / 64) * sizeof(unsigned long long);
-            k_nbf_bits<<<dim3(cdiv(A, NBF_RB), V), 256, smem, s>>>(visb, maskb, A, r, out + (size_t)k * n);
+            k_nbf_bits<<<dim3(cdiv(A, NBF_RB), V), 256, smem, s>>>(visb, maskb, A, r, out + (size_t)k * n, vps);
         }
         PD_LAUNCH_CHECK();
         return PDHIP_OK;
     }
-    k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges);
+    k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges, vps);
     for (int k = 0; k < K; ++k) {
         int same = -1;                              // the reference's list repetition yields identical levels: copy them
         for (int j = 0; j < k; ++j) if (kernels[j] == kernels[k]) { same = j; break; }
@@ -306,7 +332,7 @@ extern "C" int pdhip_nbf_triptych(const uint8_t* mask, const uint8_t* visibility
     uint8_t* bg = ws + 2 * n;
     dim3 g(min(cdiv((long long)A * A, 256), 2048), V);
     const int r = (kernel - 1) / 2;
-    k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges);
+    k_nbf_edges<<<g, 256, 0, s>>>(mask, visibility, A, edges, V);
     k_nbf_bg_edges<<<g.x, 256, 0, s>>>(mask, A, bg);
     k_nbf_dilate_h<<<g, 256, 0, s>>>(edges, A, r, tmp);
     k_nbf_triptych<<<dim3(min(cdiv((long long)A * (3 * A + 20), 256), 4096), V), 256, 0, s>>>(visibility, bg, edges, tmp, A, r, out);
@@ -322,24 +348,29 @@ __global__ void k_view_select_blend(const float* __restrict__ cams, int V, const
                                     const float* __restrict__ scale_factors, const uint8_t* __restrict__ shrinked, int K,
                                     const uint8_t* __restrict__ visibility, int complete,
                                     const float* __restrict__ inpainted, int r, float* __restrict__ atlas,
-                                    uint8_t* __restrict__ painted, int32_t* __restrict__ view_ids) {
-    const size_t n = (size_t)A * A;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+                                    uint8_t* __restrict__ painted, int32_t* __restrict__ view_ids, int S, int F) {
+    // S atlases (shapes) in one launch: the per-texel maps and the face normals ([S,F,3]) are stacked by shape, the per-view arrays hold
+    // S*V entries (view g = sh * V + v), the shrunk levels are [K][S*V][A][A]; view ids stay LOCAL to the shape (0 .. V-1)
+    const size_t n = (size_t)A * A, total = n * (size_t)S;
+    for (size_t gidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t sh = gidx / n, idx = gidx - sh * n;
+        const size_t VT = (size_t)S * V;                  // views of the whole call
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
         uint8_t pt = 0;
         int vid = -1;
-        if (mask[idx]) {
+        if (mask[gidx]) {
             // candidate views: level 0, then looser levels only while nothing is visible (unproject.py:324-356)
             uint32_t cand = 0;
             for (int k = 0; k < K; ++k) {
                 if (k > 0 && cand) break;
-                for (int v = 0; v < V; ++v) cand |= (shrinked[((size_t)k * V + v) * n + idx] ? 1u : 0u) << v;
+                for (int v = 0; v < V; ++v) cand |= (shrinked[((size_t)k * VT + sh * V + v) * n + idx] ? 1u : 0u) << v;
             }
             if (complete && !cand)
-                for (int v = 0; v < V; ++v) cand |= (visibility[(size_t)v * n + idx] ? 1u : 0u) << v;
+                for (int v = 0; v < V; ++v) cand |= (visibility[(sh * V + v) * n + idx] ? 1u : 0u) << v;
             // similarity of the face normal with every view direction, softmax in view order
-            const int64_t f = face_id[idx];
-            const float n0 = f_normals[3 * f], n1 = f_normals[3 * f + 1], n2 = f_normals[3 * f + 2];
+            const int64_t f = face_id[gidx];
+            const float* fnp = f_normals + 3 * (sh * (size_t)F + (size_t)f);
+            const float n0 = fnp[0], n1 = fnp[1], n2 = fnp[2];
             float sim[MAXV];
             float mx = -INFINITY;
             for (int v = 0; v < V; ++v) {
@@ -361,23 +392,45 @@ __global__ void k_view_select_blend(const float* __restrict__ cams, int V, const
             if (!complete && !cand) vid = -100;
             if (vid >= 0) {
                 const Cam c = load_cam(cams + 16 * vid);
+                const size_t g = sh * V + vid;
                 float xn, yn, zn;
-                cam_transform(c, gb_pos[3 * idx], gb_pos[3 * idx + 1], gb_pos[3 * idx + 2], xn, yn, zn);
-                float u = (((xn - uv_centers[2 * vid]) / uv_scales[vid]) * scale_factors[vid]) * pad9 + 0.5f;
-                float w = (((yn - uv_centers[2 * vid + 1]) / uv_scales[vid]) * scale_factors[vid]) * pad9 + 0.5f;
+                cam_transform(c, gb_pos[3 * gidx], gb_pos[3 * gidx + 1], gb_pos[3 * gidx + 2], xn, yn, zn);
+                float u = (((xn - uv_centers[2 * g]) / uv_scales[g]) * scale_factors[g]) * pad9 + 0.5f;
+                float w = (((yn - uv_centers[2 * g + 1]) / uv_scales[g]) * scale_factors[g]) * pad9 + 0.5f;
                 int col = clip_to_int(u * (float)r, r - 1);
                 int row = clip_to_int(w * (float)r, r - 1);
-                const float* img = inpainted + (size_t)vid * 3 * r * r + (size_t)(r - 1 - row) * r + col;
+                const float* img = inpainted + g * 3 * r * r + (size_t)(r - 1 - row) * r + col;
                 o0 = img[0]; o1 = img[(size_t)r * r]; o2 = img[2 * (size_t)r * r];
                 pt = 1;
             }
         }
-        atlas[3 * idx] = o0; atlas[3 * idx + 1] = o1; atlas[3 * idx + 2] = o2;
-        painted[idx] = pt;
-        view_ids[idx] = vid;
+        atlas[3 * gidx] = o0; atlas[3 * gidx + 1] = o1; atlas[3 * gidx + 2] = o2;
+        painted[gidx] = pt;
+        view_ids[gidx] = vid;
     }
 }
 
+// S atlases with V views each in ONE launch: gb_pos / mask / face_id / atlas / painted / view_ids stacked [S,A,A,..], f_normals [S,F,3],
+// cam_params / base_dirs [V] shared by the shapes, uv_centers / uv_scales / scale_factors / visibility / inpainted with S*V leading entries,
+// shrinked [K][S*V][A][A]; view ids are local to a shape.  S = 1 (F unused): pdhip_view_select_blend.
+extern "C" int pdhip_view_select_blend_shapes(const float* cam_params, int V, int S, const float* gb_pos, const uint8_t* mask,
+                                              const int64_t* face_id, int A, const float* f_normals, int F, const float* base_dirs,
+                                              const float* uv_centers, const float* uv_scales, double padding,
+                                              const float* scale_factors, const uint8_t* shrinked, int K,
+                                              const uint8_t* visibility, int complete_unseen_by_projection,
+                                              const float* inpainted, int r, float* atlas, uint8_t* painted,
+                                              int32_t* view_ids, void* stream) {
+    PD_REQUIRE(V > 0 && V <= MAXV && A > 0 && K > 0 && r > 0 && S >= 1 && (S == 1 || F > 0), "pdhip_view_select_blend: bad sizes V=%d A=%d K=%d r=%d S=%d", V, A, K, r, S);
+    PD_REQUIRE(cam_params && gb_pos && mask && face_id && f_normals && base_dirs && uv_centers && uv_scales &&
+                   scale_factors && shrinked && visibility && inpainted && atlas && painted && view_ids,
+               "pdhip_view_select_blend: null pointer");
+    const float pad9 = (float)(1.0 - 2.0 * padding);
+    k_view_select_blend<<<min(cdiv((long long)A * A * S, 256), 4096 * min(S, 8)), 256, 0, as_stream(stream)>>>(
+        cam_params, V, gb_pos, mask, face_id, A, f_normals, base_dirs, uv_centers, uv_scales, pad9, scale_factors,
+        shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted, view_ids, S, S == 1 ? 0 : F);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
 extern "C" int pdhip_view_select_blend(const float* cam_params, int V, const float* gb_pos, const uint8_t* mask,
                                        const int64_t* face_id, int A, const float* f_normals, const float* base_dirs,
                                        const float* uv_centers, const float* uv_scales, double padding,
@@ -385,18 +438,10 @@ extern "C" int pdhip_view_select_blend(const float* cam_params, int V, const flo
                                        const uint8_t* visibility, int complete_unseen_by_projection,
                                        const float* inpainted, int r, float* atlas, uint8_t* painted,
                                        int32_t* view_ids, void* stream) {
-    PD_REQUIRE(V > 0 && V <= MAXV && A > 0 && K > 0 && r > 0, "pdhip_view_select_blend: bad sizes V=%d A=%d K=%d r=%d", V, A, K, r);
-    PD_REQUIRE(cam_params && gb_pos && mask && face_id && f_normals && base_dirs && uv_centers && uv_scales &&
-                   scale_factors && shrinked && visibility && inpainted && atlas && painted && view_ids,
-               "pdhip_view_select_blend: null pointer");
-    const float pad9 = (float)(1.0 - 2.0 * padding);
-    k_view_select_blend<<<min(cdiv((long long)A * A, 256), 4096), 256, 0, as_stream(stream)>>>(
-        cam_params, V, gb_pos, mask, face_id, A, f_normals, base_dirs, uv_centers, uv_scales, pad9, scale_factors,
-        shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted, view_ids);
-    PD_LAUNCH_CHECK();
-    return PDHIP_OK;
+    return pdhip_view_select_blend_shapes(cam_params, V, 1, gb_pos, mask, face_id, A, f_normals, 0, base_dirs, uv_centers, uv_scales, padding,
+                                          scale_factors, shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted,
+                                          view_ids, stream);
 }
-
 // ------------------------------------------------------------------------------ compaction
 __global__ void k_compact_count(const uint8_t* __restrict__ mask, int A, int32_t* __restrict__ row_cnt) {
     const int row = blockIdx.x;

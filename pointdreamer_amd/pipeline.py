@@ -141,6 +141,21 @@ def colorize_meshes_batched(shapes, camera_info, view_num, res, cam_res, inpaint
     for sh in shapes:
         _check_options(sh['xatlas'], refine_point_validation_by_remove_abnormal_depth, complete_unseen_by, optimize_from)
     paths = list(save_img_paths) if save_img_paths is not None else [None] * len(shapes)
+    # shapes of equal sizes, plain options: ONE launch per stage for all of them (pointdreamer_amd/shapes.py, pdhip_*_shapes)
+    from . import shapes as _shp
+    if (unused.get('stacked_launches', True) and len(shapes) > 1 and len(shapes) * view_num <= 64 and complete_unseen_by == 'unproject' and
+            optimize_from in (None, 'None') and not refine_point_validation_by_remove_abnormal_depth and all(pth is None for pth in paths) and
+            texture_gen_method in ('nearest', 'linear', 'DDNM_inpaint') and shapes[0]['coords'].is_cuda and _shp.uniform(shapes)):
+        atl = _shp.colorize_shapes(_shp.stack(shapes), camera_info, view_num, res, cam_res, inpainter=inpainter,
+                                   texture_gen_method=texture_gen_method, point_size=point_size, edge_point_size=edge_point_size,
+                                   crop_img=crop_img, crop_padding=crop_padding, mask_ratio_thresh=mask_ratio_thresh,
+                                   edge_dilate_kernels=edge_dilate_kernels, point_validation_by_o3d=point_validation_by_o3d,
+                                   hidden_point_removal_radius=hidden_point_removal_radius)
+        outs = []
+        for i, sh in enumerate(shapes):
+            xat = sh['xatlas']
+            outs.append((sh['vertices'], xat.get('uvs'), sh['faces'], xat.get('mesh_tex_idx'), atl[i], xat['mask']) if return_full else atl[i])
+        return outs
     # The per-shape stages of different shapes are independent and mostly latency-bound (a few hundred wavefronts per kernel): each
     # shape's stages are queued on a HIP stream of its own so that the GPU overlaps them; the inpainter runs on the caller's stream.
     dev = shapes[0]['coords'].device

@@ -223,3 +223,44 @@ def test_skip_conv_folded_into_conv2_k_loop(nn, full_model, N):
     assert not torch.equal(outs[1], outs[0]), "the fold is taken somewhere at this batch (otherwise the test tests nothing)"
     linf, l2 = _rel(outs[1], outs[0])
     assert linf <= 4e-3 and l2 <= 2.5e-3, (N, linf, l2)
+
+
+@pytest.mark.parametrize("method,hpr,crop", [('nearest', True, True), ('nearest', False, False), ('linear', True, True)])
+def test_shapes_batched_equals_per_shape(method, hpr, crop):
+    """BASELINE configs[4] / SURVEY 8(e): S shapes of equal sizes through ONE launch per stage (pdhip_*_shapes: P1, P2, P3b, P4-P6,
+    Uq1-Uq4 with per-shape strides; P2b, P3, I0, Uq5 with S*V images) against colorize_one_mesh shape by shape: every intermediate and
+    the atlas bit for bit.  Different clouds AND different meshes / atlases per shape."""
+    from pointdreamer_amd import pipeline, shapes as shp, synthetic as syn
+    import pointdreamer_amd.camera_utils as cu
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    S, V, R, r, A = 3, 4, 256, 128, 256
+    cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, R, device=DEV)
+    cam_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    shapes = []
+    for s in range(S):
+        verts, faces, lut = syn.uv_sphere(12, 24)
+        verts = (verts * (1.0 - 0.07 * s)).astype(np.float32)                 # a different mesh per shape (same sizes)
+        gb_pos, mask, fid = syn.latlong_atlas(A, 12, 24, gutter=2 + s, lut=lut)
+        gb_pos = (gb_pos * (1.0 - 0.07 * s)).astype(np.float32)
+        x, c = syn.sphere_points(4000, seed=20 + s)
+        x = (x * (1.0 - 0.07 * s)).astype(np.float32)
+        shapes.append(dict(coords=T(x), colors=T(c), vertices=T(verts), faces=T(faces), f_normals=T(syn.face_normals(verts, faces)),
+                           xatlas=dict(gb_pos=T(gb_pos), mask=T(mask), per_atlas_pixel_face_id=T(fid))))
+    assert shp.uniform(shapes)
+    kw = dict(texture_gen_method=method, point_size=1, edge_point_size=1, crop_img=crop, crop_padding=0.05, mask_ratio_thresh=0.82,
+              edge_dilate_kernels=[21, 11], point_validation_by_o3d=hpr)
+    got = shp.colorize_shapes(shp.stack(shapes), cam_info, V, r, R, return_intermediates=True, **kw)
+    for s, sh in enumerate(shapes):
+        ref = pipeline.colorize_one_mesh(sh['coords'], sh['colors'], sh['vertices'], sh['faces'], sh['f_normals'], sh['xatlas'], cam_info,
+                                         V, r, R, complete_unseen_by='unproject', optimize_from=None, return_intermediates=True, **kw)
+        lo, hi = s * V, (s + 1) * V
+        for k in ('point_validation', 'sparse', 'mask0', 'mask2', 'scale_factors', 'mesh_depths', 'visibility', 'shrinked'):
+            assert torch.equal(got[k][lo:hi], ref[k]), (s, k)
+        a, b = got['inpainted'][lo:hi], ref['inpainted']
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (s, 'inpainted')
+        assert torch.equal(got['view_ids'][s], ref['view_ids']) and torch.equal(got['painted'][s], ref['painted'])
+        assert torch.equal(torch.nan_to_num(got['atlas'][s], nan=-7.0), torch.nan_to_num(ref['atlas'], nan=-7.0)), (s, 'atlas')
+    # the batched driver of a directory run takes the same path for uniform batches
+    outs = pipeline.colorize_meshes_batched(shapes, cam_info, V, r, R, complete_unseen_by='unproject', optimize_from=None, **kw)
+    for s in range(S):
+        assert torch.equal(torch.nan_to_num(outs[s], nan=-7.0), torch.nan_to_num(got['atlas'][s], nan=-7.0))
