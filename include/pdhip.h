@@ -317,7 +317,7 @@ int pdhip_debug_set_conv_sk_order(int order);   /* lab hook: tile order of the s
  * w_packed [256][C] f16, bias [256] f32 or NULL; h0 [N,H,W,C], sk [N,H,W,256] f16. */
 int pdhip_gn_silu_skip1x1_nhwc_f16(const void* xa, const void* xb, int Ca, int C, const float* stats, const float* gamma, const float* beta,
                                    const void* w_packed, const float* bias, void* h0, void* sk, int N, int H, int W, void* stream);
-int pdhip_debug_set_gn_skip_variant(int v);   /* lab hook of the one-pass GroupNorm + skip kernel: 0 = two workgroups per CU, 1 (default) = one workgroup per CU with activation chunks requested three K-steps ahead; returns the previous value */
+int pdhip_debug_set_gn_skip_variant(int v);   /* lab hook of the one-pass GroupNorm + skip kernel: 0 = loads requested under the MFMA phase, 1 (default) = activation chunk k + 1 requested at the top of iteration k, 64-pixel tiles where 128-pixel tiles would leave CUs idle (< 256 tiles), 2 = as 1 with 128-pixel tiles always; returns the previous value */
 int pdhip_debug_set_fuse_skip(int mode, int min_tiles);   /* ResBlock GroupNorm-apply + skip 1x1 as one pass: mode 0 never / 1 (default) layers of at least min_tiles 128-pixel tiles (default 1024; <= 0 keeps the value) / 2 every eligible layer; returns the previous mode */
 int pdhip_debug_set_fuse_gn(int on);   /* 1: the UNet uses the fused form wherever the halo kernel serves a conv; 0 (default, measured faster): stand-alone passes */
 /* ---- complete_unseen_by='neighbor' (pointdreamer/unproject.py:93-196, demo.py:180-200).

@@ -452,7 +452,8 @@ constexpr int GS_SMEM = GS_BM * GS_CLD * 2;                 // epilogue staging 
 
 // epilogue shared by the variants: lane holds pixel 16 i + (lane & 15), channels 16 j + 4 (lane >> 4) + r (weights x activations) ->
 // f16(acc + bias) -> LDS -> 16-byte coalesced NHWC rows.  The caller has synchronised: the staging area is free.
-__device__ __forceinline__ void gs_epilogue(const float4_t (&acc)[4][8], char* smem, const float* __restrict__ bias, half_t* __restrict__ SK,
+template <int MI = 4>
+__device__ __forceinline__ void gs_epilogue(const float4_t (&acc)[MI][8], char* smem, const float* __restrict__ bias, half_t* __restrict__ SK,
                                             long long m0, int tid) {
     const int lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
     half_t* const Cs = reinterpret_cast<half_t*>(smem);
@@ -462,8 +463,8 @@ __device__ __forceinline__ void gs_epilogue(const float4_t (&acc)[4][8], char* s
         float4_t bv = (float4_t){0.f, 0.f, 0.f, 0.f};
         if (bias != nullptr) bv = *reinterpret_cast<const float4_t*>(bias + nl);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = wm * 64 + i * 16 + (lane & 15);
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * (16 * MI) + i * 16 + (lane & 15);
             half4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
@@ -473,27 +474,27 @@ __device__ __forceinline__ void gs_epilogue(const float4_t (&acc)[4][8], char* s
     __syncthreads();
     const int col8 = (tid & 31) * 8;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int p = 0; p < 4 * MI; ++p) {
         const int row = p * 8 + (tid >> 5);
         *reinterpret_cast<half8*>(SK + (size_t)(m0 + row) * GS_BN + col8) = *reinterpret_cast<const half8*>(&Cs[row * GS_CLD + col8]);
     }
 }
 // one 64-deep K-step of the skip GEMM on the staged tiles (wave tile 64 px x 128 co); NB weight fragments per batch (register budget)
-template <int NB>
-__device__ __forceinline__ void gs_mfma_step(float4_t (&acc)[4][8], const char* As, const char* Ws, int lane, int wm, int wn) {
+template <int NB, int MI = 4>
+__device__ __forceinline__ void gs_mfma_step(float4_t (&acc)[MI][8], const char* As, const char* Ws, int lane, int wm, int wn) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int fo = ((kk * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
-        half8 a[4];
+        half8 a[MI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(As + (wm * 64 + i * 16 + (lane & 15)) * 128 + fo);
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const half8*>(As + (wm * (16 * MI) + i * 16 + (lane & 15)) * 128 + fo);
 #pragma unroll
         for (int jh = 0; jh < 8 / NB; ++jh) {
             half8 b[NB];
 #pragma unroll
             for (int j = 0; j < NB; ++j) b[j] = *reinterpret_cast<const half8*>(Ws + (wn * 128 + (jh * NB + j) * 16 + (lane & 15)) * 128 + fo);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][jh * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][jh * NB + j], 0, 0, 0);
         }
@@ -582,6 +583,8 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip(const half_t* __restrict__ X
 #define GS1_NB 2
 #endif
 constexpr int GS1_SMEM = GS_SMEM;                           // tiles 48 KiB + constants C * 8 B <= 16 KiB < epilogue staging 66 KiB
+// BM = 128 pixels per workgroup, or 64 (round 4) where 128-pixel tiles would leave CUs idle: the 128^2 level at UNet batch 1 is 128 tiles
+template <int BM>
 __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict__ XA, const half_t* __restrict__ XB, int Ca, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const half_t* __restrict__ Wt,
@@ -589,14 +592,15 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
                                                        int HW) {
     extern __shared__ __align__(16) char gs_smem[];
     char* const As = gs_smem;
-    char* const Ws = gs_smem + GS_BM * 128;
-    float* const Gs = reinterpret_cast<float*>(gs_smem + GS_BM * 128 + GS_BN * 128);   // [C/8][16] = (ga0..7, gb0..7) per channel octet
+    constexpr int MI = BM / 32, RJ = BM / 32;                // 16-pixel row tiles per wave; 32-row load passes per chunk
+    char* const Ws = gs_smem + BM * 128;
+    float* const Gs = reinterpret_cast<float*>(gs_smem + BM * 128 + GS_BN * 128);   // [C/8][16] = (ga0..7, gb0..7) per channel octet
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-    const long long m0 = (long long)blockIdx.x * GS_BM;
+    const long long m0 = (long long)blockIdx.x * BM;
     const int n = (int)(m0 / HW), cg = C / 32, Cb = C - Ca, KC = C / 64;
     const int slot = tid & 7, prow = tid >> 3;
     const int sw = (slot ^ (prow & 7)) << 4;                  // (rows prow + 32 j share prow & 7)
-    half8 xa[2][4], wr[8];
+    half8 xa[2][RJ], wr[8];
     // addressing: wave-uniform 64-bit bases (scalar registers) + 32-bit per-lane byte offsets that do not depend on the chunk
     const unsigned offA = (unsigned)(prow * Ca + slot * 8) * 2u, offB = (unsigned)(prow * Cb + slot * 8) * 2u;   // row prow of XA / XB
     const unsigned offC = (unsigned)(prow * C + slot * 8) * 2u;                                                  // row prow of Wt / H0
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
         const char* const src = gs_uniform(second ? baseB + (size_t)(cu - Ca) * 2 : baseA + (size_t)cu * 2);
         const unsigned off = second ? offB : offA, rs = (unsigned)(second ? Cb : Ca) * 64u;   // 32 rows in bytes
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const half8*>(src + (off + j * rs));
+        for (int j = 0; j < RJ; ++j) dst[j] = *reinterpret_cast<const half8*>(src + (off + j * rs));
     };
     auto issue_w = [&](int kc) {
         const char* const src = gs_uniform(baseW + (size_t)(min(kc, KC - 1) * 64) * 2);
@@ -625,9 +629,9 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
         Gs[(c >> 3) * 16 + (c & 7)] = ga;
         Gs[(c >> 3) * 16 + 8 + (c & 7)] = beta[c] - st[0] * ga;
     }
-    float4_t acc[4][8];
+    float4_t acc[MI][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
     auto gn_part = [&](int kc, const half8* cur) {           // h0 = silu(GN(x)) of chunk kc straight from its registers
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
         const float4_t a0 = gp[0], a1 = gp[1], b0 = gp[2], b1 = gp[3];
         char* const hb = gs_uniform(baseH + (size_t)(kc * 64) * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RJ; ++j) {
             half8 hv;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<half8*>(Ws + (prow + 32 * j) * 128 + sw) = wr[j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<half8*>(As + (prow + 32 * j) * 128 + sw) = cur[j];
+        for (int j = 0; j < RJ; ++j) *reinterpret_cast<half8*>(As + (prow + 32 * j) * 128 + sw) = cur[j];
         issue_acts(kc + 1, nxt);
 #ifndef GS1_GN_LATE
         gn_part(kc, cur);
@@ -658,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
 #ifndef GS1_W_LATE
         issue_w(kc + 1);
 #endif
-        gs_mfma_step<GS1_NB>(acc, As, Ws, lane, wm, wn);
+        gs_mfma_step<GS1_NB, MI>(acc, As, Ws, lane, wm, wn);
 #ifdef GS1_GN_LATE
         // the GroupNorm math needs registers only: same basic block as the MFMAs, interleaved (matrix pipe and VALU overlap in-wave)
         gn_part(kc, cur);
@@ -679,12 +683,12 @@ __global__ __launch_bounds__(256, 2) void k_gn_skip_w1(const half_t* __restrict_
         step(kc + 1, xa[1], xa[0]);
     }
     __syncthreads();
-    gs_epilogue(acc, gs_smem, bias, SK, m0, tid);
+    gs_epilogue<MI>(acc, gs_smem, bias, SK, m0, tid);
 }
 thread_local int g_gs_variant = 1;     // tuning hook (pdhip_debug_set_gn_skip_variant)
 
 bool gn_skip_eligible(int N, int HW, int Ca, int C, int Cout, int Cout_pad) {
-    return Cout == GS_BN && Cout_pad == GS_BN && C % 64 == 0 && Ca % 64 == 0 && Ca > 0 && Ca <= C && ((C / 32) % 8) == 0 && C <= 2048 && HW % GS_BM == 0;
+    return Cout == GS_BN && Cout_pad == GS_BN && C % 64 == 0 && Ca % 64 == 0 && Ca > 0 && Ca <= C && ((C / 32) % 8) == 0 && C <= 2048 && HW % GS_BM == 0 && C % 128 == 0;
 }
 
 int gn_skip(const half_t* XA, const half_t* XB, int Ca, int C, const float* stats, const float* gamma, const float* beta, const half_t* Wt,
@@ -693,12 +697,14 @@ int gn_skip(const half_t* XA, const half_t* XB, int Ca, int C, const float* stat
     static thread_local bool attr_set = false;
     if (!attr_set) {
         PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip, hipFuncAttributeMaxDynamicSharedMemorySize, GS_SMEM));
-        PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip_w1, hipFuncAttributeMaxDynamicSharedMemorySize, GS1_SMEM));
+        PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip_w1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, GS1_SMEM));
+        PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip_w1<64>, hipFuncAttributeMaxDynamicSharedMemorySize, GS1_SMEM));
         attr_set = true;
     }
     const long long tiles = (long long)N * HW / GS_BM;
     if (g_gs_variant == 0) k_gn_skip<<<(int)tiles, 256, GS_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
-    else k_gn_skip_w1<<<(int)tiles, 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
+    else if (tiles < 256 && g_gs_variant != 2) k_gn_skip_w1<64><<<(int)(2 * tiles), 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
+    else k_gn_skip_w1<128><<<(int)tiles, 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -13,6 +13,7 @@ ap.add_argument('--fuse', type=int, default=0, help='pdhip_debug_set_fuse_gn')
 ap.add_argument('--fin', type=int, default=-1, help='pdhip_debug_set_fold_finalize (largest batch with in-kernel GroupNorm statistics; -1 = default)')
 ap.add_argument('--sk', type=int, default=-1, help='pdhip_debug_set_conv_sk mode (0 off, 1 auto, 2 every eligible layer; -1 = default)')
 ap.add_argument('--fskip', type=int, default=-1, help='pdhip_debug_set_fuse_skip mode (0 off, 1 auto, 2 always; -1 = default)')
+ap.add_argument('--gsv', type=int, default=-1, help='pdhip_debug_set_gn_skip_variant (-1 = default)')
 ap.add_argument('--finc', type=int, default=-1, help='pdhip_debug_set_fold_finalize_chunks (-1 = default)')
 ap.add_argument('--out', default='gpurun_out/unet_latency.json')
 ap.add_argument('--graph', type=int, default=0, help='1: also time the forward and the sampler replayed from a HIP graph (torch.cuda.CUDAGraph)')
@@ -25,6 +26,8 @@ if os.environ.get('PDHIP_LAB_LIB'):                      # lab builds: PDHIP_LAB
 _lib.lib().pdhip_debug_set_fuse_gn(a.fuse); _lib.lib().pdhip_debug_set_fold_resample(a.fold)
 if a.fin >= 0:
     _lib.lib().pdhip_debug_set_fold_finalize(a.fin)
+if a.gsv >= 0:
+    _lib.lib().pdhip_debug_set_gn_skip_variant(a.gsv)
 if a.finc >= 0:
     _lib.lib().pdhip_debug_set_fold_finalize_chunks(a.finc)
 if a.fskip >= 0:
