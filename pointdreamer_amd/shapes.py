@@ -16,7 +16,6 @@ import torch
 from . import _lib
 from ._lib import ptr, as_u8, stream, check
 from . import ours_utils as ou
-from . import unproject as up
 from .camera_utils import stack_params
 
 _EYES = {}
