@@ -264,3 +264,32 @@ def test_shapes_batched_equals_per_shape(method, hpr, crop):
     outs = pipeline.colorize_meshes_batched(shapes, cam_info, V, r, R, complete_unseen_by='unproject', optimize_from=None, **kw)
     for s in range(S):
         assert torch.equal(torch.nan_to_num(outs[s], nan=-7.0), torch.nan_to_num(got['atlas'][s], nan=-7.0))
+
+
+def test_meshes_batched_falls_back_for_ragged_or_optioned_batches():
+    """colorize_meshes_batched takes the stacked one-launch-per-stage route only for uniform batches with the plain options; clouds of
+    different sizes, or neighbour completion, go shape by shape on streams as before -- same atlases as colorize_one_mesh either way."""
+    from pointdreamer_amd import pipeline, shapes as shp, synthetic as syn
+    import pointdreamer_amd.camera_utils as cu
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    V, R, r, A = 3, 128, 64, 256
+    cams, base_dirs, eyes, ups = cu.create_cameras(V, 1.6, R, device=DEV)
+    cam_info = dict(cams=cams, base_dirs=base_dirs, eye_positions=eyes, up_dirs=ups)
+    verts, faces, lut = syn.uv_sphere(12, 24)
+    gb_pos, mask, fid = syn.latlong_atlas(A, 12, 24, gutter=2, lut=lut)
+    uvs, fuv = syn.uv_sphere_uvs(12, 24, A, gutter=2)
+    xat = dict(gb_pos=T(gb_pos), mask=T(mask), per_atlas_pixel_face_id=T(fid), uvs=T(uvs), mesh_tex_idx=T(fuv))
+    fn = T(syn.face_normals(verts, faces))
+    mk = lambda n, seed: dict(zip(('coords', 'colors'), map(T, syn.sphere_points(n, seed=seed))), vertices=T(verts), faces=T(faces), f_normals=fn, xatlas=xat)
+    kw = dict(texture_gen_method='nearest', point_size=1, edge_point_size=1, crop_img=True, crop_padding=0.05, mask_ratio_thresh=0.82,
+              edge_dilate_kernels=[21], point_validation_by_o3d=True)
+    ragged = [mk(1500, 1), mk(2100, 2)]
+    assert not shp.uniform(ragged)
+    even = [mk(1800, 3), mk(1800, 4)]
+    assert shp.uniform(even)
+    for batch, extra in ((ragged, dict(complete_unseen_by='unproject')), (even, dict(complete_unseen_by='neighbor')), (even, dict(complete_unseen_by='unproject'))):
+        outs = pipeline.colorize_meshes_batched(batch, cam_info, V, r, R, optimize_from=None, **kw, **extra)
+        for sh, got in zip(batch, outs):
+            ref = pipeline.colorize_one_mesh(sh['coords'], sh['colors'], sh['vertices'], sh['faces'], sh['f_normals'], sh['xatlas'], cam_info,
+                                             V, r, R, optimize_from=None, **kw, **extra)[4]
+            assert torch.equal(got, ref)
