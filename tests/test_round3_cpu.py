@@ -35,3 +35,24 @@ def test_c0_camera_distribution_errors():
         cu.create_cameras(8, 1.6, 64, distribution='self_defined', device=torch.device('cpu'))      # the reference knows 6 or 20 views only
     with pytest.raises(ValueError):
         cu.create_cameras(8, 1.6, 64, distribution='spiral', device=torch.device('cpu'))
+
+
+def test_shapes_uniform_and_stack_host_logic():
+    """pointdreamer_amd/shapes.py (round 4): which batches take the one-launch-per-stage route (equal tensor shapes throughout) and how
+    their inputs are stacked ([S, ...], int32 faces, int64 face ids, the leading singleton of the atlas maps dropped)."""
+    import torch
+    from pointdreamer_amd import shapes as shp
+
+    def mk(n, vn=10, f=7, a=16, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        return dict(coords=torch.rand((n, 3), generator=g), colors=torch.rand((n, 3), generator=g), vertices=torch.rand((vn, 3), generator=g),
+                    faces=torch.randint(0, vn, (f, 3), generator=g), f_normals=torch.rand((f, 3), generator=g),
+                    xatlas=dict(gb_pos=torch.rand((1, a, a, 3), generator=g), mask=torch.rand((1, a, a, 1), generator=g) > 0.5,
+                                per_atlas_pixel_face_id=torch.randint(-1, f, (1, a, a), generator=g)))
+    a, b, c = mk(50, seed=1), mk(50, seed=2), mk(51, seed=3)
+    assert shp.uniform([a, b]) and not shp.uniform([a, c]) and not shp.uniform([a, mk(50, f=8)]) and not shp.uniform([a, mk(50, a=32)])
+    st = shp.stack([a, b])
+    assert st['coords'].shape == (2, 50, 3) and st['faces'].dtype == torch.int32 and st['faces'].shape == (2, 7, 3)
+    assert st['gb_pos'].shape == (2, 16, 16, 3) and st['mask'].shape == (2, 16, 16, 1) and st['face_id'].dtype == torch.int64
+    assert torch.equal(st['coords'][1], b['coords']) and torch.equal(st['face_id'][0], a['xatlas']['per_atlas_pixel_face_id'][0])
+    assert all(t.is_contiguous() for t in st.values())
