@@ -154,6 +154,7 @@ static int oc_scan(const int* in, int n, int* out, int* bsum, int* total, hipStr
 }
 
 
+#define OC_FW_PX 4                                    // pixels per forward thread (sign bytes stored as one word)
 // masked pixel -> its base texel's bucket count
 __global__ void k_oc_count(const float* __restrict__ uv_map, const uint8_t* __restrict__ wmask, int V, int res, int A, int* __restrict__ cntb) {
     const long long total = (long long)V * res * res;
@@ -227,6 +228,9 @@ __global__ void k_oc_records(const int* __restrict__ pix, const int* __restrict_
         const size_t o = (size_t)v * 3 * plane + idx;
         tgt4[i] = make_float4(target[o], target[o + plane], target[o + 2 * plane], __int_as_float(tex));
     }
+    // the forward pass reads whole groups of OC_FW_PX records: the tail group's padding must be finite and in range (base texel 0)
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < OC_FW_PX) { fxy[n + gid] = make_float2(0.f, 0.f); tgt4[n + gid] = make_float4(0.f, 0.f, 0.f, __int_as_float(0)); }
 }
 // texels that receive a contribution (tools / tests: counters[1])
 __global__ void k_oc_nactive(const int* __restrict__ boff, int A, int ntex, int* __restrict__ nact) {
@@ -256,7 +260,6 @@ __global__ void k_oc_pack(const float* __restrict__ atlas, int ntex, float4* __r
 // forward: bilinear lookup (f64), clamp, sign of the L1 residual per channel (0 where the clamp or the residual kills the gradient).
 // sign byte: 2 bits per channel, code = sign + 1.  A thread takes OC_FW_PX consecutive pixels (sorted by base texel: its gathers and
 // its neighbours' hit the same lines) and stores their sign bytes as one word.
-#define OC_FW_PX 4
 __global__ __launch_bounds__(256) void k_oc_forward(const float4* __restrict__ at4, int A, const float2* __restrict__ fxy,
                                                     const float4* __restrict__ tgt4, const int* __restrict__ npix,
                                                     uint8_t* __restrict__ sgn, const int* __restrict__ pix_of, int res,
@@ -454,9 +457,6 @@ extern "C" int pdhip_optimize_color(float* atlas /*[3,A,A] in/out*/, int A, cons
     k_oc_scatter<<<gp, 256, 0, s>>>(uv_map, wmask, V, res, A, boff, cursor, pix);
     const int gw = min(cdiv((long long)tx, 64), 16384);
     k_oc_sortb<<<gw, 64, 0, s>>>(boff, (int)tx, pix);
-    // (the forward pass reads whole groups of OC_FW_PX records: the tail group's padding must be finite and in range)
-    PD_HIP(hipMemsetAsync(fxy, 0, (px + 64) * 8, s));
-    PD_HIP(hipMemsetAsync(tgt4, 0, (px + 64) * 16, s));
     k_oc_records<<<gp, 256, 0, s>>>(pix, npix, uv_map, target, res, A, fxy, tgt4);
     k_oc_nactive<<<min(gt, 256), 256, 0, s>>>(boff, A, (int)tx, nact);
     k_oc_pack<<<gt, 256, 0, s>>>(atlas, (int)tx, at4);
