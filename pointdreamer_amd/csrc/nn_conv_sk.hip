@@ -25,15 +25,19 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
 
+template <int AUX = 0>
 __device__ __forceinline__ void sk_glds16(const void* gsrc, void* lds_wave_base) {
 #ifndef PD_LAB_SK_NOGLDS                                   // (lab builds only: the loop without its L2 -> LDS traffic)
-    __builtin_amdgcn_global_load_lds((sk_gbl_void*)gsrc, (sk_lds_void*)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((sk_gbl_void*)gsrc, (sk_lds_void*)lds_wave_base, 16, 0, AUX);
 #endif
 }
+#ifndef PD_SK_B_AUX
+#define PD_SK_B_AUX 0                                       // cache policy of the weight stream (lab: 2 = nt, 16 = sc1: both bypass the CU's L1)
+#endif
 __device__ __forceinline__ int sk_swz(int row) { return (row >> 1) & 7; }       // 128-byte rows: 16-byte slot ^= (row >> 1) & 7
 
 #ifdef PD_LAB_SK_STAMP                                      // (lab builds only: where one wave's loop time goes, s_memtime cycles)
-__device__ unsigned long long g_sk_stamps[8 * 64];
+__device__ unsigned long long g_sk_stamps[16 * 64];
 #define SK_CLK() __builtin_readcyclecounter()
 #endif
 // s_waitcnt lgkmcnt(n) for a compile-time-unrolled n in [0, 15], tying the A fragment and the B fragments of the group to the wait
@@ -64,8 +68,12 @@ template <int N> __device__ __forceinline__ void sk_wait_vm() { asm volatile("s_
 // (2x2 as before), waves 4-7 only issue the LDS-DMA pieces (wave 4 + w stages what wave w staged): a SIMD then holds one compute
 // wave and one loader wave, and the ~80 cycles a wave's issue slot is blocked per LDS-DMA piece (640 of a 128x128 step's 1 600
 // cycles) run beside the MFMAs of the partner instead of in front of them.
-template <int TAPS, int BM, int BN, int NST, int KG, bool LS>
-__global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
+// NL (LS only): loader waves per workgroup, 4 or 8.  Round 5 (tools/ub/ub_lds.hip, profiles/r05_ub_lds.txt): a wave's issue slot is blocked
+// ~100 cycles per LDS-DMA piece, so FOUR loaders deliver a 128x128 step's 32 pieces in ~810 cycles (40 B/clk) against 544 cycles of MFMA
+// -- the loaders, not the LDS port (ds_read_b128 measured at 256 B/clk, 25 % busy), were the pole of the K-step; EIGHT loaders (two per
+// SIMD beside one compute wave, 12 waves at <= 168 VGPRs) issue in parallel up to the ~60 B/clk the CU's L2 -> LDS path delivers.
+template <int TAPS, int BM, int BN, int NST, int KG, bool LS, int NL = 4>
+__global__ __launch_bounds__(LS ? (4 + NL) * 64 : KG * 256) void k_conv_sk(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
                                                       const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int W, int Cin,
                                                       int Cout, int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, int splits,
                                                       float* __restrict__ slabs, unsigned* __restrict__ tickets, float* __restrict__ gn_part,
@@ -78,14 +86,21 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     constexpr bool SKIPK = TAPS == 10;
     constexpr int XT = SKIPK ? 9 : TAPS;                // taps over X
     constexpr int ROWB = 128, RPI = 8;                 // bytes per tile row (K-step 64), rows per 1 KiB wave-instruction
-    constexpr int LPO = BM / 32, LPB = BN / 32;        // LDS-DMA pieces per wave per K-step: activation rows, weight rows
+    static_assert(NL == 4 || (LS && NL == 8 && BM >= 64 && BN >= 64), "loader waves: 4, or 8 in the loader-specialised form");
+    constexpr int LPO = BM / (8 * NL), LPB = BN / (8 * NL);   // LDS-DMA pieces per loading wave per K-step: activation rows, weight rows
+#if defined(PD_LAB_SK_NOA)                                 // (lab: fill diagnostics -- one operand stream compiled out)
+    constexpr int OPS = LPB;
+#elif defined(PD_LAB_SK_NOB)
+    constexpr int OPS = LPO;
+#else
     constexpr int OPS = LPO + LPB;
+#endif
     constexpr int TM = BM / 32, TN = BN / 32;          // accumulator tiles per wave (wave tile BM/2 x BN/2)
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int CS_LD = BN + 8;
     constexpr int D = NST - 1;                         // prefetch distance
     static_assert(!LS || KG == 1, "loader specialisation replaces the K-groups");
-    constexpr int NT = (LS ? 2 : KG) * 256;
+    constexpr int NT = LS ? (4 + NL) * 64 : KG * 256;
     constexpr int RING_BYTES = NST * STAGE_BYTES;
     constexpr int FLAG_OFF = KG * RING_BYTES;          // "I drew the last ticket" (ONE __shared__ object: cdna guide section 5 trap 4a)
     static_assert(NST >= 2 && NST <= 8 && OPS * (NST - 2) <= 63, "stage count / vmcnt range");
@@ -95,6 +110,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (provably wave-uniform: LDS-DMA bases stay in SGPRs)
     const int grp = LS ? 0 : wave >> 2, w4 = wave & 3, t4 = tid & 255;
+    const int lw = LS ? (wave >= 4 ? wave - 4 : 0) : w4;   // index among the NL loading waves
     const bool loader = !LS || wave >= 4, consumer = !LS || wave < 4;      // LS: the role of this wave
     const int wm = w4 >> 1, wn = w4 & 1;
     // XCD-aware work id: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (tile, split) ids, so the K-slices of a
@@ -128,7 +144,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     const half_t* bp[LPB];
 #pragma unroll
     for (int i = 0; i < LPO; ++i) {
-        const int r = w4 * (BM / 4) + i * RPI + lrow;
+        const int r = lw * (BM / NL) + i * RPI + lrow;
         const int c = lpos ^ sk_swz(r);
         const int m = m0 + r;
         const bool inm = m < M;
@@ -152,36 +168,59 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     }
 #pragma unroll
     for (int i = 0; i < LPB; ++i) {
-        const int r = w4 * (BN / 4) + i * RPI + lrow;
+        const int r = lw * (BN / NL) + i * RPI + lrow;
         bp[i] = Wt + (size_t)(n0 + r) * K + (lpos ^ sk_swz(r)) * 8;
     }
     const int it0 = (int)((long long)KI * split / splits), it1 = (int)((long long)KI * (split + 1) / splits);
     char* const ring = smem + grp * RING_BYTES;
-    char* const wave_dst_a = ring + w4 * ((BM / 4) * ROWB);
-    char* const wave_dst_b = ring + A_BYTES + w4 * ((BN / 4) * ROWB);
+    char* const wave_dst_a = ring + lw * ((BM / NL) * ROWB);
+    char* const wave_dst_b = ring + A_BYTES + lw * ((BN / NL) * ROWB);
     // (tap, channel chunk) of the group's next K-step to issue: scalars advanced by KG steps per issue (no division in the loop)
     int is_tap = 0, is_nc = 0;
     auto issue = [&](int stage, int it) {                 // all pieces of K-step `it` (wave-uniform) into `stage` of this group's ring
         const int tap = is_tap, nc = is_nc;
+#ifndef PD_LAB_SK_TAPMAJOR
+        // K order (round 5): chunk-major -- the nine taps of a 64-channel chunk back to back, then the next chunk (weights stay
+        // [Cout_pad][tap * Cin + c]: only the order in which the K-steps are walked changes).  Consecutive steps then re-read the same
+        // activation lines shifted by one pixel / one row; tap-major walked all Cin / 64 chunks of a tap first, 64 KB of other lines
+        // between two uses of a line.  1-8 % on every 3x3 layer (profiles/r05_sk_order.txt); the f32 summation order is a fixed
+        // function of the layer either way.
+        if (TAPS == 1 || is_tap >= XT) is_nc += KG;
+        else { is_tap += KG; while (is_tap >= XT && is_nc + 1 < kc) { is_tap -= XT; ++is_nc; } if (is_tap >= XT) { is_nc = is_tap - XT; is_tap = XT; } }
+#else
         is_nc += KG;
         while (TAPS != 1 && is_tap < XT && is_nc >= kc) { is_nc -= kc; ++is_tap; }
+#endif
         const int dy = (TAPS == 1) ? 0 : tap / 3 - 1, dx = (TAPS == 1) ? 0 : tap - (tap / 3) * 3 - 1;
         const bool second = TAPS == 1 && X2 != nullptr && nc * 64 >= Cin1;
         const long long koff = second ? (long long)nc * 64 - Cin1 : ((long long)dy * W + dx) * Cin1 + (long long)nc * 64;
         const bool skp = SKIPK && tap == 9;               // (wave-uniform) the appended 1x1 over the block input
         const bool skp2 = skp && nc * 64 >= Cs1;
+#ifndef PD_LAB_SK_NOA
 #pragma unroll
         for (int p = 0; p < LPO; ++p) {
             const half_t* src = (second ? abase2[p] : abase[p]) + koff;
             if (skp) {
-                const int cc = (lpos ^ sk_swz(w4 * (BM / 4) + p * RPI + lrow)) * 8;
+                const int cc = (lpos ^ sk_swz(lw * (BM / NL) + p * RPI + lrow)) * 8;
                 src = skp2 ? XS2 + (size_t)apix[p] * (unsigned)(Cskip - Cs1) + (nc * 64 - Cs1) + cc : XS + (size_t)apix[p] * (unsigned)Cs1 + nc * 64 + cc;
             }
-            if (((amask[p] >> tap) & 1u) == 0u) src = zero_page + ((lpos ^ sk_swz(w4 * (BM / 4) + p * RPI + lrow)) * 8 & 63);
+            if (((amask[p] >> tap) & 1u) == 0u) src = zero_page + ((lpos ^ sk_swz(lw * (BM / NL) + p * RPI + lrow)) * 8 & 63);
             sk_glds16(src, wave_dst_a + stage * STAGE_BYTES + p * 1024);
         }
+#endif
+#ifndef PD_LAB_SK_NOB
+#ifdef PD_LAB_SK_ROT                                        // (lab: every workgroup walks the weight rows' K range from another start)
+        const int itb = (it + wid * PD_LAB_SK_ROT) % KI;
+#else
+#ifndef PD_LAB_SK_TAPMAJOR
+        const int itb = (TAPS == 1 || tap >= XT) ? it : tap * kc + nc;
+#else
+        const int itb = it;
+#endif
+#endif
 #pragma unroll
-        for (int p = 0; p < LPB; ++p) sk_glds16(bp[p] + (size_t)it * 64, wave_dst_b + stage * STAGE_BYTES + p * 1024);
+        for (int p = 0; p < LPB; ++p) sk_glds16<PD_SK_B_AUX>(bp[p] + (size_t)itb * 64, wave_dst_b + stage * STAGE_BYTES + p * 1024);
+#endif
     };
 
     // ---- consumer role
@@ -196,7 +235,11 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
 
     // this group's K-steps: g0, g0 + KG, ...; `mine` of them.  Every group runs `iters` loop trips (the barrier counts must match).
     const int g0 = it0 + grp;
+#ifndef PD_LAB_SK_TAPMAJOR
+    if (TAPS == 1) is_nc = g0; else if (g0 >= XT * kc) { is_tap = XT; is_nc = g0 - XT * kc; } else { is_nc = g0 / XT; is_tap = g0 - is_nc * XT; }
+#else
     if (TAPS == 1) is_nc = g0; else { is_tap = min(g0 / kc, XT); is_nc = g0 - is_tap * kc; }
+#endif
     const int mine = g0 < it1 ? (it1 - g0 + KG - 1) / KG : 0;
     const int iters = (it1 - it0 + KG - 1) / KG;
     if (loader) {
@@ -206,7 +249,7 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     }
     int cur = 0, nxt = D % NST;
 #ifdef PD_LAB_SK_STAMP
-    unsigned long long lab_w = 0, lab_b = 0, lab_i = 0, lab_c = 0, lab_t, lab_u;
+    unsigned long long lab_w = 0, lab_b = 0, lab_i = 0, lab_c = 0, lab_t, lab_u, lab_f[4] = {0, 0, 0, 0};
     const unsigned long long lab_start = SK_CLK();
 #endif
     for (int k = 0; k < iters; ++k) {
@@ -240,36 +283,75 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
 #ifdef PD_LAB_SK_STAMP
         lab_u = SK_CLK(); lab_i += lab_u - lab_t; lab_t = lab_u;
 #endif
+#ifdef PD_LAB_SK_NOCOMPUTE
+        if (false) {                                       // (lab: the loop without its fragment reads and MFMAs -- the fill alone)
+#else
         if (consumer && k < mine) {
-            // All 2 (TM + TN) fragment reads of the K-step are issued at once (inline asm: hipcc waits lgkmcnt(0) in front of every
-            // batch of MFMAs, which left one compute wave per SIMD exposed to four LDS round trips per step -- 1 017 cycles for the
-            // 544 cycles of a 128x128 step's MFMAs, tools/lab_sk.sh stamp); the MFMA groups then follow the reads with counted waits
-            // (LDS returns in issue order: group (kk, i) may leave the reads issued after its own A fragment in flight).
+#endif
+            // Fragment reads by inline asm with counted lgkmcnt waits in front of each MFMA group (hipcc waits lgkmcnt(0) before every
+            // batch of MFMAs; LDS returns in issue order).  Round 5: only k-half 0's TM + TN reads go out before the first MFMA; the reads
+            // of k-half 1 follow the groups of k-half 0 in equal shares.  Issued all at once (round 3) the wave sat ~210 cycles in the
+            // ISSUE of 16 ds_read_b128 -- four waves share a port that serves one read per 4 cycles -- before its first wait could even
+            // execute (fine stamps, profiles/r05_sk_loop_stamps.txt: first group at cycle 220, MFMAs back to back from there).
             const uint32_t a_ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + cur * STAGE_BYTES + (wm * (BM / 2)) * ROWB);
             const uint32_t b_ad = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring + cur * STAGE_BYTES + A_BYTES + (wn * (BN / 2)) * ROWB);
             half8 fa[2][TM], fb[2][TN];
-            constexpr int RPK = TM + TN, RTOT = 2 * RPK;
+            constexpr int RPK = TM + TN;
+#ifdef PD_LAB_SK_STAMP
+            // fine stamps: s_memtime WITHOUT a wait (a waited stamp is an lgkmcnt(0) in the middle of the counted waits; an outstanding
+            // one can only make a counted wait conservative), read behind the phase's final lgkmcnt(0)
+            unsigned long long f_a, f_b, f_c = 0, f_d = 0, f_e = 0;
+            asm volatile("s_memtime %0" : "=s"(f_a));
+#endif
 #define SK_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+            const uint32_t ba0 = b_ad + frag_off[0], aa0 = a_ad + frag_off[0], ba1 = b_ad + frag_off[1], aa1 = a_ad + frag_off[1];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const uint32_t ba = b_ad + frag_off[kk], aa = a_ad + frag_off[kk];
+            for (int j = 0; j < TN; ++j) SK_DSR(fb[0][j], ba0, j * 16 * ROWB);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) SK_DSR(fb[kk][j], ba, j * 16 * ROWB);
+            for (int i = 0; i < TM; ++i) SK_DSR(fa[0][i], aa0, i * 16 * ROWB);
+#ifdef PD_LAB_SK_READS_UPFRONT
 #pragma unroll
-                for (int i = 0; i < TM; ++i) SK_DSR(fa[kk][i], aa, i * 16 * ROWB);
-            }
-#undef SK_DSR
+            for (int j = 0; j < TN; ++j) SK_DSR(fb[1][j], ba1, j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) SK_DSR(fa[1][i], aa1, i * 16 * ROWB);
+#endif
+#ifdef PD_LAB_SK_STAMP
+            asm volatile("s_memtime %0" : "=s"(f_b));
+#endif
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int idx = kk * RPK + TN + i;                      // issue index of this group's A fragment
-                    sk_wait_lgkm_tied<TN>(RTOT - 1 - idx, fa[kk][i], fb[kk]);
+#ifdef PD_LAB_SK_READS_UPFRONT
+                    const int q_lo = RPK, q_hi = RPK;
+#else
+                    const int q_lo = (i * RPK) / TM, q_hi = ((i + 1) * RPK) / TM;      // k-half 1 reads issued behind group (0, i)
+#endif
+                    // outstanding reads this group may leave in flight: everything issued behind its own A fragment
+                    const int allowed = kk == 0 ? RPK + q_lo - (TN + i + 1) : TM - 1 - i;
+                    sk_wait_lgkm_tied<TN>(allowed, fa[kk][i], fb[kk]);
+#ifdef PD_LAB_SK_STAMP
+                    if (kk == 0 && i == 0) asm volatile("s_memtime %0" : "=s"(f_c));
+                    if (kk == 1 && i == 0) asm volatile("s_memtime %0" : "=s"(f_d));
+                    if (kk == 1 && i == TM - 1) asm volatile("s_memtime %0" : "=s"(f_e));
+#endif
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                    if (kk == 0) {
+#pragma unroll
+                        for (int q = 0; q < RPK; ++q) {
+                            if (q < q_lo || q >= q_hi) continue;
+                            if (q < TN) SK_DSR(fb[1][q < TN ? q : 0], ba1, (q < TN ? q : 0) * 16 * ROWB);
+                            else SK_DSR(fa[1][q >= TN ? q - TN : 0], aa1, (q >= TN ? q - TN : 0) * 16 * ROWB);
+                        }
+                    }
                 }
             }
+#undef SK_DSR
+#ifdef PD_LAB_SK_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(f_a), "+s"(f_b), "+s"(f_c), "+s"(f_d), "+s"(f_e));   // (the stamps have landed; tied: no use above this line)
+            lab_f[0] += f_b - f_a; lab_f[1] += f_c - f_a; lab_f[2] += f_d - f_a; lab_f[3] += f_e - f_a;
+#endif
         }
 #ifdef PD_LAB_SK_STAMP
         asm volatile("" : "+v"(acc[0][0]));
@@ -281,8 +363,9 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     }
 #ifdef PD_LAB_SK_STAMP
     if (lane == 0 && blockIdx.x == 8 && wave < 8) {
-        unsigned long long* o = g_sk_stamps + wave * 8;
+        unsigned long long* o = g_sk_stamps + wave * 16;
         o[0] = lab_w; o[1] = lab_b; o[2] = lab_i; o[3] = lab_c; o[4] = SK_CLK() - lab_start; o[5] = iters; o[6] = lab_start;
+        o[8] = lab_f[0]; o[9] = lab_f[1]; o[10] = lab_f[2]; o[11] = lab_f[3];
     }
 #endif
     __syncthreads();                                       // all fragment reads done before the stages are reused
@@ -431,13 +514,28 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
         red[tid * 2] = gs[0]; red[tid * 2 + 1] = gq[0];
         red[(NT + tid) * 2] = gs[1]; red[(NT + tid) * 2 + 1] = gq[1];
         __syncthreads();
+        // two-level, fixed-order column sums (round 5).  One thread per (segment, octet) summing all RPP rows was a serial chain that
+        // hipcc unrolled into RPP x 2 loads in flight -- 256 VGPRs and a spill on the 64x32 tiles, ~2 000 cycles at the tail of every
+        // launch; now 8 threads per (segment, octet) take every 8th row each, one thread adds the 8 sub-sums in order.
         const int nseg = BM / seg_rows;
+        constexpr int SUB = 8;
+        static_assert(RPP % SUB == 0 && (2 * NT + 2 * 2 * CT * SUB) * 8 <= (LS ? 1 : KG) * RING_BYTES, "GroupNorm partial reduce staging");
+        float* red2 = red + 2 * NT * 2;                    // [segment][octet][SUB][2]
+        if (tid < CT * nseg * SUB) {
+            const int j = tid % SUB, c = (tid / SUB) % CT, seg = tid / (SUB * CT);
+            float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP / SUB; ++r) { s1 += red[(seg * NT + (r * SUB + j) * CT + c) * 2]; q1 += red[(seg * NT + (r * SUB + j) * CT + c) * 2 + 1]; }
+            red2[tid * 2] = s1; red2[tid * 2 + 1] = q1;
+        }
+        __syncthreads();
         if (tid < CT * nseg) {
             const int seg = tid / CT, c = tid - seg * CT;
             const int img = m0 / HWp + seg;
             if (n0 + c * 8 < Cout && img < N) {
                 float s1 = 0.f, q1 = 0.f;
-                for (int r = 0; r < RPP; ++r) { s1 += red[(seg * NT + r * CT + c) * 2]; q1 += red[(seg * NT + r * CT + c) * 2 + 1]; }
+#pragma unroll
+                for (int j = 0; j < SUB; ++j) { s1 += red2[(tid * SUB + j) * 2]; q1 += red2[(tid * SUB + j) * 2 + 1]; }
                 const int chunks = HWp >= BM ? HWp / BM : 1;
                 const int chunk = HWp >= BM ? (m0 - (m0 / HWp) * HWp) / BM : 0;
                 float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + c) * 2;
@@ -447,15 +545,15 @@ __global__ __launch_bounds__((LS ? 2 : KG) * 256) void k_conv_sk(const half_t* _
     }
 }
 
-template <int TAPS, int BM, int BN, int NST, int KG, bool LS = false>
+template <int TAPS, int BM, int BN, int NST, int KG, bool LS = false, int NL = 4>
 int launch_sk(int grid, hipStream_t s, const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H,
               int W, int Cin, int Cout, int n_tiles, int total, const half_t* zero_page, int splits, float* slabs, unsigned* tickets,
               float* gnp, const half_t* X2, int Cin1, int m_fast, const half_t* XS = nullptr, const half_t* XS2 = nullptr, int Cs1 = 0, int Cs = 0, int res_up = 0) {
-    auto kern = k_conv_sk<TAPS, BM, BN, NST, KG, LS>;
+    auto kern = k_conv_sk<TAPS, BM, BN, NST, KG, LS, NL>;
     constexpr size_t smem = (size_t)KG * NST * (BM + BN) * 128 + 16;
     static_assert(smem <= 160 * 1024, "LDS budget");
     if (smem > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    kern<<<grid, (LS ? 2 : KG) * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast, XS, XS2, Cs1, Cs, res_up);
+    kern<<<grid, LS ? (4 + NL) * 64 : KG * 256, smem, s>>>(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, splits, slabs, tickets, gnp, X2, Cin1, m_fast, XS, XS2, Cs1, Cs, res_up);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -561,6 +659,14 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     if (kg == 0) kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 8 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
 #define SK_L(T, BM_, BN_, NST_, KG_) launch_sk<T, BM_, BN_, NST_, KG_>(SK_ARGS)
 #define SK_LS(T, BM_, BN_, NST_) launch_sk<T, BM_, BN_, NST_, 1, true>(SK_ARGS)
+#define SK_LS8(T, BM_, BN_, NST_) launch_sk<T, BM_, BN_, NST_, 1, true, 8>(SK_ARGS)
+    if (kg == 12 && pl.tile_id > 2) kg = 8;                // (the 8-loader form exists for the 128-row tiles)
+    if (kg == 12) {                                        // loader-specialised, EIGHT loader waves (hook value 12): 128x128 and 128x64 tiles
+        if (taps == 9) return pl.tile_id == 1 ? (st == 2 ? SK_LS8(9, 128, 128, 2) : st == 4 ? SK_LS8(9, 128, 128, 4) : SK_LS8(9, 128, 128, 3))
+                                              : (st == 3 ? SK_LS8(9, 128, 64, 3) : SK_LS8(9, 128, 64, 4));
+        return pl.tile_id == 1 ? (st == 2 ? SK_LS8(1, 128, 128, 2) : st == 4 ? SK_LS8(1, 128, 128, 4) : SK_LS8(1, 128, 128, 3))
+                               : (st == 3 ? SK_LS8(1, 128, 64, 3) : SK_LS8(1, 128, 64, 4));
+    }
     if (kg == 8) {                                         // loader-specialised form (hook value 8)
         if (taps == 9) return pl.tile_id == 1 ? (st == 2 ? SK_LS(9, 128, 128, 2) : st == 4 ? SK_LS(9, 128, 128, 4) : SK_LS(9, 128, 128, 3))
                             : pl.tile_id == 2 ? (st == 2 ? SK_LS(9, 128, 64, 2) : st == 3 ? SK_LS(9, 128, 64, 3) : SK_LS(9, 128, 64, 4))
@@ -583,6 +689,7 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
 #undef SK_TILE
 #undef SK_L
 #undef SK_LS
+#undef SK_LS8
 #undef SK_ARGS
 }
 

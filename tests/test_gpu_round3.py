@@ -154,7 +154,7 @@ def test_conv_sk_small_m_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, k, res, ti
     old = L.pdhip_debug_set_conv_sk(2 if tile else 1, tile, splits)
     ref = F.conv2d(x, w, b, padding=k // 2) + (r if res else 0)
     try:
-        for kg in (0, 1, 2, 4, 8):                  # K-groups per workgroup (4-wave groups on alternate K-steps of one tile); 8 = loader-specialised
+        for kg in (0, 1, 2, 4, 8, 12):              # K-groups per workgroup (4-wave groups on alternate K-steps of one tile); 8 = loader-specialised, 12 = with eight loader waves
             L.pdhip_debug_set_conv_sk_kgroups(kg)
             y1 = hip_conv(nn, x, w, b, r)
             y2 = hip_conv(nn, x, w, b, r)

@@ -16,6 +16,8 @@ SHAPES = [  # (N, H, W, Cin, Cout, taps)
     (8, 256, 256, 512, 256, 1), (8, 128, 128, 512, 256, 1), (32, 32, 32, 512, 1536, 1)]
 ap = argparse.ArgumentParser()
 ap.add_argument('--shapes', type=int, nargs='*', default=None)
+ap.add_argument('--shape', type=int, nargs=6, action='append', default=None, metavar=('N', 'H', 'W', 'CIN', 'COUT', 'TAPS'), help='an extra layer (repeatable); runs instead of the table')
+ap.add_argument('--no-old', action='store_true', help='skip the igemm + reduce comparison')
 ap.add_argument('--tiles', type=int, nargs='*', default=[1, 2, 3, 4])
 ap.add_argument('--splits', type=int, nargs='*', default=[0, 1, 2, 4, 8, 16, 32])
 ap.add_argument('--stages', type=int, nargs='*', default=[0])
@@ -26,6 +28,8 @@ ap.add_argument('--fixed', action='store_true')
 ap.add_argument('--stamps', action='store_true', help='lab stamp build: print the per-wave loop time split of the last launch')
 ap.add_argument('--lib', default=None, help='alternative libpdhip.so (tools/lab_unit.sh NAME nn_conv_sk -D... builds)')
 a = ap.parse_args()
+if a.shape:
+    SHAPES = [tuple(x) for x in a.shape]; a.shapes = None
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
 L = _lib.lib()
@@ -59,7 +63,7 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
         return e0.elapsed_time(e1) / a.iters * 1e3
     L.pdhip_debug_set_conv_splitk(P(ws), ws.numel(), 0)
     old = L.pdhip_debug_set_conv_sk(0, 0, 0)
-    t_old = timed()
+    t_old = 0.0 if a.no_old else timed()
     print(f"N{N} {H}x{W} Cin{Cin} Cout{Cout} taps{taps}  {fl/1e9:6.1f} GFLOP  weights {wbytes/1e6:5.1f} MB x{nb}   igemm+reduce {t_old:6.1f} us")
     for st, kg in [(s_, k_) for k_ in a.kg for s_ in a.stages]:
         L.pdhip_debug_set_conv_sk_stages(st); L.pdhip_debug_set_conv_sk_kgroups(kg)
@@ -72,13 +76,14 @@ for si, (N, H, W, Cin, Cout, taps) in enumerate(SHAPES):
                 row.append(f"s{sp}:{timed():6.1f}")
                 if a.stamps:
                     import numpy as np
-                    buf = (C.c_ulonglong * 512)()
+                    buf = (C.c_ulonglong * 1024)()
                     fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_sk_read_stamps
-                    assert fn(buf, 512) == 0
-                    st_ = np.array(buf, dtype=np.uint64).astype(np.int64).reshape(64, 8)[:8]
+                    assert fn(buf, 1024) == 0
+                    st_ = np.array(buf, dtype=np.uint64).astype(np.int64).reshape(64, 16)[:8]
                     for r in st_:
                         n_ = max(int(r[5]), 1)
-                        row.append(f"\n        [steps {n_}: per step wait {r[0]/n_:6.0f} barrier {r[1]/n_:6.0f} issue {r[2]/n_:6.0f} compute {r[3]/n_:6.0f} | loop {r[4]/n_:6.0f} cyc]")
+                        row.append(f"\n        [steps {n_}: per step wait {r[0]/n_:6.0f} barrier {r[1]/n_:6.0f} issue {r[2]/n_:6.0f} compute {r[3]/n_:6.0f} | loop {r[4]/n_:6.0f} cyc"
+                                   f" | compute phase from its first ds_read: reads issued {r[8]/n_:5.0f}, first group may start {r[9]/n_:5.0f}, k-half 1 may start {r[10]/n_:5.0f}, last wait passed {r[11]/n_:5.0f}]")
             if row:
                 print(f"   kg {kg} stages {st} tile {tile}: " + "  ".join(row))
     L.pdhip_debug_set_conv_sk_stages(0); L.pdhip_debug_set_conv_sk_kgroups(0)
