@@ -138,6 +138,13 @@ def random_weights(cfg, seed=0, std=0.02):
     return w
 
 
+def boost_out_layers(w, factor):
+    """Large-activation variant of a weight set (tests/golden/unet_small_fp16.npz): every ResBlock's second conv (`out_layers.3`,
+    weight and bias) scaled by `factor`, so that the residual stream grows to f16's upper range (factor 4096: max |activation| 4.8e4 in
+    the reference's fp16 forward) or past it (6144: one image of the fixture overflows to inf -> NaN, the other stays finite)."""
+    return {k: (v * factor if '.out_layers.3.' in k else v) for k, v in w.items()}
+
+
 def timestep_embedding(timesteps, dim, max_period=10000):
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)

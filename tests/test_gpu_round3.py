@@ -13,7 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
+from conftest import load_golden, note_measured, U1_FP32_LINF, U1_FP32_L2
 from oracle import unet as ounet
 
 pytestmark = pytest.mark.gpu
@@ -121,7 +121,8 @@ def test_unet_small_batch_routing_variants(nn, full_model):
             assert torch.equal(outs[(fin, sk)], again), "a forward is deterministic (fixed-order in-launch split-K combine)"
             for b in range(N):
                 linf, l2 = _rel(outs[(fin, sk)][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))
-                assert linf <= 2e-2 and l2 <= 5e-3, (N, fin, sk, b, linf, l2)
+                note_measured(test='unet_full_fp32_routing', batch=N, fin=fin, sk=sk, linf=linf, l2=l2)
+                assert linf <= U1_FP32_LINF and l2 <= U1_FP32_L2, (N, fin, sk, b, linf, l2)
         for key in ((0, 1), (4, 0), (0, 0)):
             linf, l2 = _rel(outs[(4, 1)], outs[key])
             assert linf <= 4e-3 and l2 <= 2.5e-3, (N, key, linf, l2)   # (two f16 routings of the same net: both inside the U1 budget, and this close to each other)

@@ -1,0 +1,96 @@
+"""Round-5 GPU parity tests: U1 pinned to the reference's OWN fp16 forward (configs/imagenet_256.yml:26 use_fp16: true,
+diffusion.py:438-439 convert_to_fp16(), unet.py:619-625 / 655-663, fp16_util.py:15-22, nn.py:17-19) -- fixtures
+tests/golden/unet_small_fp16.npz / unet_full_fp16.npz written by tools/gen_golden_nn.py small16 / full16 from the imported reference
+run on the CPU -- including the f16 RANGE behaviour: a large-activation weight set (residual stream at 3-5e4, f16's top binade) and one
+that overflows one image of a batch (inf -> NaN in the reference; the engine must lose exactly that image and keep the other)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import unet as ounet
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+MEASURED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'r05_u1_measured.jsonl')
+
+# Bounds = 2x the largest value measured on the GPU boxes of the round (profiles/r05_u1_bounds.txt); relative L-inf / relative L2.
+FP16_SMALL = (4.2e-3, 3.4e-3)          # engine vs the reference's fp16 forward, 64^2 / 32-channel config; measured 2.06e-3 / 1.68e-3
+FP16_FULL = (2.3e-3, 2.4e-3)           # ... full 256^2 / 552.8 M-parameter config, batch 1 and 8; measured 1.15e-3 / 1.20e-3
+FP16_LARGE_SMALL = (5.5e-3, 4.7e-3)    # ... large-activation weight set (x 4096: peak |activation| 3.5e4), small config; measured 2.74e-3 / 2.32e-3
+FP16_LARGE_FULL = (3.8e-3, 3.3e-3)     # ... (x 2048 / x 4096: peaks 2.1e4 / 4.3e4), full config; measured 1.86e-3 / 1.63e-3
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).norm() / b.norm()).item()
+
+
+def _note(**kw):
+    os.makedirs(os.path.dirname(MEASURED), exist_ok=True)
+    with open(MEASURED, 'a') as f:
+        f.write(json.dumps(kw) + '\n')
+
+
+@pytest.fixture(scope="module")
+def nn():
+    assert torch.cuda.is_available()
+    from pointdreamer_amd import _lib
+    import pointdreamer_amd.ddnm_inpainting as di
+    return dict(L=_lib.lib(), lib=_lib, di=di)
+
+
+def test_unet_small_vs_reference_fp16_forward_and_f16_range(nn):
+    g16, g = load_golden('unet_small_fp16.npz'), load_golden('unet_small.npz')
+    cfg = ounet.make_config(int(g['cfg_image_size']), int(g['cfg_channels']), 2, "32,16,8", int(g['cfg_head']), True)
+    w = ounet.random_weights(cfg, int(g16['seed']))
+    x, t = torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['t']).to(DEV)
+    kw = dict(image_size=cfg['image_size'], num_channels=cfg['model_channels'], num_head_channels=cfg['num_head_channels'], max_batch=2, device=DEV)
+    # (the reference's fp16 forward sits this far from its own fp32 forward: the engine must be at most as far from the fp16 one)
+    assert float(g16['fp16_vs_fp32_linf']) < 2.5e-3 and float(g16['fp16_vs_fp32_l2']) < 2.5e-3
+    for factor in [1.0] + [float(b) for b in g16['boosts']]:
+        tag = '' if factor == 1.0 else '_x%d' % int(factor)
+        m = nn['di'].UNetModel(**kw)
+        m.load_state_dict(w if factor == 1.0 else ounet.boost_out_layers(w, factor), strict=True)
+        out = m(x, t).cpu()
+        ref, fin = torch.from_numpy(g16['ref16_out' + tag]), g16['finite' + tag]
+        mine_fin = torch.isfinite(out).flatten(1).all(1).numpy()
+        assert np.array_equal(mine_fin, fin), (factor, mine_fin, fin)     # the SAME images survive / overflow as in the reference
+        if not fin.all():
+            assert not torch.isfinite(out[~torch.from_numpy(fin)]).any(), "an overflowed image is lost whole (inf -> GroupNorm -> NaN), as in the reference"
+            assert float(g16['peak' + tag]) > 4.0e4
+        for b in np.nonzero(fin)[0]:
+            linf, l2 = _rel(out[b:b + 1], ref[b:b + 1])
+            _note(test='small_fp16', factor=factor, image=int(b), linf=linf, l2=l2, peak=float(g16['peak' + tag]))
+            bound = FP16_SMALL if factor == 1.0 else FP16_LARGE_SMALL
+            assert linf <= bound[0] and l2 <= bound[1], (factor, b, linf, l2)
+
+
+@pytest.mark.parametrize("N", [1, 8])
+def test_unet_full_vs_reference_fp16_forward(nn, N):
+    g16, g = load_golden('unet_full_fp16.npz'), load_golden('unet_full.npz')
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, int(g16['seed']))
+    st = int(g16['stride'])
+    gen = torch.Generator().manual_seed(500 + N)
+    x = torch.randn((N, 3, 256, 256), generator=gen)
+    t = torch.randint(0, 1000, (N,), generator=gen).float()
+    x[0], t[0] = torch.from_numpy(g['x'])[0], torch.from_numpy(g['t'])[0]          # image 0 = the fixture's input, the rest fill the batch
+    x, t = x.to(DEV), t.to(DEV)
+    for factor in [1.0] + [float(b) for b in g16['boosts']]:
+        tag = '' if factor == 1.0 else '_x%d' % int(factor)
+        m = nn['di'].UNetModel(max_batch=N, device=DEV, **nn['di'].IMAGENET_256)
+        m.load_state_dict(w if factor == 1.0 else ounet.boost_out_layers(w, factor), strict=True)
+        out = m(x, t)[:1, :, ::st, ::st].cpu()
+        del m
+        assert bool(g16['finite' + tag][0]) and torch.isfinite(out).all()
+        linf, l2 = _rel(out, torch.from_numpy(g16['ref16_out' + tag]))
+        _note(test='full_fp16', batch=N, factor=factor, linf=linf, l2=l2, peak=float(g16['peak' + tag]))
+        bound = FP16_FULL if factor == 1.0 else FP16_LARGE_FULL
+        assert linf <= bound[0] and l2 <= bound[1], (N, factor, linf, l2)
+        if factor == 1.0:
+            l32 = _rel(out, torch.from_numpy(g['ref_out']))
+            _note(test='full_fp32', batch=N, linf=l32[0], l2=l32[1])

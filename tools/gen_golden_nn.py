@@ -61,6 +61,66 @@ def gen_unet(name, kw, seed, batch, stride):
                         cfg_head=kw['num_head_channels'])
 
 
+def ref_unet_fp16(cfg_kwargs, weights):
+    """The reference's OWN fp16 path (configs/imagenet_256.yml:26 use_fp16: true; diffusion.py:438-439): create_model(use_fp16=True),
+    strict load of the f32 weights, convert_to_fp16() (unet.py:619-625 -> fp16_util.py:15-22: conv weights and biases of the torso to
+    half), forward on the CPU (h = x.type(self.dtype) ... h.type(x.dtype), unet.py:655-663; GroupNorm32 and softmax in f32, nn.py:17-19,
+    unet.py:352)."""
+    unet_mod, script_util, gnn = rh.import_reference_unet()
+    model = script_util.create_model(**dict(cfg_kwargs, use_fp16=True))
+    model.load_state_dict(weights, strict=True)
+    model.convert_to_fp16()
+    model.eval()
+    assert model.dtype == torch.float16 and model.input_blocks[0][0].weight.dtype == torch.float16 and model.out[2].weight.dtype == torch.float32
+    return model
+
+
+def gen_unet_fp16(name, kw, seed, batch, stride, src, boosts=()):
+    """U1 pinned to the reference's fp16 forward: same seeded weights and the same x, t as `src` (the fp32 fixture),
+    outputs of the fp16 model; `boosts`: large-activation variants (oracle.unet.boost_out_layers) -- per factor the output, the
+    per-image finiteness and the largest finite |activation| any conv produced."""
+    import time
+    cfg = ounet.make_config(kw['image_size'], kw['num_channels'], kw['num_res_blocks'], kw['attention_resolutions'],
+                            kw['num_head_channels'], kw['learn_sigma'])
+    w = ounet.random_weights(cfg, seed)
+    g = np.load(os.path.join(OUT, src))
+    x, t = torch.from_numpy(g['x']), torch.from_numpy(g['t'])
+    assert int(g['seed']) == seed and x.shape[0] == batch
+    out = dict(seed=seed, stride=stride, src=src)
+    for factor in (1.0,) + tuple(boosts):
+        wb = w if factor == 1.0 else ounet.boost_out_layers(w, factor)
+        model = ref_unet_fp16(kw, wb)
+        peak = {'v': 0.0}
+
+        def hook(mod, inp, o):
+            if torch.is_tensor(o):
+                f = o.float().abs()
+                f = f[torch.isfinite(f)]
+                if f.numel():
+                    peak['v'] = max(peak['v'], float(f.max()))
+        for mod in model.modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Conv1d)):
+                mod.register_forward_hook(hook)
+        t0 = time.time()
+        with torch.no_grad():
+            y = model(x, t)
+        fin = torch.isfinite(y).flatten(1).all(1)
+        tag = '' if factor == 1.0 else '_x%d' % int(factor)
+        print(name, 'factor', factor, '%.0f s' % (time.time() - t0), 'finite per image', fin.tolist(), 'peak finite |conv out| %.0f' % peak['v'],
+              'out std', float(y[fin].std()) if fin.any() else None, flush=True)
+        if factor == 1.0:
+            ref32 = torch.from_numpy(g['ref_out'])
+            d = y[:, :, ::stride, ::stride] - ref32
+            out['fp16_vs_fp32_linf'] = float(d.abs().max() / ref32.abs().max())
+            out['fp16_vs_fp32_l2'] = float(d.norm() / ref32.norm())
+            print(name, 'reference fp16 vs reference fp32: rel Linf %.3e rel L2 %.3e' % (out['fp16_vs_fp32_linf'], out['fp16_vs_fp32_l2']))
+        out['ref16_out' + tag] = np.nan_to_num(y.numpy()[:, :, ::stride, ::stride], nan=0.0, posinf=0.0, neginf=0.0).copy()
+        out['finite' + tag] = fin.numpy()
+        out['peak' + tag] = peak['v']
+    out['boosts'] = np.array(boosts, np.float64)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+
+
 def gen_ddnm(name):
     rh.install()
     # the reference's diffusion.py pulls torchvision.utils and its datasets package; both are stubbed/importable
@@ -310,6 +370,10 @@ def main():
         gen_unet('unet_small.npz', SMALL, seed=11, batch=2, stride=1)
     if 'full' in which:
         gen_unet('unet_full.npz', FULL, seed=12, batch=1, stride=8)
+    if 'small16' in which:
+        gen_unet_fp16('unet_small_fp16.npz', SMALL, seed=11, batch=2, stride=1, src='unet_small.npz', boosts=(4096.0, 6144.0))
+    if 'full16' in which:
+        gen_unet_fp16('unet_full_fp16.npz', FULL, seed=12, batch=1, stride=8, src='unet_full.npz', boosts=(2048.0, 4096.0))
     if 'ddnm_full' in which:
         gen_ddnm_full('ddnm_unet_full.npz')
     if 'ddnm_full100' in which:
