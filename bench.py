@@ -150,12 +150,107 @@ def cpu_baseline(timed=3, max_workers=None):
                        f"({workers * timed} timed shapes in all), value = aggregate rate over the slowest core, the per-shape figure is the median")
 
 
+class LoadSampler:
+    """Shader clock and board power sampled from sysfs WHILE the timed region runs (the evidence for the
+    'power-limited ceiling' has to be read under load, not after it).  A daemon thread reads, at >= 5 Hz, the amdgpu hwmon / DPM files
+    of the GPU this rank runs on (matched by PCI bus id; falls back to the first card): freq1_input (current sclk, Hz), the '*' line of
+    pp_dpm_sclk, power1_average or power1_input (uW), once power1_cap.  Nothing here touches the GPU queue."""
+
+    def __init__(self, dev, hz=10.0):
+        import glob
+        self.period = 1.0 / hz
+        self.samples = []
+        self.files = {}
+        self._stop = False
+        self._thread = None
+        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device'))
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            want = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:                                   # noqa: BLE001 -- older torch: no PCI ids on the properties object
+            pass
+        pick = None
+        for c in cards:
+            real = os.path.realpath(c)
+            if want and want in real.lower():
+                pick = c
+                break
+        if pick is None:
+            amd = [c for c in cards if os.path.exists(os.path.join(c, 'pp_dpm_sclk'))]
+            pick = amd[0] if amd else None
+        self.card = pick
+        self.matched_pci = bool(want and pick and want in os.path.realpath(pick).lower())
+        if pick:
+            hw = sorted(glob.glob(os.path.join(pick, 'hwmon', 'hwmon*')))
+            cand = {'freq': [os.path.join(h, 'freq1_input') for h in hw], 'dpm': [os.path.join(pick, 'pp_dpm_sclk')],
+                    'power': [os.path.join(h, n) for h in hw for n in ('power1_average', 'power1_input')],
+                    'cap': [os.path.join(h, 'power1_cap') for h in hw]}
+            for k, fs in cand.items():
+                for f in fs:
+                    try:
+                        open(f).read()
+                        self.files[k] = f
+                        break
+                    except OSError:
+                        continue
+
+    def _read(self):
+        row = {}
+        try:
+            if 'freq' in self.files:
+                row['sclk_mhz'] = int(open(self.files['freq']).read()) / 1e6
+            if 'dpm' in self.files:
+                cur = [ln for ln in open(self.files['dpm']).read().splitlines() if ln.strip().endswith('*')]
+                if cur:
+                    row['dpm_mhz'] = float(''.join(ch for ch in cur[0].split(':')[1] if ch.isdigit() or ch == '.'))
+            if 'power' in self.files:
+                row['power_w'] = int(open(self.files['power']).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return row
+
+    def _loop(self):
+        while not self._stop:
+            r = self._read()
+            if r:
+                self.samples.append(r)
+            time.sleep(self.period)
+
+    def start(self):
+        import threading
+        if self.files:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        out = dict(samples=len(self.samples), sample_hz=1.0 / self.period, card=self.card, matched_by_pci_bus_id=self.matched_pci,
+                   source={k: os.path.basename(v) for k, v in self.files.items()})
+        if self.samples and not any('sclk_mhz' in r for r in self.samples):     # no hwmon freq1_input: the DPM table's current level stands in
+            for r in self.samples:
+                if 'dpm_mhz' in r:
+                    r['sclk_mhz'] = r['dpm_mhz']
+            out['source']['freq'] = 'pp_dpm_sclk (current level)'
+        for key, name in (('sclk_mhz', 'sclk_mhz_under_load'), ('dpm_mhz', 'dpm_sclk_mhz_under_load'), ('power_w', 'power_w_under_load')):
+            v = [r[key] for r in self.samples if key in r]
+            if v:
+                out[name + '_mean'] = float(np.mean(v)); out[name + '_min'] = float(np.min(v)); out[name + '_max'] = float(np.max(v))
+        try:
+            if 'cap' in self.files:
+                out['power_cap_w'] = int(open(self.files['cap']).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return out
+
+
 def calibrate(dev, seconds=3.0):
     """In-run calibration of the box ("calibrate with a measured GEMM and a copy kernel, and report both"), untimed, after
     the timed region: the vendor's plain f16 GEMM (hipBLASLt through torch.matmul, 8192^3) on operands with the bench's statistics
     (activations ~ N(0, 1), weights ~ N(0, 0.05^2)) and on zeros -- the gap between the two is the data-dependent power limit --
     and a device-to-device copy of a 1 GiB f16 tensor (read + write).  sclk / power are read from sysfs when the box exposes them."""
-    import glob
     out = {}
     n = 8192
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -181,22 +276,29 @@ def calibrate(dev, seconds=3.0):
         out['gemm_f16_zeros_tflops'] = 2.0 * n ** 3 / t / 1e12
         del a, b, c
         x = torch.empty((512 * 1024 * 1024,), device=dev, dtype=torch.float16).normal_(); y = torch.empty_like(x)
-        t = timed(lambda: y.copy_(x), seconds * 0.3)
+        t = timed(lambda: y.copy_(x), seconds * 0.2)
         out['copy_gbs'] = 2.0 * x.numel() * 2 / t / 1e9
+        # the library's own 16-byte-per-lane copy kernel (pdhip_bench_copy16): the ceiling the GroupNorm passes are judged against
+        import ctypes as C
+        from pointdreamer_amd import _lib
+        L = _lib.lib()
+        best = {}
+        for unroll in (1, 2, 4, 16 + 2, 16 + 4, 32 + 2, 32 + 4):     # (low bits: loads in flight; 16 +: nontemporal; 32 +: one slab per workgroup)
+            for blocks in (16384, 65536, 262144):
+                fn = lambda: L.pdhip_bench_copy16(C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_longlong(x.numel() * 2), blocks, unroll,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                t = timed(fn, seconds * 0.02)
+                best[f"{('sweep', 'nt', 'slab')[unroll >> 4]}_u{unroll & 15}_b{blocks}"] = 2.0 * x.numel() * 2 / t / 1e9
+        out['copy16_gbs'] = max(best.values())
+        out['copy16_config'] = max(best, key=best.get)
+        out['copy16_sweep_gbs'] = {k: round(v, 1) for k, v in best.items()}
+        assert torch.equal(x[-4096:], y[-4096:])
         del x, y
     except Exception as e:                                  # noqa: BLE001 -- a side figure must not take the headline line down
         out['error'] = str(e)[:200]
-    try:
-        for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))[:1]:
-            cur = [l for l in open(f).read().splitlines() if l.strip().endswith('*')]
-            if cur:
-                out['sclk_mhz_idle_after_run'] = int(''.join(ch for ch in cur[0].split(':')[1] if ch.isdigit()))
-        for f in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_average'))[:1]:
-            out['power_w_after_run'] = int(open(f).read()) / 1e6
-    except Exception:                                       # noqa: BLE001 -- sysfs is optional
-        pass
-    out['note'] = ("torch.matmul (hipBLASLt) 8192^3 f16 on N(0,1) x N(0,0.05^2) operands and on zeros; copy = 1 GiB f16 device-to-device, "
-                   "read + write bytes; measured by this run after the timed region")
+    out['note'] = ("torch.matmul (hipBLASLt) 8192^3 f16 on N(0,1) x N(0,0.05^2) operands and on zeros; copy = 1 GiB f16 device-to-device through "
+                   "torch's copy_ and through the library's own 16-byte-per-lane kernel (best of a small unroll / grid sweep), read + write "
+                   "bytes; measured by this run after the timed region.  sclk / power under load are sampled DURING the timed region")
     return out
 
 
@@ -218,8 +320,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the nearest-workload / one-shape-latency side measurements')
     ap.add_argument('--shapes-per-step', type=int, default=4,
                     help='independent shapes textured per step on each GPU, their 8-view sets batched through the UNet together '
-                         '(BASELINE configs[4] style).  Measured on one MI355X (round 3): 1 -> 1 926, 4 -> 2 100-2 150, 8 -> 2 081 '
-                         'shapes/hour; 1 = one shape at a time (configs[2], lowest latency)')
+                         '(BASELINE configs[4] style); 1 = one shape at a time (configs[2], lowest latency).  What each setting measures on '
+                         'one MI355X is in DESIGN.md section 8 (the default is the fastest)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -308,11 +410,15 @@ def main():
     sync()
     if inpainter is not None:
         inpainter.model.profile(args.profile_period)
+    sampler = LoadSampler(dev) if rank == 0 else None
+    if sampler is not None:
+        sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
+    under_load = sampler.stop() if sampler is not None else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -475,6 +581,16 @@ def main():
             roofline['calibrated_peak'] = calib['gemm_f16_random_tflops']
             roofline['frac_of_calibrated'] = roofline['achieved'] / calib['gemm_f16_random_tflops'] if roofline.get('achieved') else None
             roofline['calibration'] = calib
+    if roofline is not None and under_load is not None:
+        roofline.setdefault('calibration', {})['under_load'] = under_load
+        for k in ('sclk_mhz_under_load_mean', 'sclk_mhz_under_load_min', 'power_w_under_load_mean', 'power_cap_w'):
+            if k in under_load:
+                roofline['calibration'][k if 'sclk' in k else k.replace('_under_load', '')] = under_load[k]
+        clk = under_load.get('sclk_mhz_under_load_mean') or under_load.get('dpm_sclk_mhz_under_load_mean')
+        if clk and roofline.get('achieved'):
+            # the dense peak is quoted at the 2 400 MHz maximum clock: the same matrix pipes at the clock the timed region actually ran at
+            roofline['clock_adjusted_peak'] = PEAK_FP16_TFLOPS * clk / 2400.0
+            roofline['frac_of_clock_adjusted_peak'] = roofline['achieved'] / roofline['clock_adjusted_peak']
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -283,7 +283,7 @@ int pdhip_debug_set_conv_tile(int geometry);    /* 2 = 128x128 tile / 4 waves, 4
                                                  * 16 = 256x128 / 4 waves, 32 = halo-resident 3x3 kernel (512x128); 0 = automatic */
 int pdhip_debug_set_conv_stages(int stages);   /* 2..4 LDS pipeline stages, 12 = 2 stages + hand-scheduled fragment loop; 0 = automatic */
 int pdhip_debug_set_conv_splitk(void* ws, long long ws_floats, int splits); /* split-K workspace for pdhip_conv2d_nhwc_f16 + forced factor (0 = automatic) */
-int pdhip_debug_set_conv_halo_strips(int mode); /* halo-resident 3x3 kernel on 256-wide images: 0 = automatic (column strips of 128), 1 = full-row tiles, 2 = strips of 64; returns the previous value */
+int pdhip_debug_set_conv_halo_strips(int mode); /* halo-resident 3x3 kernel on 256-wide images: 0 = automatic (column strips of 128), 1 = full-row tiles; returns the previous value */
 int pdhip_pack_conv_weight_f16(const float* w_oihw, int Cout, int Cin, int taps, void* w_packed /*[Cout][taps*Cin] f16*/, void* stream);
 int pdhip_conv2d_nhwc_f16(const void* x, const void* w_packed /*[Cout_pad][taps*Cin]*/, const float* bias, const void* residual,
                           void* y, int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, const void* zero_page,
@@ -317,7 +317,8 @@ int pdhip_debug_set_conv_sk_order(int order);   /* lab hook: tile order of the s
  * w_packed [256][C] f16, bias [256] f32 or NULL; h0 [N,H,W,C], sk [N,H,W,256] f16. */
 int pdhip_gn_silu_skip1x1_nhwc_f16(const void* xa, const void* xb, int Ca, int C, const float* stats, const float* gamma, const float* beta,
                                    const void* w_packed, const float* bias, void* h0, void* sk, int N, int H, int W, void* stream);
-int pdhip_debug_set_gn_skip_variant(int v);   /* lab hook of the one-pass GroupNorm + skip kernel: 0 = loads requested under the MFMA phase, 1 (default) = activation chunk k + 1 requested at the top of iteration k, 64-pixel tiles where 128-pixel tiles would leave CUs idle (< 256 tiles), 2 = as 1 with 128-pixel tiles always; returns the previous value */
+int pdhip_debug_set_gn_iters(int iters);   /* lab hook: pixels per thread of the GroupNorm-apply kernel (1 .. 32; 0 = default); returns the previous value */
+int pdhip_debug_set_gn_skip_variant(int v);   /* lab hook of the one-pass GroupNorm + skip kernel: 1 (default; 0 is taken as 1) = activation chunk k + 1 requested at the top of iteration k, 64-pixel tiles where 128-pixel tiles would leave CUs idle (< 256 tiles), 2 = as 1 with 128-pixel tiles always; returns the previous value */
 int pdhip_debug_set_fuse_skip(int mode, int min_tiles);   /* ResBlock GroupNorm-apply + skip 1x1 as one pass: mode 0 never / 1 (default) layers of at least min_tiles 128-pixel tiles (default 1024; <= 0 keeps the value) / 2 every eligible layer; returns the previous mode */
 int pdhip_debug_set_fuse_gn(int on);   /* 1: the UNet uses the fused form wherever the halo kernel serves a conv; 0 (default, measured faster): stand-alone passes */
 /* ---- complete_unseen_by='neighbor' (pointdreamer/unproject.py:93-196, demo.py:180-200).
@@ -357,6 +358,10 @@ int pdhip_unet_head_f32(const void* x, const float* gamma, const float* beta, co
 int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim,
                         void* vt_ws /*N*T*C halfs, non-NULL selects the 128-query MFMA kernel for T % 128 == 0, head_dim 64, N*heads % 8 == 0 (QKVAttentionLegacy, unet.py:341-373); the buffer is written only in the transposed-V lab form (pdhip_debug_set_attn); NULL: the 64-query kernel*/, void* stream);
 int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream);
+/* Calibration only (no reference counterpart): a streaming device-to-device copy, 16 bytes per lane, `unroll` & 15 (1, 2, 4, 8; 0 = 4) loads in
+ * flight per lane, `unroll` >> 4 the form (0 grid-stride sweep, 1 the same with nontemporal loads / stores, 2 one contiguous slab per workgroup), `blocks` workgroups of 256 threads (0 = 2048).  bench.py reports its rate (read + write bytes) as
+ * roofline.calibration.copy16_gbs next to torch's copy_: the ceiling the HBM-bound GroupNorm passes are judged against. */
+int pdhip_bench_copy16(const void* src, void* dst, long long bytes, int blocks, int unroll, void* stream);
 
 #ifdef __cplusplus
 }

@@ -109,6 +109,8 @@ int ddnm_prepare(const float* masked_img, const float* mask, float* y, int N, in
 int ddnm_finish(const float* x, float* out, long long n, hipStream_t s);
 // Philox counter = (quad0 + element / 4, stream_id), key = seed.  quad0 = first image key * quads per image makes the noise of an
 // image a function of its KEY only (not of its position in the batch or of how views are sharded over ranks).
+extern thread_local int g_gn_iters;
+int copy16(const void* src, void* dst, long long bytes, int blocks, int unroll, hipStream_t s);   // calibration copy (nn_misc.hip)
 int philox_normal(float* out, long long n, unsigned long long seed, unsigned long long stream_id, hipStream_t s,
                   unsigned long long quad0 = 0);
 

@@ -376,17 +376,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         }
         const bool col_ok = n0 + col8 < Cout;
         const int ccol = col_ok ? n0 + col8 : 0;
-        half8 rres[RES ? BMT / RPP : 1];
+        // residual rows in two batches of 8: the first before the accumulators are staged (its HBM latency runs under the staging),
+        // the second right behind the staging stores, when the 128 accumulator registers are dead -- all 16 rows in one batch next to
+        // the live accumulators cost the W = 32 / strip-64 instances 4-8 spilled VGPRs, and a spilled row is a load + vmcnt(0) + scratch
+        // store in the MIDDLE of the batch (round 5: zero scratch on every routed kernel)
+        constexpr int NRES = BMT / RPP, NR1 = NRES / 2;
+        half8 rres[RES ? NRES : 1];
+        auto res_load = [&](int p) {
+            // res_up: the residual is the HALF-resolution tensor of an up-ResBlock, nearest-upsampled on the fly (unet.py:237-242
+            // h = conv(...) + upsample(x)): the x2 copy of x is never materialised
+            const int rp = p * RPP + tid / CT;
+            const int ry = ty0 + (rp >> WLOG), rx = x0 + (rp & (W - 1));
+            const long long rm = res_up ? ((long long)img * (H >> 1) + (ry >> 1)) * ((1 << ILOG) >> 1) + (rx >> 1) : pix(rp);
+            rres[p] = *reinterpret_cast<const half8*>(residual + (size_t)rm * Cout + ccol);
+        };
         if (RES) {
 #pragma unroll
-            for (int p = 0; p < BMT / RPP; ++p)
-            {   // res_up: the residual is the HALF-resolution tensor of an up-ResBlock, nearest-upsampled on the fly (unet.py:237-242
-                // h = conv(...) + upsample(x)): the x2 copy of x is never materialised
-                const int rp = p * RPP + tid / CT;
-                const int ry = ty0 + (rp >> WLOG), rx = x0 + (rp & (W - 1));
-                const long long rm = res_up ? ((long long)img * (H >> 1) + (ry >> 1)) * ((1 << ILOG) >> 1) + (rx >> 1) : pix(rp);
-                rres[p] = *reinterpret_cast<const half8*>(residual + (size_t)rm * Cout + ccol);
-            }
+            for (int p = 0; p < NR1; ++p) res_load(p);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -400,6 +406,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
                 for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv[r]);
                 *reinterpret_cast<half4*>(&Cs[ml * CS_LD + nl]) = h;
             }
+        }
+        if (RES) {
+            asm volatile("" ::: "memory");                 // (the second batch is issued HERE, not hoisted above the staging stores)
+#pragma unroll
+            for (int p = NR1; p < NRES; ++p) res_load(p);
         }
         __syncthreads();
 #pragma unroll
@@ -426,9 +437,22 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
         float* red = reinterpret_cast<float*>(smem);
         red[tid * 2] = gs; red[tid * 2 + 1] = gq;
         __syncthreads();
+        // two-level fixed-order column sums (as k_conv_sk): 8 threads per octet take every 8th row, one thread adds the 8 sub-sums
+        constexpr int SUB = 8;
+        static_assert(RPP % SUB == 0, "GroupNorm partial reduce");
+        float* red2 = red + NWAVES * 64 * 2;
+        if (tid < CT * SUB) {
+            const int j = tid % SUB, c = tid / SUB;
+            float s1 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPP / SUB; ++r) { s1 += red[((r * SUB + j) * CT + c) * 2]; q1 += red[((r * SUB + j) * CT + c) * 2 + 1]; }
+            red2[tid * 2] = s1; red2[tid * 2 + 1] = q1;
+        }
+        __syncthreads();
         if (tid < CT && n0 + tid * 8 < Cout) {
             float s1 = 0.f, q1 = 0.f;
-            for (int r = 0; r < RPP; ++r) { s1 += red[(r * CT + tid) * 2]; q1 += red[(r * CT + tid) * 2 + 1]; }
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) { s1 += red2[(tid * SUB + j) * 2]; q1 += red2[(tid * SUB + j) * 2 + 1]; }
             const int chunks = tpi;
             const int chunk = tin;
             float* dst = gn_part + (((size_t)img * chunks + chunk) * (Cout >> 3) + (n0 >> 3) + tid) * 2;
@@ -508,9 +532,9 @@ int conv3x3_halo(const half_t* X, const half_t* Wt, const float* bias, const hal
     int rc;
 #define HL_LAUNCH2(WL, IL) launch_halo<WL, IL>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, s, gnp, splits, partial, apply_table, res_up, in_up)
     // 256-wide images: column strips of 128 (4 rows x 128 per tile: 780 halo pixels per chunk instead of 1 032) measured +2-3 %
-    // over full rows, strips of 64 +1.5-3 %; at 128 wide strips do not pay.  g_halo_strips: 0 automatic, 1 full rows, 2 = 64 wide.
-    if (W == 256 && g_halo_strips == 2 && H % 8 == 0) rc = HL_LAUNCH2(6, 8);
-    else if (W == 256 && g_halo_strips != 1 && H % 4 == 0) rc = HL_LAUNCH2(7, 8);
+    // over full rows, strips of 64 +1.5-3 % (that instance spilled 8 VGPRs and was never the default: removed in round 5); at 128 wide
+    // strips do not pay.  g_halo_strips: 0 automatic, 1 full rows.
+    if (W == 256 && g_halo_strips != 1 && H % 4 == 0) rc = HL_LAUNCH2(7, 8);
     else if (W == 256 && apply_table != nullptr) { set_error("conv3x3_halo: APPLY needs H %% 4 == 0 at W = 256"); return PDHIP_E_ARG; }
     else if (W == 256) rc = HL_LAUNCH(8);
     else if (W == 128) rc = HL_LAUNCH(7);

@@ -264,4 +264,50 @@ int ddnm_finish(const float* x, float* out, long long n, hipStream_t s) {
     return PDHIP_OK;
 }
 
+// Calibration only (bench.py `roofline.calibration.copy16_gbs`): the plain 16-byte-per-lane streaming copy the HBM-bound
+// passes (k_gn_apply, k_gn_skip_w1) are judged against -- MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy.  U 16-byte loads in
+// flight per lane, one workgroup-stride sweep, nothing else.
+// MODE 0: grid-stride sweep; 1: the same with nontemporal loads and stores; 2: every workgroup copies one contiguous slab (U x 4 KiB
+// per trip)
+typedef __attribute__((ext_vector_type(4))) float cp_f4;
+template <int U, int MODE>
+__global__ __launch_bounds__(256) void k_copy16(const cp_f4* __restrict__ src, cp_f4* __restrict__ dst, long long n16) {
+    if (MODE == 2) {
+        const long long per = (n16 + gridDim.x - 1) / gridDim.x, b0 = (long long)blockIdx.x * per, b1 = b0 + per < n16 ? b0 + per : n16;
+        long long i = b0 + threadIdx.x;
+        for (; i + (U - 1) * 256 < b1; i += U * 256) {
+            cp_f4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = src[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dst[i + u * 256] = v[u];
+        }
+        for (; i < b1; i += 256) dst[i] = src[i];
+        return;
+    }
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        cp_f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = MODE == 1 ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { if (MODE == 1) __builtin_nontemporal_store(v[u], dst + i + u * stride); else dst[i + u * stride] = v[u]; }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+int copy16(const void* src, void* dst, long long bytes, int blocks, int unroll, hipStream_t s) {
+    PD_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0, "copy16: bytes must be a positive multiple of 16");
+    const long long n16 = bytes / 16;
+    if (blocks <= 0) blocks = 256 * 8;
+    const int mode = unroll >> 4, u = unroll & 15;         // unroll: low 4 bits = loads in flight per lane, bits 4.. = mode
+#define PD_CP(U_, M_) k_copy16<U_, M_><<<blocks, 256, 0, s>>>((const cp_f4*)src, (cp_f4*)dst, n16)
+#define PD_CPM(M_) (u == 8 ? PD_CP(8, M_) : u == 2 ? PD_CP(2, M_) : u == 1 ? PD_CP(1, M_) : PD_CP(4, M_))
+    if (mode == 1) PD_CPM(1); else if (mode == 2) PD_CPM(2); else PD_CPM(0);
+#undef PD_CPM
+#undef PD_CP
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+
 }  // namespace pdnn

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const half_t* __restrict__ X, 
     }
 }
 
+thread_local int g_gn_iters = 0;       // lab hook (pdhip_debug_set_gn_iters): pixels per thread of k_gn_apply, 0 = default
 int gn_apply(const half_t* X, const float* stats, const float* gamma, const float* beta, const float* film,
              long long film_stride, int N, int H, int W, int C, int silu, int resample, void* Y, int out_f32, hipStream_t s,
              const half_t* XB, int Ca, half_t* Yraw, const GnPartsArg* parts) {
@@ -368,7 +369,7 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     const int opp = C >> 3, pps = max(1, 256 / opp);
     // pixels per thread: 32 on the big tensors (constants amortised), fewer on the small ones so that the grid still fills
     // the chip (a 64-pixel 8x8 level with 32 pixels per thread is 8 workgroups walking a serial latency chain)
-    int iters = GNA_ITERS;
+    int iters = g_gn_iters > 0 ? g_gn_iters : GNA_ITERS;
     // (with the in-kernel statistics every workgroup pays the re-reduction of its image's partials first: fewer, longer workgroups --
     // 512 against 2 048 is -2.3 % on the batch-1 forward, -1 % at batch 8; tools/time_unet.py)
     const int tgt_blocks = parts != nullptr && N <= 8 ? 512 : 2048;
@@ -507,72 +508,7 @@ template <typename T> __device__ __forceinline__ T* gs_uniform(T* p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
-// variant 0: two workgroups per CU, loads requested under the MFMA phase of the previous chunk
-__global__ __launch_bounds__(256, 2) void k_gn_skip(const half_t* __restrict__ XA, const half_t* __restrict__ XB, int Ca, int C,
-                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, const half_t* __restrict__ Wt,
-                                                    const float* __restrict__ bias, half_t* __restrict__ H0, half_t* __restrict__ SK,
-                                                    int HW) {
-    extern __shared__ __align__(16) char gs_smem[];
-    char* const As = gs_smem;                                // activations [128 px][64 ch] f16, 16-byte slots XOR-swizzled by (row & 7)
-    char* const Ws = gs_smem + GS_BM * 128;                  // weights     [256 co][64 ch]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
-    const long long m0 = (long long)blockIdx.x * GS_BM;
-    const int n = (int)(m0 / HW), cg = C / 32, Cb = C - Ca, KC = C / 64;
-    const int slot = tid & 7, prow = tid >> 3;
-    half8 xa[4], wr[8];
-    float4_t g0, g1, b0, b1;
-    float mean, rstd;
-    auto issue = [&](int kc) {
-        const int c0 = kc * 64 + slot * 8;
-        const bool second = c0 >= Ca;                         // (uniform over the workgroup: Ca % 64 == 0)
-        const half_t* const src = second ? XB + (size_t)m0 * Cb + (c0 - Ca) : XA + (size_t)m0 * Ca + c0;
-        const int cs = second ? Cb : Ca;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xa[j] = *reinterpret_cast<const half8*>(src + (size_t)(prow + 32 * j) * cs);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wr[j] = *reinterpret_cast<const half8*>(Wt + (size_t)(prow + 32 * j) * C + c0);
-        g0 = *reinterpret_cast<const float4_t*>(gamma + c0); g1 = *reinterpret_cast<const float4_t*>(gamma + c0 + 4);
-        b0 = *reinterpret_cast<const float4_t*>(beta + c0);  b1 = *reinterpret_cast<const float4_t*>(beta + c0 + 4);
-        const float* st = stats + ((size_t)n * 32 + c0 / cg) * 2;   // (an octet lies inside one group: cg % 8 == 0)
-        mean = st[0]; rstd = st[1];
-    };
-    float4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    issue(0);
-    for (int kc = 0; kc < KC; ++kc) {
-        if (kc > 0) __syncthreads();                          // the previous chunk's fragment reads are done
-        const int sw = (slot ^ (prow & 7)) << 4;              // (rows prow + 32 j share prow & 7)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<half8*>(As + (prow + 32 * j) * 128 + sw) = xa[j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<half8*>(Ws + (prow + 32 * j) * 128 + sw) = wr[j];
-        {   // h0 = silu(GN(x)) of the registers just parked
-            float ga[8], gb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ga[e] = rstd * (e < 4 ? g0[e] : g1[e - 4]);
-                gb[e] = (e < 4 ? b0[e] : b1[e - 4]) - mean * ga[e];
-            }
-            const int c0 = kc * 64 + slot * 8;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half8 hv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = (half_t)gn_elem<false, false>((float)xa[j][e], ga[e], gb[e], 1.f, 0.f, 1);
-                *reinterpret_cast<half8*>(H0 + (size_t)(m0 + prow + 32 * j) * C + c0) = hv;
-            }
-        }
-        __syncthreads();
-        if (kc + 1 < KC) issue(kc + 1);                       // in flight under this chunk's MFMAs (and the other workgroup's)
-        gs_mfma_step<4>(acc, As, Ws, lane, wm, wn);
-    }
-    __syncthreads();
-    gs_epilogue(acc, gs_smem, bias, SK, m0, tid);
-}
+// (variant 0 of round 3 -- activation loads requested under the MFMA phase, 2 spilled VGPRs, 3.8 TB/s against 4.3 -- was removed in round 5)
 
 // variant 1: two workgroups per CU like variant 0, but the activation chunk k + 1 is requested at the TOP of iteration k (second
 // register set) and is in flight for the whole iteration -- GroupNorm math, barrier, MFMA phase -- instead of one MFMA phase
@@ -696,14 +632,12 @@ int gn_skip(const half_t* XA, const half_t* XB, int Ca, int C, const float* stat
     PD_REQUIRE(gn_skip_eligible(N, HW, Ca, C, GS_BN, GS_BN) && (Ca == C || XB != nullptr), "gn_skip: shape not served by the fused kernel");
     static thread_local bool attr_set = false;
     if (!attr_set) {
-        PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip, hipFuncAttributeMaxDynamicSharedMemorySize, GS_SMEM));
         PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip_w1<128>, hipFuncAttributeMaxDynamicSharedMemorySize, GS1_SMEM));
         PD_HIP(hipFuncSetAttribute((const void*)k_gn_skip_w1<64>, hipFuncAttributeMaxDynamicSharedMemorySize, GS1_SMEM));
         attr_set = true;
     }
     const long long tiles = (long long)N * HW / GS_BM;
-    if (g_gs_variant == 0) k_gn_skip<<<(int)tiles, 256, GS_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
-    else if (tiles < 256 && g_gs_variant != 2) k_gn_skip_w1<64><<<(int)(2 * tiles), 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
+    if (tiles < 256 && g_gs_variant != 2) k_gn_skip_w1<64><<<(int)(2 * tiles), 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
     else k_gn_skip_w1<128><<<(int)tiles, 256, GS1_SMEM, s>>>(XA, XB, Ca, C, stats, gamma, beta, Wt, bias, H0, SK, HW);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;

@@ -962,3 +962,7 @@ extern "C" int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint6
     PD_REQUIRE(out && n > 0, "pdhip_philox_normal: bad arguments");
     return philox_normal(out, n, seed, stream_id, as_stream(stream));
 }
+extern "C" int pdhip_bench_copy16(const void* src, void* dst, long long bytes, int blocks, int unroll, void* stream) {
+    return copy16(src, dst, bytes, blocks, unroll, as_stream(stream));
+}
+extern "C" int pdhip_debug_set_gn_iters(int iters) { const int old = g_gn_iters; g_gn_iters = iters; return old; }

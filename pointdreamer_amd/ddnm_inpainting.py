@@ -62,6 +62,8 @@ _reg('pdhip_debug_set_attn', C.c_int, [i32, i32, i32])
 _reg('pdhip_debug_conv3x3_apply', C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_attention_f16', C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_philox_normal', C.c_int, [vp, C.c_longlong, u64, u64, vp])
+_reg('pdhip_debug_set_gn_iters', C.c_int, [i32])
+_reg('pdhip_bench_copy16', C.c_int, [vp, vp, C.c_longlong, i32, i32, vp])
 
 # models/DDNM/configs/imagenet_256.yml (model + diffusion + time_travel sections); values must be reproduced
 IMAGENET_256 = dict(image_size=256, num_channels=256, num_res_blocks=2, attention_resolutions="32,16,8",

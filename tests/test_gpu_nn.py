@@ -369,10 +369,10 @@ def test_conv3x3_halo_kernel_vs_torch_fp32(nn, N, H, W, Cin, Cout, res, splits):
         L.pdhip_debug_set_conv_splitk(None, 0, 0)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("N,H,Cin,Cout,res", [(2, 16, 64, 128, True), (1, 24, 96, 256, False)])
 def test_conv3x3_halo_tile_geometries_on_256_wide_images(nn, mode, N, H, Cin, Cout, res):
-    """256-wide images: tiles of 4 rows x 128 columns (automatic), full rows (1) or 8 rows x 64 columns (2) -- strip borders inside
+    """256-wide images: tiles of 4 rows x 128 columns (automatic) or full rows (1) -- strip borders inside
     the image must read their neighbours' columns, the image border the zero padding; the fused GroupNorm partials (one chunk per
     tile) are covered by the UNet tests, which run the automatic geometry."""
     L = nn['L']

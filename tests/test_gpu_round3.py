@@ -323,7 +323,7 @@ def test_gn_skip_one_pass_equals_two_launches(nn, N, H, W, Ca, Cb):
     t_ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, b.cpu()).permute(0, 2, 3, 1)
     scale = t_ref.abs().max().item()
     sks = []
-    for variant in (0, 1, 2):                            # (1: 64-pixel tiles where 128-pixel tiles would not fill the chip -- round 4; 2: 128 always)
+    for variant in (1, 2):                               # (1: 64-pixel tiles where 128-pixel tiles would not fill the chip -- round 4; 2: 128 always)
         old = L.pdhip_debug_set_gn_skip_variant(variant)
         try:
             h0 = torch.full_like(xd, float('nan')); sk = torch.full_like(sk_ref, float('nan'))
@@ -337,7 +337,7 @@ def test_gn_skip_one_pass_equals_two_launches(nn, N, H, W, Ca, Cb):
         assert (sk.float().cpu() - t_ref).abs().max().item() <= 2e-3 * scale + 1e-3
         assert (sk.float() - sk_ref.float()).abs().max().item() <= 2e-3 * scale          # (one f16 ulp at most: same products, f32 sums)
         sks.append(sk)
-    assert torch.equal(sks[0], sks[1]) and torch.equal(sks[1], sks[2])     # same K order, same fragments: the forms agree bit for bit
+    assert torch.equal(sks[0], sks[1])                                     # same K order, same fragments: the forms agree bit for bit
     # shapes the kernel does not serve are refused, not mis-computed
     assert L.pdhip_gn_silu_skip1x1_nhwc_f16(_ptr(xa), _ptr(xb) if Cb else None, Ca, Cc, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(wp), _ptr(b),
                                             _ptr(h0), _ptr(sk), N, 1, 127, _stream()) != 0      # (H * W not a multiple of the 128-pixel tile)

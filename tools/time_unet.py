@@ -15,6 +15,7 @@ ap.add_argument('--sk', type=int, default=-1, help='pdhip_debug_set_conv_sk mode
 ap.add_argument('--fskip', type=int, default=-1, help='pdhip_debug_set_fuse_skip mode (0 off, 1 auto, 2 always; -1 = default)')
 ap.add_argument('--gsv', type=int, default=-1, help='pdhip_debug_set_gn_skip_variant (-1 = default)')
 ap.add_argument('--finc', type=int, default=-1, help='pdhip_debug_set_fold_finalize_chunks (-1 = default)')
+ap.add_argument('--gn-iters', type=int, default=-1, help='pdhip_debug_set_gn_iters (-1 = default)')
 ap.add_argument('--out', default='gpurun_out/unet_latency.json')
 ap.add_argument('--graph', type=int, default=0, help='1: also time the forward and the sampler replayed from a HIP graph (torch.cuda.CUDAGraph)')
 ap.add_argument('--sampler-steps', type=int, default=10, help='also time this many DDNM steps through pdhip_ddnm_sample (0 = skip)')
@@ -24,6 +25,8 @@ from pointdreamer_amd import _lib
 if os.environ.get('PDHIP_LAB_LIB'):                      # lab builds: PDHIP_LAB_LIB=path/to/lab.so python tools/time_unet.py
     _lib.LIB_PATH = os.path.abspath(os.environ['PDHIP_LAB_LIB'])
 _lib.lib().pdhip_debug_set_fuse_gn(a.fuse); _lib.lib().pdhip_debug_set_fold_resample(a.fold)
+if a.gn_iters >= 0:
+    _lib.lib().pdhip_debug_set_gn_iters(a.gn_iters)
 if a.fin >= 0:
     _lib.lib().pdhip_debug_set_fold_finalize(a.fin)
 if a.gsv >= 0:
