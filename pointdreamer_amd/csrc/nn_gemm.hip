@@ -570,10 +570,23 @@ bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
            conv3x3_halo_splits(N, H, W, Cin, Cout, Cout_pad, 0) == 1;
 }
 
+// THE routing decision of conv_igemm() -- the one copy of it (run_res predicts the route of conv2 to decide whether the
+// up-sampled x branch needs materialising; a second copy of the predicate could drift from the one that launches): 0 = halo-resident
+// kernel, 1 = k_conv_sk (plan in *plan), 2 = the implicit-GEMM kernel.
+int conv_route(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats, bool two_source, bool in_up,
+               bool apply, SkPlan* plan) {
+    if (!two_source && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats)) return 0;
+    if (!in_up && !apply && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
+        const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, two_source, splitk_ws_floats);
+        if (pl.bm > 0) {
+            if (plan) *plan = pl;
+            return 1;
+        }
+    }
+    return 2;
+}
 bool conv_routes_sk(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats) {
-    if (conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats)) return false;
-    if (g_force_wmw != 0 || g_force_bk != 0 || g_force_stages != 0 || g_force_splits != 0) return false;
-    return conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, false, splitk_ws_floats).bm > 0;
+    return conv_route(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats, false, false, false, nullptr) == 1;
 }
 
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
@@ -596,7 +609,9 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     const long long M = (long long)N * H * W;
     // large-image 3x3 layers: halo-resident kernel (2.1x less L2 -> LDS traffic per flop) once it fills the chip
     // (tuning hook: tile geometry 32 forces it, any other forced geometry disables it)
-    if (X2 == nullptr && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0)) {
+    SkPlan pl{0, 0, 0, 0};
+    const int route = conv_route(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws ? splitk_ws_floats : 0, X2 != nullptr, in_up != 0, apply_table != nullptr, &pl);
+    if (route == 0) {
         // (the first PD_SK_TICKET_FLOATS words of the workspace are k_conv_sk's self-resetting ticket counters: the halo kernel's f32
         // partials -- only under the forced-split tuning hooks -- must not land on them, or the next split k_conv_sk launch never
         // sees its last ticket)
@@ -606,13 +621,10 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
                             res_up, in_up);
     }
     // small-M layers (output tiles do not fill the chip): small tiles, deep staging, split-K combined inside the launch
-    if (in_up == 0 && apply_table == nullptr && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
-        const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, X2 != nullptr, splitk_ws ? splitk_ws_floats : 0);
-        if (pl.bm > 0) {
-            float* gnp = (gn_part != nullptr && (((long long)H * W) % pl.bm == 0 || pl.bm == 2 * H * W)) ? gn_part : nullptr;
-            return conv_sk(pl, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, taps, zero_page, s, splitk_ws, splitk_ws_floats, gnp,
-                           gn_fused, X2, Cin1, res_up);
-        }
+    if (route == 1) {
+        float* gnp = (gn_part != nullptr && (((long long)H * W) % pl.bm == 0 || pl.bm == 2 * H * W)) ? gn_part : nullptr;
+        return conv_sk(pl, X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, taps, zero_page, s, splitk_ws, splitk_ws_floats, gnp,
+                       gn_fused, X2, Cin1, res_up);
     }
     // (the first PD_SK_TICKET_FLOATS words of the split-K workspace are k_conv_sk's ticket counters)
     if (splitk_ws != nullptr) {

@@ -20,7 +20,7 @@ namespace {
 struct ConvW { half_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, cout_pad = 0, taps = 0; bool have_w = false, have_b = false; };
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; bool have_g = false, have_b = false; };
 struct ResB { std::string name; int cin, cout, mode; NormW n1, n2; ConvW c1, c2, skip; long long emb_off; bool has_skip; bool have_ew = false, have_eb = false;
-              half_t* c2s_w = nullptr; float* c2s_b = nullptr; bool c2s_ready = false; };   // conv2 with the skip 1x1 appended to its K loop (conv_sk_skip), built on first use
+              half_t* c2s_w = nullptr; float* c2s_b = nullptr; bool c2s_ready = false; };   // conv2 with the skip 1x1 appended to its K loop (conv_sk_skip), built by pdhip_unet_load_tensor once its four sources are loaded
 struct AttB { std::string name; int c; NormW n; ConvW qkv, proj; };
 struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 
@@ -311,10 +311,7 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
         const SkPlan pl = conv_sk_plan(c.N, h1.H, h1.W, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, false, c.u->splitk_floats, rb.skip.cin);
         if (pl.bm > 0) {
             PD_REQUIRE(rb.c2.have_w && rb.c2.have_b && rb.skip.have_w && rb.skip.have_b, "unet: conv2 / skip weights of %s not loaded", rb.name.c_str());
-            if (!rb.c2s_ready) {
-                PD_TRY(fuse_skip_weights(rb.c2.w, 9 * rb.c2.cin, rb.skip.w, rb.skip.cin, rb.c2.cout_pad, rb.c2.b, rb.skip.b, rb.cout, rb.c2s_w, rb.c2s_b, c.s));
-                rb.c2s_ready = true;
-            }
+            PD_REQUIRE(rb.c2s_ready, "unet: fused conv2 + skip weights of %s were not built at load time", rb.name.c_str());
             PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
             *out = Act{nullptr, rb.cout, h1.H, h1.W};
             out->p = arena_take(c.u, (size_t)c.N * h1.H * h1.W * rb.cout);
@@ -613,7 +610,6 @@ extern "C" int pdhip_unet_num_tensors(const pdhip_unet* u) {
 
 extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const void* data, int is_f16, const int64_t* shape,
                                       int ndim, void* stream) {
-    if (u) for (ResB& rb : u->res) rb.c2s_ready = false;      // (fused [conv2 | skip] copies are rebuilt on the next forward)
     PD_REQUIRE(u && name_c && data && shape && ndim >= 1 && ndim <= 4, "pdhip_unet_load_tensor: bad arguments");
     u->steps_cached = 0;                         // any weight change invalidates the sampler's per-step embedding table
     hipStream_t s = as_stream(stream);
@@ -677,10 +673,22 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
         if (rest == "emb_layers.1.bias") return load_vec(u->emb_b + rb.emb_off, 2 * rb.cout, &rb.have_eb, 0);
         if (rest == "out_layers.0.weight") return load_vec(rb.n2.g, rb.cout, &rb.n2.have_g, 0);
         if (rest == "out_layers.0.bias") return load_vec(rb.n2.b, rb.cout, &rb.n2.have_b, 0);
-        if (rest == "out_layers.3.weight") return load_conv_w(rb.c2);
-        if (rest == "out_layers.3.bias") return load_vec(rb.c2.b, rb.cout, &rb.c2.have_b, 1);
-        if (rb.has_skip && rest == "skip_connection.weight") return load_conv_w(rb.skip);
-        if (rb.has_skip && rest == "skip_connection.bias") return load_vec(rb.skip.b, rb.cout, &rb.skip.have_b, 1);
+        // The fused [conv2 | skip] copy of conv_sk_skip is (re)built HERE, on the loading stream, as soon as its four source tensors are
+        // present (built lazily inside the first forward it could be merely RECORDED by a HIP-graph capture, and an eager
+        // forward issued before the replay would have read uninitialised weights).
+        auto refuse = [&](int rc) -> int {
+            if (rc != PDHIP_OK || rb.c2s_w == nullptr) return rc;
+            rb.c2s_ready = false;
+            if (rb.c2.have_w && rb.c2.have_b && rb.skip.have_w && rb.skip.have_b && rb.skip.taps == 1) {
+                PD_TRY(fuse_skip_weights(rb.c2.w, 9 * rb.c2.cin, rb.skip.w, rb.skip.cin, rb.c2.cout_pad, rb.c2.b, rb.skip.b, rb.cout, rb.c2s_w, rb.c2s_b, s));
+                rb.c2s_ready = true;
+            }
+            return PDHIP_OK;
+        };
+        if (rest == "out_layers.3.weight") return refuse(load_conv_w(rb.c2));
+        if (rest == "out_layers.3.bias") return refuse(load_vec(rb.c2.b, rb.cout, &rb.c2.have_b, 1));
+        if (rb.has_skip && rest == "skip_connection.weight") return refuse(load_conv_w(rb.skip));
+        if (rb.has_skip && rest == "skip_connection.bias") return refuse(load_vec(rb.skip.b, rb.cout, &rb.skip.have_b, 1));
     }
     for (AttB& ab : u->att) {
         if (!starts(ab.name + ".")) continue;

@@ -22,12 +22,22 @@ _EYES = {}
 
 
 def uniform(shapes):
-    """Can these shape dicts (pipeline.colorize_meshes_batched) be stacked?  Equal tensor shapes throughout."""
+    """Can these shape dicts (pipeline.colorize_meshes_batched) be stacked?  Equal tensor shapes throughout, every tensor of every shape
+    on the SAME device (the caller checks that it is a CUDA device), and atlas maps with the leading singleton dimension stack() indexes away (gb_pos [1, A, A, 3], mask
+    [1, A, A, 1], face ids [1, A, A]) -- anything else takes the per-shape route instead of failing inside torch.stack / [0]."""
     def sig(sh):
         x = sh['xatlas']
-        return (tuple(sh['coords'].shape), tuple(sh['colors'].shape), tuple(sh['vertices'].shape), tuple(sh['faces'].shape),
-                tuple(sh['f_normals'].shape), tuple(x['gb_pos'].shape), tuple(x['mask'].shape), tuple(x['per_atlas_pixel_face_id'].shape))
-    return len(shapes) >= 1 and all(sig(sh) == sig(shapes[0]) for sh in shapes)
+        ts = (sh['coords'], sh['colors'], sh['vertices'], sh['faces'], sh['f_normals'], x['gb_pos'], x['mask'], x['per_atlas_pixel_face_id'])
+        if not all(torch.is_tensor(t) for t in ts) or len({t.device for t in ts}) != 1:
+            return None
+        if not (x['gb_pos'].dim() == 4 and x['mask'].dim() == 4 and x['per_atlas_pixel_face_id'].dim() == 3 and
+                x['gb_pos'].shape[0] == 1 and x['mask'].shape[0] == 1 and x['per_atlas_pixel_face_id'].shape[0] == 1):
+            return None
+        return tuple((tuple(t.shape), t.device) for t in ts)
+    if len(shapes) < 1:
+        return False
+    s0 = sig(shapes[0])
+    return s0 is not None and all(sig(sh) == s0 for sh in shapes[1:])
 
 
 def stack(shapes):

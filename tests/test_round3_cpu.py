@@ -51,6 +51,12 @@ def test_shapes_uniform_and_stack_host_logic():
                                 per_atlas_pixel_face_id=torch.randint(-1, f, (1, a, a), generator=g)))
     a, b, c = mk(50, seed=1), mk(50, seed=2), mk(51, seed=3)
     assert shp.uniform([a, b]) and not shp.uniform([a, c]) and not shp.uniform([a, mk(50, f=8)]) and not shp.uniform([a, mk(50, a=32)])
+    #  equal shapes are not enough: one device throughout, atlas maps with their leading singleton dimension
+    d = mk(50, seed=4); d['colors'] = d['colors'].to('meta')
+    e = mk(50, seed=5); e['xatlas'] = dict(e['xatlas'], mask=e['xatlas']['mask'][0])
+    f_ = mk(50, seed=6); f_['xatlas'] = dict(f_['xatlas'], gb_pos=f_['xatlas']['gb_pos'][0].numpy())
+    assert not shp.uniform([a, d]) and not shp.uniform([d, d]) and not shp.uniform([a, e]) and not shp.uniform([e, e]) and not shp.uniform([a, f_])
+    assert not shp.uniform([])
     st = shp.stack([a, b])
     assert st['coords'].shape == (2, 50, 3) and st['faces'].dtype == torch.int32 and st['faces'].shape == (2, 7, 3)
     assert st['gb_pos'].shape == (2, 16, 16, 3) and st['mask'].shape == (2, 16, 16, 1) and st['face_id'].dtype == torch.int64
