@@ -63,9 +63,9 @@ def save_shrink_triptychs(per_pixel_mask, vis_VAA, kernel, save_path, view_offse
     check(L.pdhip_nbf_triptych(ptr(as_u8(per_pixel_mask.contiguous())), ptr(as_u8(vis_VAA.contiguous())), V, A, int(kernel),
                                ptr(out), ptr(ws), stream()), 'pdhip_nbf_triptych')
     os.makedirs(save_path, exist_ok=True)
-    host = out.cpu().numpy()
+    host, wait = io_utils._host_u8(out)
     for v in range(V):
-        io_utils.save_HWC_u8_img(host[v], os.path.join(save_path, f'{v + view_offset}.png'))
+        io_utils.save_HWC_u8_img(host[v], os.path.join(save_path, f'{v + view_offset}.png'), wait=wait)
 
 
 def per_view_visibility(cams, cam_res, gb_pos, mask, uv_centers, uv_scales, padding, mesh_normalized_depths, edge_dilate_kernels,
