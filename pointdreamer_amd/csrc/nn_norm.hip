@@ -190,7 +190,9 @@ __device__ __forceinline__ float gn_elem(float x, float ga, float gb, float t1, 
 // grid (pixel chunks, N).  thread -> (pixel sub-slot, channel octet): the octet's affine constants live in
 // registers for the whole chunk; consecutive threads touch consecutive 16-byte octets (full 128-B lines).
 // RES: 0 none, 1 avgpool2 (of activated values), 2 nearest-up2.
-#define GNA_ITERS 32
+#define GNA_ITERS 8        // pixels per thread (round 5: 32 -> 8, -0.5 % on the batch-32 forward, -0.6 % at batch 1; 4 ties, 2 and 1 lose to the per-thread
+                           // constant set-up.  The chip's copy ceiling -- 6.2 TB/s -- is only reached by ONE 16-byte element per thread in
+                           // hundreds of thousands of workgroups; any per-thread loop copies at 4.8-5.4 TB/s: bench.py calibration.copy16_sweep_gbs)
 // The statistics come either finished (stats [N][32][2], FIN = false) or as the producing convs' octet partials (GnParts, FIN = true):
 // at small batches every workgroup re-reduces its image's few hundred partials itself (L2-resident, f64, fixed order) and the
 // k_gn_finalize_oct launch -- 94 per forward, 5 us each at batch 1 -- disappears.
@@ -367,7 +369,7 @@ int gn_apply(const half_t* X, const float* stats, const float* gamma, const floa
     PD_REQUIRE(film == nullptr || resample == 0, "gn_apply: FiLM only without resampling");
     const int Ho = resample == 1 ? H / 2 : (resample == 2 ? H * 2 : H), Wo = resample == 1 ? W / 2 : (resample == 2 ? W * 2 : W);
     const int opp = C >> 3, pps = max(1, 256 / opp);
-    // pixels per thread: 32 on the big tensors (constants amortised), fewer on the small ones so that the grid still fills
+    // pixels per thread: GNA_ITERS on the big tensors (constants amortised), fewer on the small ones so that the grid still fills
     // the chip (a 64-pixel 8x8 level with 32 pixels per thread is 8 workgroups walking a serial latency chain)
     int iters = g_gn_iters > 0 ? g_gn_iters : GNA_ITERS;
     // (with the in-kernel statistics every workgroup pays the re-reduction of its image's partials first: fewer, longer workgroups --
