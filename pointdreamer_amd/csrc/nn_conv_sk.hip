@@ -656,7 +656,9 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
     // The 128x128 tile takes the loader-specialised form instead (8): 26.2 vs 26.8 us at 128^2 batch 1, 42.4 vs 44.3 at 32^2 batch 8.
     // (four K-groups exist for the 64x32 tile only: on the 64x64 tile the form needed 138 spilled VGPRs and was never routed)
     if (kg == 4 && pl.tile_id != 4) kg = 2;
-    if (kg == 0) kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 8 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
+    // (round 5: the 128x128 tile's loader-specialised form runs with EIGHT loader waves -- 12 waves, 133 VGPRs: 26.5 -> 25.7 us at 128^2
+    // batch 1, 43.7 -> 42.2 at 32^2 batch 8, 51.6 -> 50.2 at 16^2 batch 8, profiles/r05_sk_probe.txt)
+    if (kg == 0) kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 12 : (pl.tile_id == 4 && taps * (Cin / 64) / pl.splits >= 32) ? 4 : 2;
 #define SK_L(T, BM_, BN_, NST_, KG_) launch_sk<T, BM_, BN_, NST_, KG_>(SK_ARGS)
 #define SK_LS(T, BM_, BN_, NST_) launch_sk<T, BM_, BN_, NST_, 1, true>(SK_ARGS)
 #define SK_LS8(T, BM_, BN_, NST_) launch_sk<T, BM_, BN_, NST_, 1, true, 8>(SK_ARGS)
@@ -711,7 +713,7 @@ int conv_sk_skip(const SkPlan& pl, const half_t* X, const half_t* Wt, const floa
     const int grid = total * pl.splits;
     const int kg = grid >= 384 ? 1 : pl.tile_id == 1 ? 8 : (pl.tile_id == 4 && (9 * (Cin / 64) + Cs / 64) / pl.splits >= 32) ? 4 : 2;
 #define SKS_ARGS grid, s, X, Wt, bias, nullptr, Y, N, H, W, Cin, Cout, n_tiles, total, zero_page, pl.splits, slabs, tickets, gn_part, nullptr, Cin, 0, XS, XS2, Cs1, Cs
-    if (pl.tile_id == 1) return kg == 8 ? launch_sk<10, 128, 128, 3, 1, true>(SKS_ARGS) : kg == 1 ? launch_sk<10, 128, 128, 2, 1>(SKS_ARGS) : launch_sk<10, 128, 128, 2, 2>(SKS_ARGS);
+    if (pl.tile_id == 1) return kg == 8 ? launch_sk<10, 128, 128, 3, 1, true, 8>(SKS_ARGS) : kg == 1 ? launch_sk<10, 128, 128, 2, 1>(SKS_ARGS) : launch_sk<10, 128, 128, 2, 2>(SKS_ARGS);
     if (pl.tile_id == 2) return kg == 1 ? launch_sk<10, 128, 64, 3, 1>(SKS_ARGS) : launch_sk<10, 128, 64, 3, 2>(SKS_ARGS);
     if (pl.tile_id == 3) return kg == 1 ? launch_sk<10, 64, 64, 4, 1>(SKS_ARGS) : launch_sk<10, 64, 64, 4, 2>(SKS_ARGS);
     return kg == 1 ? launch_sk<10, 64, 32, 4, 1>(SKS_ARGS) : kg == 4 ? launch_sk<10, 64, 32, 3, 4>(SKS_ARGS) : launch_sk<10, 64, 32, 4, 2>(SKS_ARGS);

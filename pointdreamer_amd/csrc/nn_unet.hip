@@ -226,6 +226,9 @@ int run_gn(Ctx& c, const Act& x, const NormW& n, const float* film, long long fi
     out->p = arena_take(c.u, (size_t)c.N * out->H * out->W * x.C);
     if (c.dry) return PDHIP_OK;
     PD_REQUIRE(n.have_g && n.have_b, "unet: norm weights not loaded");
+#ifdef PD_LAB_SKIP_GN                                       // (lab, timing only -- WRONG results: what the small-level GroupNorm-apply launches cost)
+    if (resample == 0 && x.p2 == nullptr && x.W <= 128 && silu) { out->p = x.p; return PDHIP_OK; }
+#endif
     // small batches: the apply kernel reduces the octet partials itself (no k_gn_finalize_oct launch); large batches: every
     // workgroup re-reducing its image's partials costs more than the 5 us launch it removes
     if (x.gn_part != nullptr && ((x.C / 32) % 8) == 0 && (x.C >> 3) <= 256 && g_fold_finalize > 0 &&
