@@ -94,3 +94,48 @@ def test_unet_full_vs_reference_fp16_forward(nn, N):
         if factor == 1.0:
             l32 = _rel(out, torch.from_numpy(g['ref_out']))
             _note(test='full_fp32', batch=N, linf=l32[0], l2=l32[1])
+
+
+# D1 o U1 against the reference's sampler driving its OWN fp16 UNet (tools/gen_golden_nn.py ddnm_full16): bounds = 2x measured
+DRIFT16_L2, DRIFT16_LINF = 6.5e-4, 7.0e-4        # x sqrt(k + 1); measured 3.1e-4 / 3.4e-4 at batch 1 and 8 (profiles/r05_u1_bounds.txt)
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_ddnm_unet_full_multistep_vs_reference_sampler_with_its_fp16_unet(nn, batch):
+    """The reference's simplified_ddnm_inpainting (diffusion.py:459-570) driving the reference's fp16 UNetModel (use_fp16: true +
+    convert_to_fp16(), the configuration it ships: configs/imagenet_256.yml:26) for the first 10 steps of the schedule on two images;
+    the engine runs the same steps with the fixture's noise tape at UNet batch 1 and 8."""
+    import ctypes as C
+    from tools.gen_golden_nn import ddnm_full_inputs
+    L = nn['L']
+    P = lambda t_: C.c_void_p(t_.data_ptr())
+    S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = load_golden('ddnm_unet_full_fp16.npz')
+    steps, n_img, st = int(g['steps']), int(g['n_img']), int(g['stride'])
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, int(g['weight_seed']))
+    m = nn['di'].UNetModel(max_batch=batch, device=DEV, **nn['di'].IMAGENET_256)
+    m.load_state_dict(w, strict=True)
+    del w
+    masked, masks, tape = ddnm_full_inputs(int(g['seed']), n_img, steps)
+    sel = [i % n_img for i in range(batch)]
+    mk = torch.from_numpy(masked[sel]).to(DEV).contiguous()
+    ms = torch.from_numpy(masks[sel]).to(DEV).contiguous()
+    tp = torch.from_numpy(tape[sel]).to(DEV)
+    HW = 256 * 256
+    y = torch.empty_like(mk)
+    assert L.pdhip_ddnm_prepare(P(mk), P(ms), P(y), batch, HW, S()) == 0
+    x = tp[:, 0].clone().contiguous()
+    _, _, t_sched, _, _ = nn['di'].ddnm_schedule()
+    worst = [0.0, 0.0]
+    for k in range(steps):
+        tt = torch.full((batch,), float(t_sched[k]), device=DEV)
+        et = m(x, tt)
+        eps = tp[:, k + 1].contiguous()
+        assert L.pdhip_ddnm_step(P(x), P(et), 6, P(y), P(ms), P(eps), 0, k, batch, HW, S()) == 0, L.pdhip_last_error()
+        xs = x[:, :, ::st, ::st].cpu()
+        for b in range(batch):
+            linf, l2 = _rel(xs[b], torch.from_numpy(g['xs'][sel[b], k]))
+            worst = [max(worst[0], linf / np.sqrt(k + 1)), max(worst[1], l2 / np.sqrt(k + 1))]
+            assert l2 <= DRIFT16_L2 * np.sqrt(k + 1) and linf <= DRIFT16_LINF * np.sqrt(k + 1), (batch, b, k, linf, l2)
+    _note(test='ddnm_full_fp16_drift_per_sqrt_k', batch=batch, linf=worst[0], l2=worst[1])

@@ -213,7 +213,7 @@ def ddnm_full_inputs(seed, n_img, steps, S=256):
     return imgs * masks[:, None], masks, tape
 
 
-def gen_ddnm_full(name, steps=10, n_img=2, seed=2024, stride=4):
+def gen_ddnm_full(name, steps=10, n_img=2, seed=2024, stride=4, fp16=False):
     """D1 o U1 at full size: the reference's own simplified_ddnm_inpainting (diffusion.py:459-570) driving the reference's own
     fp32 UNetModel (552.8 M parameters, seeded weights) for the first `steps` of the 100-step schedule; the loop is cut after
     `steps` updates by the model wrapper.  Stored: a strided sample of x_k after every update and the full x after the last."""
@@ -233,7 +233,7 @@ def gen_ddnm_full(name, steps=10, n_img=2, seed=2024, stride=4):
     config = to_ns(yaml.safe_load(open(os.path.join(rh.REF, 'models/DDNM/configs/imagenet_256.yml'))))
     cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
     w = ounet.random_weights(cfg, 12)
-    model = ref_unet(FULL, w)
+    model = ref_unet_fp16(FULL, w) if fp16 else ref_unet(FULL, w)      # fp16: the reference's own fp16 torso, same sampler
     masked, masks, tape = ddnm_full_inputs(seed, n_img, steps)
     xs_all, final_all = [], []
 
@@ -376,6 +376,8 @@ def main():
         gen_unet_fp16('unet_full_fp16.npz', FULL, seed=12, batch=1, stride=8, src='unet_full.npz', boosts=(2048.0, 4096.0))
     if 'ddnm_full' in which:
         gen_ddnm_full('ddnm_unet_full.npz')
+    if 'ddnm_full16' in which:
+        gen_ddnm_full('ddnm_unet_full_fp16.npz', fp16=True)
     if 'ddnm_full100' in which:
         gen_ddnm_full100('ddnm_unet_full100.npz')
 
