@@ -499,7 +499,11 @@ __global__ __launch_bounds__(LS ? (4 + NL) * 64 : KG * 256) void k_conv_sk(const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
+#ifdef PD_LAB_SK_NTSTORE                                    // (lab: streaming output stores -- does a clean L2 shorten the kernel boundary?)
+            __builtin_nontemporal_store(v, reinterpret_cast<half8*>(Y + o));
+#else
             *reinterpret_cast<half8*>(Y + o) = v;
+#endif
             float s8 = 0.f, q8 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s8 += f; q8 += f * f; }
