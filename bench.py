@@ -345,7 +345,7 @@ def main():
     import pointdreamer_amd.camera_utils as cu
     # (torch sizes its intra-op CPU pool by the host's logical CPUs -- 256 on the pool's boxes -- while the container's cgroup grants 16:
     # an oversized OpenMP region exhausts the CFS quota and throttles the launch thread; the host side of a step is small tensors)
-    torch.set_num_threads(max(1, min(8, io_utils.usable_cpus() // 2)))
+    torch.set_num_threads(max(1, min(8, io_utils.cpus_per_rank() // 2)))
     import pointdreamer_amd.ddnm_inpainting as di
     from pointdreamer_amd import dist as pdist
     _lib.lib()

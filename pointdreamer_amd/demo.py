@@ -280,7 +280,7 @@ def main(argv=None):
     # grants 16 -- a 128-thread OpenMP region around a 90 000-element `.float()` next to the PNG-encoder threads exhausts the CFS quota
     # and the whole process is throttled for the rest of the period (round 5: 99 ms per `_load_shape` in a directory run against 2.5 ms
     # alone).  The CLI's CPU tensors are small: a few threads, inside the quota.
-    torch.set_num_threads(max(1, min(4, io_utils.usable_cpus() // 4)))
+    torch.set_num_threads(max(1, min(4, io_utils.cpus_per_rank() // 4)))
     # one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m pointdreamer_amd.demo ...`): every rank textures its
     # own contiguous block of the directory's clouds -- independent shapes, no collective on the data path
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -303,7 +303,7 @@ def main(argv=None):
     outs = []
     # PNG / OBJ encoding of one shape runs on host threads under the GPU work of the next (io_utils.set_async); every file is on
     # disk when main() returns
-    io_utils.set_async(True, workers=max(2, min(8, io_utils.usable_cpus() - 4)))
+    io_utils.set_async(True, workers=max(2, min(8, io_utils.cpus_per_rank() - 4)))
     try:
         for g0 in range(0, len(pc_files), group):
             chunk = pc_files[g0:g0 + group]

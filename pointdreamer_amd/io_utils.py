@@ -84,6 +84,11 @@ def usable_cpus():
     return n
 
 
+def cpus_per_rank():
+    """usable_cpus() shared between the ranks of this node (torchrun's LOCAL_WORLD_SIZE; one process per GPU)."""
+    return max(1, usable_cpus() // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', 1))))
+
+
 def set_async(on, workers=8):
     global _pool
     flush()
