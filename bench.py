@@ -18,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -318,6 +319,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU rehearsal of the N > 1 path)")
     ap.add_argument('--one-device', action='store_true', help='rehearsal of the N > 1 code path on a one-GPU box: every rank uses cuda:0 (with --backend gloo)')
     ap.add_argument('--no-extras', action='store_true', help='skip the nearest-workload / one-shape-latency side measurements')
+    ap.add_argument('--extras-timeout', type=float, default=300.0, help='N > 1: seconds the view-parallel side figure may take before the headline line is printed without it')
     ap.add_argument('--shapes-per-step', type=int, default=4,
                     help='independent shapes textured per step on each GPU, their 8-view sets batched through the UNet together '
                          '(BASELINE configs[4] style); 1 = one shape at a time (configs[2], lowest latency).  What each setting measures on '
@@ -431,6 +433,44 @@ def main():
 
     roofline = None
     extras = {}
+
+    def finish(extras_, from_watchdog=False):
+        calib = None
+        if rank == 0 and inpainter is not None and not args.no_extras and not from_watchdog:
+            calib = calibrate(dev)
+            if roofline is not None and calib.get('gemm_f16_random_tflops'):
+                roofline['calibrated_peak'] = calib['gemm_f16_random_tflops']
+                roofline['frac_of_calibrated'] = roofline['achieved'] / calib['gemm_f16_random_tflops'] if roofline.get('achieved') else None
+                roofline['calibration'] = calib
+        if roofline is not None and under_load is not None:
+            roofline.setdefault('calibration', {})['under_load'] = under_load
+            for k in ('sclk_mhz_under_load_mean', 'sclk_mhz_under_load_min', 'power_w_under_load_mean', 'power_cap_w'):
+                if k in under_load:
+                    roofline['calibration'][k if 'sclk' in k else k.replace('_under_load', '')] = under_load[k]
+            clk = under_load.get('sclk_mhz_under_load_mean') or under_load.get('dpm_sclk_mhz_under_load_mean')
+            if clk and roofline.get('achieved'):
+                # the dense peak is quoted at the 2 400 MHz maximum clock: the same matrix pipes at the clock the timed region actually ran at
+                roofline['clock_adjusted_peak'] = PEAK_FP16_TFLOPS * clk / 2400.0
+                roofline['frac_of_clock_adjusted_peak'] = roofline['achieved'] / roofline['clock_adjusted_peak']
+        if world > 1 and not from_watchdog:
+            dist.barrier()
+        if rank == 0:
+            out = dict(metric=f"shapes/hour (30k-pt cloud, 8x256^2 views, {'DDNM' if args.workload == 'ddnm' else 'nearest inpainting, no diffusion'}) on MI355X", value=value, unit="shapes/hour",
+                       n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+                       higher_is_better=True, scaling="weak" if args.parallel == 'shapes' else "strong", vs_baseline=None,
+                       dtype="f16 (f32 accumulate; f32 GroupNorm/softmax statistics, f32 geometry)", data="synthetic",
+                       config=dict(workload=f"configs[2]: synthetic 30k-point sphere shape, 8x256^2 views, texture_gen_method="
+                                            f"'{method}' ({args.ddnm_steps} DDNM steps, 552.8M-param guided-diffusion UNet, random-init weights), "
+                                            f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, hidden-point removal on (device)" + (f"; {SPS} independent shapes per step, their views batched through the UNet together" if SPS > 1 else ""),
+                                   parallelism=f"{args.parallel}-parallel x{world}", views_per_unet_batch=views_here,
+                                   shapes_per_step=world * SPS if args.parallel == 'shapes' else 1),
+                       roofline=roofline, extras=extras_ or None)
+            if world == 1 and not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline()
+            else:
+                out['cpu_baseline'] = None
+            print(json.dumps(out), flush=True)
+
     if inpainter is not None:
         ms, flops, launches = inpainter.model.profile_read()
         ams, aflops, alaunches = inpainter.model.profile_read(attention=True)
@@ -546,6 +586,13 @@ def main():
         # the north_star's scaling claim (configs[3]): ONE shape, its 8 views sharded over the ranks, one RCCL all_gather -- run after the
         # timed region on every rank, next to the same shape on rank 0 alone (UNet batch 8), so the line carries the speed-up itself
         if world > 1 and args.parallel == 'shapes' and not args.no_extras and world <= V:
+            # (this side figure is the only collective after the timed region and has never met N > 1 hardware: if it does not come
+            # back, every rank leaves through the watchdog and rank 0 still prints the headline line)
+            watchdog = threading.Timer(args.extras_timeout, lambda: (finish(dict(extras, view_parallel=dict(
+                error=f"no result within {args.extras_timeout:.0f} s: side figure abandoned, headline unaffected")), True) if rank == 0 else None,
+                os._exit(0)))
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 vp = lambda: pdist.colorize_one_mesh_view_parallel(g0['points'], g0['colors'], g0['vertices'], g0['faces'], g0['f_normals'],
                                                                   xatlas0, camera_info, rank=rank, world=world, **cfg)
@@ -574,44 +621,11 @@ def main():
                                                speedup_vs_n1_one_shape=(d1 / dvp) if d1 else None)
             except Exception as e:                          # noqa: BLE001 -- a side figure must not take the headline line down
                 extras['view_parallel'] = dict(error=str(e)[:300])
+            watchdog.cancel()
     else:
         roofline = dict(bound="hbm", kernel="n/a (nearest workload: sub-millisecond HBM-bound kernels)", achieved=None, peak=8000.0,
                         unit="GB/s", frac=None, traffic=None)
-    calib = None
-    if rank == 0 and inpainter is not None and not args.no_extras:
-        calib = calibrate(dev)
-        if roofline is not None and calib.get('gemm_f16_random_tflops'):
-            roofline['calibrated_peak'] = calib['gemm_f16_random_tflops']
-            roofline['frac_of_calibrated'] = roofline['achieved'] / calib['gemm_f16_random_tflops'] if roofline.get('achieved') else None
-            roofline['calibration'] = calib
-    if roofline is not None and under_load is not None:
-        roofline.setdefault('calibration', {})['under_load'] = under_load
-        for k in ('sclk_mhz_under_load_mean', 'sclk_mhz_under_load_min', 'power_w_under_load_mean', 'power_cap_w'):
-            if k in under_load:
-                roofline['calibration'][k if 'sclk' in k else k.replace('_under_load', '')] = under_load[k]
-        clk = under_load.get('sclk_mhz_under_load_mean') or under_load.get('dpm_sclk_mhz_under_load_mean')
-        if clk and roofline.get('achieved'):
-            # the dense peak is quoted at the 2 400 MHz maximum clock: the same matrix pipes at the clock the timed region actually ran at
-            roofline['clock_adjusted_peak'] = PEAK_FP16_TFLOPS * clk / 2400.0
-            roofline['frac_of_clock_adjusted_peak'] = roofline['achieved'] / roofline['clock_adjusted_peak']
-    if world > 1:
-        dist.barrier()
-    if rank == 0:
-        out = dict(metric=f"shapes/hour (30k-pt cloud, 8x256^2 views, {'DDNM' if args.workload == 'ddnm' else 'nearest inpainting, no diffusion'}) on MI355X", value=value, unit="shapes/hour",
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-                   higher_is_better=True, scaling="weak" if args.parallel == 'shapes' else "strong", vs_baseline=None,
-                   dtype="f16 (f32 accumulate; f32 GroupNorm/softmax statistics, f32 geometry)", data="synthetic",
-                   config=dict(workload=f"configs[2]: synthetic 30k-point sphere shape, 8x256^2 views, texture_gen_method="
-                                        f"'{method}' ({args.ddnm_steps} DDNM steps, 552.8M-param guided-diffusion UNet, random-init weights), "
-                                        f"NBF [21], atlas 1024^2, complete_unseen_by='unproject', optimize_from=None, hidden-point removal on (device)" + (f"; {SPS} independent shapes per step, their views batched through the UNet together" if SPS > 1 else ""),
-                               parallelism=f"{args.parallel}-parallel x{world}", views_per_unet_batch=views_here,
-                               shapes_per_step=world * SPS if args.parallel == 'shapes' else 1),
-                   roofline=roofline, extras=extras or None)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
-        else:
-            out['cpu_baseline'] = None
-        print(json.dumps(out))
+    finish(extras)
     if world > 1:
         dist.destroy_process_group()
 
