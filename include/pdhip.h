@@ -187,6 +187,11 @@ int pdhip_linear_fill(const float* img, float* out, int B, int C, int H, int W, 
 int pdhip_linear_fill_unresolved(const void* ws, int B, int H, int W, int* out, void* stream);
 int pdhip_debug_set_linear_local(int on);   /* tuning / test hook: 1 (default) = local 16x16-tile window pass first, global scans only for what it cannot certify; 0 = global scans only */
 
+/* test / lab hook: 1 = Uq1-Uq4 run their run-time-view-count kernels even at V = 8 (default 0: the view loop is unrolled at V = 8 and
+ * the view selection skips the softmax exponentials where the selected view provably does not depend on them; same results bit for
+ * bit, tests/test_gpu_round5.py).  Returns the previous value; thread-local. */
+int pdhip_debug_set_unproject_generic(int on);
+
 /* ---- Uq1+Uq2: unproject.unproject texel transform + depth visibility (unproject.py:219-284).
  *      visibility[V,A,A] u8 (0 outside the chart mask). */
 int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos /*[A,A,3]*/,

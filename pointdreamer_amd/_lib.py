@@ -52,6 +52,7 @@ _SIGS = {
     'pdhip_linear_fill': (C.c_int, [vp, vp, i32, i32, i32, i32, vp, i32, i64, vp, vp, vp]),
     'pdhip_linear_fill_unresolved': (C.c_int, [vp, i32, i32, i32, vp, vp]),
     'pdhip_debug_set_linear_local': (C.c_int, [i32]),
+    'pdhip_debug_set_unproject_generic': (C.c_int, [i32]),
     'pdhip_texel_visibility': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, f64, vp, i32, f32, vp, vp]),
     'pdhip_nbf_shrink': (C.c_int, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
     'pdhip_nbf_triptych': (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),

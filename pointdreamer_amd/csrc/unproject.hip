@@ -7,6 +7,8 @@
 using namespace pdhip;
 
 #define MAXV 32
+static thread_local int g_unproject_generic = 0;        // test / lab hook: 1 = the run-time-V kernels even at V = 8
+extern "C" int pdhip_debug_set_unproject_generic(int on) { const int old = g_unproject_generic; g_unproject_generic = on; return old; }
 
 // ------------------------------------------------------------------------------ Uq1 + Uq2
 // (measured: four texels per thread with 16-byte position loads and 4-byte verdict stores is SLOWER, 34 vs 28 us -- the kernel is
@@ -41,6 +43,44 @@ __global__ void k_texel_visibility(const float* __restrict__ cams, int V, const 
     }
 }
 
+// The same with the view count a compile-time constant (round 5): a texel's VC depth-map reads are independent, but with a run-time
+// trip count the loop is gather -> wait -> store, VC times in a row; unrolled, all VC gathers are in flight together and the verdicts
+// are stored after one wait.  Same expressions in the same order per view (the verdict is a comparison: bit-identical).
+template <int VC>
+__global__ __launch_bounds__(256) void k_texel_visibility_v(const float* __restrict__ cams, const float* __restrict__ gb_pos,
+                                                            const uint8_t* __restrict__ mask, int A, const float* __restrict__ uv_centers,
+                                                            const float* __restrict__ uv_scales, float pad9, const float* __restrict__ mesh,
+                                                            int R, float offset, uint8_t* __restrict__ vis, int S) {
+    const size_t n = (size_t)A * A, total = n * (size_t)S;
+    for (size_t gidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t sh = gidx / n, idx = gidx - sh * n;
+        const bool m = mask[gidx];
+        uint8_t o[VC];
+#pragma unroll
+        for (int v = 0; v < VC; ++v) o[v] = 0;
+        if (m) {
+            const float x = gb_pos[3 * gidx], y = gb_pos[3 * gidx + 1], z = gb_pos[3 * gidx + 2];
+            float zn[VC], ref[VC];
+#pragma unroll
+            for (int v = 0; v < VC; ++v) {
+                const size_t g = sh * VC + v;
+                const Cam c = load_cam(cams + 16 * v);
+                float xn, yn;
+                cam_transform(c, x, y, z, xn, yn, zn[v]);
+                float u = ((xn - uv_centers[2 * g]) / uv_scales[g]) * pad9 + 0.5f;
+                float w = ((yn - uv_centers[2 * g + 1]) / uv_scales[g]) * pad9 + 0.5f;
+                int col = clip_to_int(u * (float)R, R - 1);
+                int row = clip_to_int(w * (float)R, R - 1);
+                ref[v] = mesh[(g * R + row) * R + col];
+            }
+#pragma unroll
+            for (int v = 0; v < VC; ++v) o[v] = ((zn[v] - ref[v]) <= offset) ? 1 : 0;
+        }
+#pragma unroll
+        for (int v = 0; v < VC; ++v) vis[(sh * VC + v) * n + idx] = o[v];
+    }
+}
+
 // S atlases with V views each in ONE launch: gb_pos [S,A,A,3], mask [S,A,A]; cam_params [V] shared by the shapes; uv_centers / uv_scales /
 // mesh_depths / visibility have S*V leading entries (view g = s * V + v).  S = 1: pdhip_texel_visibility.
 extern "C" int pdhip_texel_visibility_shapes(const float* cam_params, int V, int S, const float* gb_pos, const uint8_t* mask, int A,
@@ -50,8 +90,11 @@ extern "C" int pdhip_texel_visibility_shapes(const float* cam_params, int V, int
     PD_REQUIRE(cam_params && gb_pos && mask && uv_centers && uv_scales && mesh_depths && visibility,
                "pdhip_texel_visibility: null pointer");
     const float pad9 = (float)(1.0 - 2.0 * padding);
-    k_texel_visibility<<<min(cdiv((long long)A * A * S, 256), 4096 * min(S, 8)), 256, 0, as_stream(stream)>>>(
-        cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility, S);
+    const int grid = min(cdiv((long long)A * A * S, 256), 4096 * min(S, 8));
+    if (V == 8 && g_unproject_generic == 0)
+        k_texel_visibility_v<8><<<grid, 256, 0, as_stream(stream)>>>(cam_params, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility, S);
+    else
+        k_texel_visibility<<<grid, 256, 0, as_stream(stream)>>>(cam_params, V, gb_pos, mask, A, uv_centers, uv_scales, pad9, mesh_depths, R, offset, visibility, S);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -386,7 +429,7 @@ __global__ void k_view_select_blend(const float* __restrict__ cams, int V, const
             int bi = 0;
             for (int v = 0; v < V; ++v) {
                 float w = ((cand >> v) & 1u) ? sim[v] / sum : -100.0f;
-                if (w > best) { best = w; bi = v; }
+                if (w > best || (w != w && best == best)) { best = w; bi = v; }       // (torch.argmax: the first NaN is the maximum)
             }
             vid = bi;
             if (!complete && !cand) vid = -100;
@@ -395,6 +438,106 @@ __global__ void k_view_select_blend(const float* __restrict__ cams, int V, const
                 const size_t g = sh * V + vid;
                 float xn, yn, zn;
                 cam_transform(c, gb_pos[3 * gidx], gb_pos[3 * gidx + 1], gb_pos[3 * gidx + 2], xn, yn, zn);
+                float u = (((xn - uv_centers[2 * g]) / uv_scales[g]) * scale_factors[g]) * pad9 + 0.5f;
+                float w = (((yn - uv_centers[2 * g + 1]) / uv_scales[g]) * scale_factors[g]) * pad9 + 0.5f;
+                int col = clip_to_int(u * (float)r, r - 1);
+                int row = clip_to_int(w * (float)r, r - 1);
+                const float* img = inpainted + g * 3 * r * r + (size_t)(r - 1 - row) * r + col;
+                o0 = img[0]; o1 = img[(size_t)r * r]; o2 = img[2 * (size_t)r * r];
+                pt = 1;
+            }
+        }
+        atlas[3 * gidx] = o0; atlas[3 * gidx + 1] = o1; atlas[3 * gidx + 2] = o2;
+        painted[gidx] = pt;
+        view_ids[gidx] = vid;
+    }
+}
+
+// The same with the view count a compile-time constant (round 5).  (i) The VC candidate bytes of a level, the face id and the position
+// are requested together (a run-time loop asked for them one at a time).  (ii) The selected view is the FIRST maximum of
+// w_v = float(exp(double(sim_v - mx))) / sum over the candidates; x -> float(exp(double(x - mx))) and y -> y / sum are monotone
+// non-decreasing, so that is the first maximum of sim_v itself unless an EARLIER candidate with a smaller sim rounds to the same
+// weight.  If every earlier candidate is below the maximum by >= 1e-5 its weight is smaller by a factor >= 1 + 8e-6 -- a hundred f32
+// ulps, no rounding of the exponential, of the sum or of the quotient can close that -- and the eight f64 exponentials (more than half
+// of the generic kernel's time) are skipped.  Anything closer, and any non-finite similarity, takes the generic expressions.
+template <int VC>
+__global__ __launch_bounds__(256) void k_view_select_blend_v(const float* __restrict__ cams, const float* __restrict__ gb_pos,
+                                    const uint8_t* __restrict__ mask, const int64_t* __restrict__ face_id, int A,
+                                    const float* __restrict__ f_normals, const float* __restrict__ base_dirs,
+                                    const float* __restrict__ uv_centers, const float* __restrict__ uv_scales, float pad9,
+                                    const float* __restrict__ scale_factors, const uint8_t* __restrict__ shrinked, int K,
+                                    const uint8_t* __restrict__ visibility, int complete,
+                                    const float* __restrict__ inpainted, int r, float* __restrict__ atlas,
+                                    uint8_t* __restrict__ painted, int32_t* __restrict__ view_ids, int S, int F) {
+    const size_t n = (size_t)A * A, total = n * (size_t)S;
+    for (size_t gidx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; gidx < total; gidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t sh = gidx / n, idx = gidx - sh * n;
+        const size_t VT = (size_t)S * VC;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        uint8_t pt = 0;
+        int vid = -1;
+        if (mask[gidx]) {
+            uint8_t sb[VC];
+#pragma unroll
+            for (int v = 0; v < VC; ++v) sb[v] = shrinked[(sh * VC + v) * n + idx];
+            const int64_t f = face_id[gidx];
+            const float px_ = gb_pos[3 * gidx], py_ = gb_pos[3 * gidx + 1], pz_ = gb_pos[3 * gidx + 2];
+            uint32_t cand = 0;
+#pragma unroll
+            for (int v = 0; v < VC; ++v) cand |= (sb[v] ? 1u : 0u) << v;
+            for (int k = 1; k < K && !cand; ++k) {
+#pragma unroll
+                for (int v = 0; v < VC; ++v) sb[v] = shrinked[((size_t)k * VT + sh * VC + v) * n + idx];
+#pragma unroll
+                for (int v = 0; v < VC; ++v) cand |= (sb[v] ? 1u : 0u) << v;
+            }
+            if (complete && !cand) {
+#pragma unroll
+                for (int v = 0; v < VC; ++v) sb[v] = visibility[(sh * VC + v) * n + idx];
+#pragma unroll
+                for (int v = 0; v < VC; ++v) cand |= (sb[v] ? 1u : 0u) << v;
+            }
+            const float* fnp = f_normals + 3 * (sh * (size_t)F + (size_t)f);
+            const float n0 = fnp[0], n1 = fnp[1], n2 = fnp[2];
+            float sim[VC];
+            float mx = -INFINITY;
+            bool finite = true;
+#pragma unroll
+            for (int v = 0; v < VC; ++v) {
+                sim[v] = (n0 * base_dirs[3 * v] + n1 * base_dirs[3 * v + 1]) + n2 * base_dirs[3 * v + 2];
+                mx = fmaxf(mx, sim[v]);
+                finite = finite && fabsf(sim[v]) <= 3.0e38f;
+            }
+            // first maximum of sim over the candidates, and the largest sim of a candidate BEFORE it
+            float s1 = -INFINITY, before = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int v = 0; v < VC; ++v)
+                if (((cand >> v) & 1u) && sim[v] > s1) { before = s1; s1 = sim[v]; bi = v; }
+            if (cand != 0u && !(finite && s1 - before >= 1.0e-5f)) {
+                // (generic expressions, same order)
+                float ew[VC];
+                float sum = 0.f;
+#pragma unroll
+                for (int v = 0; v < VC; ++v) {
+                    ew[v] = (float)exp((double)(sim[v] - mx));
+                    sum = sum + ew[v];
+                }
+                float best = -INFINITY;
+                bi = 0;
+#pragma unroll
+                for (int v = 0; v < VC; ++v) {
+                    const float w = ((cand >> v) & 1u) ? ew[v] / sum : -100.0f;
+                    if (w > best || (w != w && best == best)) { best = w; bi = v; }   // (torch.argmax: the first NaN is the maximum)
+                }
+            }
+            vid = bi;
+            if (!complete && !cand) vid = -100;
+            if (vid >= 0) {
+                const Cam c = load_cam(cams + 16 * vid);
+                const size_t g = sh * VC + vid;
+                float xn, yn, zn;
+                cam_transform(c, px_, py_, pz_, xn, yn, zn);
                 float u = (((xn - uv_centers[2 * g]) / uv_scales[g]) * scale_factors[g]) * pad9 + 0.5f;
                 float w = (((yn - uv_centers[2 * g + 1]) / uv_scales[g]) * scale_factors[g]) * pad9 + 0.5f;
                 int col = clip_to_int(u * (float)r, r - 1);
@@ -425,9 +568,15 @@ extern "C" int pdhip_view_select_blend_shapes(const float* cam_params, int V, in
                    scale_factors && shrinked && visibility && inpainted && atlas && painted && view_ids,
                "pdhip_view_select_blend: null pointer");
     const float pad9 = (float)(1.0 - 2.0 * padding);
-    k_view_select_blend<<<min(cdiv((long long)A * A * S, 256), 4096 * min(S, 8)), 256, 0, as_stream(stream)>>>(
-        cam_params, V, gb_pos, mask, face_id, A, f_normals, base_dirs, uv_centers, uv_scales, pad9, scale_factors,
-        shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted, view_ids, S, S == 1 ? 0 : F);
+    const int grid = min(cdiv((long long)A * A * S, 256), 4096 * min(S, 8));
+    if (V == 8 && g_unproject_generic == 0)
+        k_view_select_blend_v<8><<<grid, 256, 0, as_stream(stream)>>>(
+            cam_params, gb_pos, mask, face_id, A, f_normals, base_dirs, uv_centers, uv_scales, pad9, scale_factors,
+            shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted, view_ids, S, S == 1 ? 0 : F);
+    else
+        k_view_select_blend<<<grid, 256, 0, as_stream(stream)>>>(
+            cam_params, V, gb_pos, mask, face_id, A, f_normals, base_dirs, uv_centers, uv_scales, pad9, scale_factors,
+            shrinked, K, visibility, complete_unseen_by_projection, inpainted, r, atlas, painted, view_ids, S, S == 1 ? 0 : F);
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }

@@ -139,3 +139,61 @@ def test_ddnm_unet_full_multistep_vs_reference_sampler_with_its_fp16_unet(nn, ba
             worst = [max(worst[0], linf / np.sqrt(k + 1)), max(worst[1], l2 / np.sqrt(k + 1))]
             assert l2 <= DRIFT16_L2 * np.sqrt(k + 1) and linf <= DRIFT16_LINF * np.sqrt(k + 1), (batch, b, k, linf, l2)
     _note(test='ddnm_full_fp16_drift_per_sqrt_k', batch=batch, linf=worst[0], l2=worst[1])
+
+
+# ---- Uq1-Uq4 with the view loop unrolled at V = 8 and the exponential-free view selection (csrc/unproject.hip, round 5)
+@pytest.mark.parametrize("complete", [True, False])
+def test_unproject_unrolled_views_equal_the_generic_kernels_incl_near_ties(complete):
+    """The V = 8 kernels against the run-time-V kernels (pdhip_debug_set_unproject_generic) and against the oracle at BASELINE sizes, on
+    face normals built to sit ON the decision boundary of the view selection: normal = bisector of two view directions (+ a push of
+    0, 1e-7 .. 1e-4 towards one of them), zero and NaN normals -- the cases where 'first maximum of the similarity' and 'first maximum of
+    the rounded softmax weight' could differ and the kernel must fall back to the generic expressions."""
+    import pointdreamer_amd.ours_utils as ou
+    import pointdreamer_amd.unproject as up
+    import pointdreamer_amd.camera_utils as cu
+    from pointdreamer_amd import synthetic, _lib
+    from oracle import camera as ocam, unproject as ounp
+    L = _lib.lib()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    N_ = lambda t: t.detach().cpu().numpy()
+    sh = synthetic.make_shape(30000, 1024)
+    cams, base_dirs, eyes, ups = cu.create_cameras(8, 1.6, 512, device=DEV)
+    hard, fidx, depth, vuv, uvc, uvs, pad, puv, pdep = ou.get_rendered_hard_mask_and_face_idx_batch(
+        cams, T(sh['vertices']), T(sh['faces']), T(sh['points']), None, True, 0.05)
+    rng = np.random.default_rng(77)
+    inp = torch.from_numpy(rng.random((8, 3, 256, 256), dtype=np.float32)).to(DEV)
+    sf = torch.ones(8, device=DEV)
+    bd = N_(base_dirs).astype(np.float64)
+    F = sh['f_normals'].shape[0]
+    fn = sh['f_normals'].copy()
+    a, b = rng.integers(0, 8, F), rng.integers(0, 8, F)
+    push = rng.choice([0.0, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4], F)
+    adv = bd[a] + bd[b] + push[:, None] * bd[b]
+    nrm = np.linalg.norm(adv, axis=1, keepdims=True)
+    adv = np.where(nrm > 0, adv / np.maximum(nrm, 1e-30), adv)
+    pick = rng.random(F) < 0.7
+    fn[pick] = adv[pick].astype(np.float32)
+    fn[rng.random(F) < 0.01] = 0.0
+    fn[rng.random(F) < 0.01] = np.nan
+    args = (inp, T(fn), 256, cams, 512, base_dirs, T(sh['gb_pos']), T(sh['mask']), T(sh['per_atlas_pixel_face_id']), uvc, uvs, pad, sf, depth,
+            [21, 11], complete)
+    fast = [N_(t) for t in up.unproject_dense(*args)]
+    old = L.pdhip_debug_set_unproject_generic(1)
+    try:
+        gen = [N_(t) for t in up.unproject_dense(*args)]
+    finally:
+        L.pdhip_debug_set_unproject_generic(old)
+    for x, y, name in zip(fast, gen, ('atlas', 'shrinked', 'view_ids', 'painted', 'visibility')):
+        assert np.array_equal(x, y, equal_nan=True), name
+    m = sh['mask'][0, :, :, 0]
+    assert len(np.unique(fast[2][m])) >= 8
+    ocams = [ocam.Camera(N_(c.params), 512) for c in cams]
+    o = ounp.unproject(N_(inp), fn, 256, ocams, 512, N_(base_dirs), sh['gb_pos'], sh['mask'], sh['per_atlas_pixel_face_id'], N_(uvc), N_(uvs), pad,
+                       N_(sf), N_(depth), [21, 11], complete)
+    assert np.array_equal(fast[1], o['shrinked'])
+    bad = fast[2][m] != o['point_view_ids']
+    if bad.any():                                                    # which kind of face disagrees
+        fb = sh['per_atlas_pixel_face_id'].reshape(-1)[m.reshape(-1)][bad]
+        kinds = dict(nan=int(np.isnan(fn[fb]).any(1).sum()), zero=int((fn[fb] == 0).all(1).sum()), adversarial=int(pick[fb].sum()), n=int(bad.sum()))
+        raise AssertionError(f"view ids differ from the oracle: {kinds}, pushes {np.unique(push[fb], return_counts=True)}")
+    assert np.array_equal(fast[0], o['atlas_img'])
