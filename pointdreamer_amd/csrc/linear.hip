@@ -26,42 +26,69 @@ namespace {
 struct i2 { double x, y; };            // integer-valued
 __device__ __forceinline__ double orient(i2 a, i2 b, i2 c) { return (b.x - a.x) * (c.y - a.y) - (b.y - a.y) * (c.x - a.x); }
 
-// per image: sites (x, y, x^2 + y^2 as f32 -- exact below 2^24) in row-major order, queries (pixel index) likewise
-__global__ __launch_bounds__(1024) void k_linear_collect(const void* __restrict__ mask, int mask_is_f32, int64_t mask_bstride, int H,
-                                                         int W, float* __restrict__ sites /*[B][3][H*W]*/, int* __restrict__ qlist /*[B][H*W]*/,
-                                                         int* __restrict__ counts /*[B][2]*/, int* __restrict__ rowstart /*[B][H+1] or null*/,
-                                                         int* __restrict__ fbcount /*[B][2] or null*/, int make_qlist) {
-    __shared__ int s_s[16], s_q[16];
+// per image: sites (x, y, x^2 + y^2 as f32 -- exact below 2^24) in row-major order, queries (pixel index) likewise.  Three launches
+// (round 5; one 1024-thread block per image walking its pixels behind 2 x 64 block barriers took 87 us for 8 views of 256^2): one
+// wavefront per image row counts the row's sites, one block per image turns the row counts into row offsets, one wavefront per row
+// writes its sites / queries at the row's offset.  rowstart[b][y] = sites before row y (rowstart[b][H] = all), rowq likewise for queries.
+__device__ __forceinline__ bool lin_site(const void* __restrict__ mask, int mask_is_f32, size_t i) {
+    return mask_is_f32 ? reinterpret_cast<const float*>(mask)[i] != 0.0f : reinterpret_cast<const uint8_t*>(mask)[i] != 0;
+}
+__global__ __launch_bounds__(256) void k_linear_rowcount(const void* __restrict__ mask, int mask_is_f32, int64_t mask_bstride, int H, int W,
+                                                          int* __restrict__ rowstart /*[B][H+1]*/) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
+    int cs = 0;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        cs += __popcll(__ballot(x < W && lin_site(mask, mask_is_f32, (size_t)b * mask_bstride + (size_t)y * W + x)));
+    }
+    if (lane == 0) rowstart[(size_t)b * (H + 1) + y] = cs;
+}
+// exclusive scan of the row counts of one image in place (H <= 2048: two rows per thread); rowq[y] = queries before row y = y W - sites
+__global__ __launch_bounds__(1024) void k_linear_rowscan(int H, int W, int* __restrict__ rowstart, int* __restrict__ rowq, int* __restrict__ counts /*[B][2]*/,
+                                                         int* __restrict__ fbcount /*[B][2]*/) {
+    __shared__ int s_w[16];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* rs = rowstart + (size_t)b * (H + 1);
+    int* rq = rowq + (size_t)b * (H + 1);
+    const int y0 = 2 * threadIdx.x;
+    const int c0 = y0 < H ? rs[y0] : 0, c1 = y0 + 1 < H ? rs[y0 + 1] : 0;
+    const int sum = c0 + c1;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    int base = inc - sum, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { base += w < wave ? s_w[w] : 0; total += s_w[w]; }
+    if (y0 < H) { rs[y0] = base; rq[y0] = y0 * W - base; }
+    if (y0 + 1 < H) { rs[y0 + 1] = base + c0; rq[y0 + 1] = (y0 + 1) * W - (base + c0); }
+    if (threadIdx.x == 0) {
+        rs[H] = total; rq[H] = H * W - total;
+        counts[2 * b] = total; counts[2 * b + 1] = H * W - total;
+        fbcount[2 * b] = total; fbcount[2 * b + 1] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void k_linear_rowwrite(const void* __restrict__ mask, int mask_is_f32, int64_t mask_bstride, int H, int W,
+                                                          const int* __restrict__ rowstart, const int* __restrict__ rowq,
+                                                          float* __restrict__ sites /*[B][3][H*W]*/, int* __restrict__ qlist /*[B][H*W]*/, int make_qlist) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= H) return;
     const int n = H * W;
     float* sx = sites + (size_t)b * 3 * n;
-    int base_s = 0, base_q = 0;
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + threadIdx.x;
-        bool site = false;
-        if (i < n) site = mask_is_f32 ? reinterpret_cast<const float*>(mask)[(size_t)b * mask_bstride + i] != 0.0f
-                                      : reinterpret_cast<const uint8_t*>(mask)[(size_t)b * mask_bstride + i] != 0;
-        const bool qry = i < n && !site;
+    int ps = rowstart[(size_t)b * (H + 1) + y], pq = rowq[(size_t)b * (H + 1) + y];
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool site = x < W && lin_site(mask, mask_is_f32, (size_t)b * mask_bstride + (size_t)y * W + x);
+        const bool qry = x < W && !site;
         const unsigned long long bs = __ballot(site), bq = __ballot(qry);
-        if (lane == 0) { s_s[wave] = __popcll(bs); s_q[wave] = __popcll(bq); }
-        __syncthreads();
-        int ps = base_s, pq = base_q, ts = 0, tq = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { ps += w < wave ? s_s[w] : 0; pq += w < wave ? s_q[w] : 0; ts += s_s[w]; tq += s_q[w]; }
         if (site) {
             const int pos = ps + __popcll(bs & ((1ull << lane) - 1ull));
-            const int y = i / W, x = i - y * W;
             sx[pos] = (float)x; sx[n + pos] = (float)y; sx[2 * (size_t)n + pos] = (float)(x * x + y * y);
         }
-        if (qry && make_qlist) qlist[(size_t)b * n + pq + __popcll(bq & ((1ull << lane) - 1ull))] = i;
-        if (rowstart != nullptr && i < n && i % W == 0) rowstart[(size_t)b * (H + 1) + i / W] = ps + __popcll(bs & ((1ull << lane) - 1ull));
-        base_s += ts; base_q += tq;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        counts[2 * b] = base_s; counts[2 * b + 1] = base_q;
-        if (rowstart != nullptr) rowstart[(size_t)b * (H + 1) + H] = base_s;
-        if (fbcount != nullptr) { fbcount[2 * b] = base_s; fbcount[2 * b + 1] = 0; }
+        if (qry && make_qlist) qlist[(size_t)b * n + pq + __popcll(bq & ((1ull << lane) - 1ull))] = y * W + x;
+        ps += __popcll(bs); pq += __popcll(bq);
     }
 }
 
@@ -241,38 +268,54 @@ __global__ __launch_bounds__(256, 2) void k_linear_tri(const float* __restrict__
 // the circumcircle" is "no site inside" and the triangle is a Delaunay triangle of the whole image.  Everything else -- circle
 // leaving the window, query outside / on the hull of the window's sites, window overflow -- goes to the global kernel through a
 // fallback list.  Same exact integer predicates in f64.
-#define LW 16                          // window margin (pixels)
-#define LT 16                          // tile edge
-#define LCAP ((LT + 2 * LW) * (LT + 2 * LW))
+// Two window sizes (round 5): a scan costs the window's site count, and most unknown pixels of a splatted view have known pixels a
+// step or two away -- their triangle's circumcircle stays inside a margin of LW1 = 6 pixels.  The first launch (LW_ = LW1, 28 x 28
+// windows: a third of the sites of the 48 x 48 one) settles those and marks what it cannot accept in `todo`; the second launch
+// (LW_ = 16, FROM_TODO) takes only the marked pixels and hands ITS rejects to the global kernel as before.  Where the Delaunay
+// triangle is unique both windows return it; on co-circular sites (several valid triangulations, see the header) the choice may
+// depend on the window, as it does on qhull's merge order in the reference.
+#define LW 16                          // window margin (pixels) of the last local pass
+#ifndef LW1
+#define LW1 6                          // ... of the first one
+#endif
+#define LT 16                          // tile edge of the last local pass
+#ifndef LT1
+#define LT1 8                          // ... of the first one (a 20 x 20 window at LW1 = 6)
+#endif
+template <int LW_, int LT_, bool FROM_TODO, bool MARK_TODO>
 __global__ __launch_bounds__(256) void k_linear_local(const float* __restrict__ img, float* __restrict__ out, int C, int H, int W,
                                                       const void* __restrict__ mask, int mask_is_f32, int64_t mask_bstride,
                                                       const int* __restrict__ rowstart /*[B][H+1]*/, int32_t* __restrict__ tri,
-                                                      int* __restrict__ fbq /*[B][H*W]*/, int* __restrict__ fbcount /*[B][2]: NS copy, count*/) {
+                                                      int* __restrict__ fbq /*[B][H*W]*/, int* __restrict__ fbcount /*[B][2]: NS copy, count*/,
+                                                      uint8_t* __restrict__ todo /*[B][H*W]: written (MARK_TODO) / read (FROM_TODO)*/) {
+    constexpr int LCAP = (LT_ + 2 * LW_) * (LT_ + 2 * LW_);
     __shared__ unsigned int s_site[4][LCAP];             // x | y << 16, window sites in row-major order
-    __shared__ unsigned short s_q[4][LT * LT];            // tile queries (x - tx0 | (y - ty0) << 8)
+    __shared__ unsigned short s_q[4][LT_ * LT_];            // tile queries (x - tx0 | (y - ty0) << 8)
     __shared__ double s_co[4][LQ][3];
     const int b = blockIdx.y, n = H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (W + LT - 1) / LT, tiles_y = (H + LT - 1) / LT;
+    const int tiles_x = (W + LT_ - 1) / LT_, tiles_y = (H + LT_ - 1) / LT_;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= tiles_x * tiles_y) return;
-    const int tx0 = (tile % tiles_x) * LT, ty0 = (tile / tiles_x) * LT;
+    const int tx0 = (tile % tiles_x) * LT_, ty0 = (tile / tiles_x) * LT_;
     auto is_site = [&](int y, int x) -> bool {
         const size_t i = (size_t)b * mask_bstride + (size_t)y * W + x;
         return mask_is_f32 ? reinterpret_cast<const float*>(mask)[i] != 0.0f : reinterpret_cast<const uint8_t*>(mask)[i] != 0;
     };
     // ---- the tile's queries
     int NQ = 0;
-    for (int i0 = 0; i0 < LT * LT; i0 += 64) {
-        const int i = i0 + lane, ly = i / LT, lx = i - ly * LT;
-        const bool qry = ty0 + ly < H && tx0 + lx < W && !is_site(ty0 + ly, tx0 + lx);
+    for (int i0 = 0; i0 < LT_ * LT_; i0 += 64) {
+        const int i = i0 + lane, ly = i / LT_, lx = i - ly * LT_;
+        bool qry = ty0 + ly < H && tx0 + lx < W;
+        if (FROM_TODO) qry = qry && todo[(size_t)b * n + (size_t)(ty0 + ly) * W + tx0 + lx] != 0;
+        else qry = qry && !is_site(ty0 + ly, tx0 + lx);
         const unsigned long long bq = __ballot(qry);
         if (qry) s_q[wave][NQ + __popcll(bq & ((1ull << lane) - 1ull))] = (unsigned short)(lx | (ly << 8));
         NQ += __popcll(bq);
     }
     if (NQ == 0) return;
     // ---- the window's sites (row-major)
-    const int wx0 = max(tx0 - LW, 0), wx1 = min(tx0 + LT + LW, W) - 1, wy0 = max(ty0 - LW, 0), wy1 = min(ty0 + LT + LW, H) - 1;
+    const int wx0 = max(tx0 - LW_, 0), wx1 = min(tx0 + LT_ + LW_, W) - 1, wy0 = max(ty0 - LW_, 0), wy1 = min(ty0 + LT_ + LW_, H) - 1;
     const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
     int NS = 0;
     for (int i0 = 0; i0 < ww * wh; i0 += 64) {
@@ -392,9 +435,12 @@ __global__ __launch_bounds__(256) void k_linear_local(const float* __restrict__ 
             accept = (wx0 == 0 || cx - r > (double)(wx0 - 1)) && (wx1 == W - 1 || cx + r < (double)(wx1 + 1)) &&
                      (wy0 == 0 || cy - r > (double)(wy0 - 1)) && (wy1 == H - 1 || cy + r < (double)(wy1 + 1));
         }
+        if (MARK_TODO) todo[(size_t)b * n + qi] = accept ? 0 : 1;
         if (!accept) {
-            const int k = atomicAdd(fbcount + 2 * b + 1, 1);
-            fbq[(size_t)b * n + k] = qi;
+            if (!MARK_TODO) {
+                const int k = atomicAdd(fbcount + 2 * b + 1, 1);
+                fbq[(size_t)b * n + k] = qi;
+            }
             continue;
         }
         float* o = out + (size_t)b * C * n + qi;
@@ -465,9 +511,9 @@ __global__ __launch_bounds__(64) void k_linear_boundary(const float* __restrict_
 
 extern "C" size_t pdhip_linear_fill_ws_bytes(int B, int H, int W) {
     return (size_t)B * 3 * H * W * sizeof(float) + (size_t)B * H * W * sizeof(int) + (size_t)(2 * B + 64) * sizeof(int) +
-           (size_t)B * H * W * 3 * sizeof(int) + (size_t)B * (H + 1) * sizeof(int) + (size_t)2 * B * sizeof(int);
+           (size_t)B * H * W * 3 * sizeof(int) + 2 * (size_t)B * (H + 1) * sizeof(int) + (size_t)2 * B * sizeof(int) + (size_t)B * H * W;
 }
-static thread_local int g_linear_local = 1;             // tuning / test hook: 0 = global scans only (the round-2 path)
+static thread_local int g_linear_local = 1;             // tuning / test hook: 0 = global scans only (the round-2 path), 2 = one local pass (the 48 x 48 window only: round 3), 1 = two
 extern "C" int pdhip_debug_set_linear_local(int on) { int old = g_linear_local; g_linear_local = on; return old; }
 
 /* tri (may be NULL): per pixel the three site indices (in the image's row-major site order) of the triangle used, -1 at
@@ -485,16 +531,27 @@ extern "C" int pdhip_linear_fill(const float* img, float* out, int B, int C, int
     int* bcount = unresolved + 1;
     int* blist = counts + 2 * B + 64;
     int* rowstart = blist + (size_t)B * n * 3;
-    int* fbcount = rowstart + (size_t)B * (H + 1);
+    int* rowq = rowstart + (size_t)B * (H + 1);
+    int* fbcount = rowq + (size_t)B * (H + 1);
+    uint8_t* todo = reinterpret_cast<uint8_t*>(fbcount + 2 * (size_t)B);
     const bool local = g_linear_local != 0 && W < 65536 && H < 65536;
     PD_HIP(hipMemsetAsync(unresolved, 0, 2 * sizeof(int), s));
-    k_linear_collect<<<B, 1024, 0, s>>>(mask, mask_is_f32, mask_batch_stride, H, W, sites, qlist, counts, rowstart, fbcount, local ? 0 : 1);
+    k_linear_rowcount<<<dim3(cdiv(H, 4), B), 256, 0, s>>>(mask, mask_is_f32, mask_batch_stride, H, W, rowstart);
+    k_linear_rowscan<<<B, 1024, 0, s>>>(H, W, rowstart, rowq, counts, fbcount);
+    k_linear_rowwrite<<<dim3(cdiv(H, 4), B), 256, 0, s>>>(mask, mask_is_f32, mask_batch_stride, H, W, rowstart, rowq, sites, qlist, local ? 0 : 1);
     k_linear_copy_sites<<<dim3(min(cdiv(n, 256), 1024), B), 256, 0, s>>>(img, out, mask, mask_is_f32, mask_batch_stride, C, n, tri);
     if (local) {
         // local pass over 16 x 16 tiles (window sites in LDS); what it cannot certify lands in the fallback list (written over the unused
         // query list), which the global kernel then finishes with (NS, count) = fbcount
-        const int tiles = cdiv(W, LT) * cdiv(H, LT);
-        k_linear_local<<<dim3(cdiv(tiles, 4), B), 256, 0, s>>>(img, out, C, H, W, mask, mask_is_f32, mask_batch_stride, rowstart, tri, qlist, fbcount);
+        const int tiles = cdiv(W, LT) * cdiv(H, LT), tiles1 = cdiv(W, LT1) * cdiv(H, LT1);
+        if (g_linear_local == 2)
+            k_linear_local<LW, LT, false, false><<<dim3(cdiv(tiles, 4), B), 256, 0, s>>>(img, out, C, H, W, mask, mask_is_f32, mask_batch_stride, rowstart, tri, qlist, fbcount, todo);
+        else {
+            // (every pixel the second pass reads was written by the first: sites and background are never queries, their bytes are never read)
+            PD_HIP(hipMemsetAsync(todo, 0, (size_t)B * n, s));
+            k_linear_local<LW1, LT1, false, true><<<dim3(cdiv(tiles1, 4), B), 256, 0, s>>>(img, out, C, H, W, mask, mask_is_f32, mask_batch_stride, rowstart, tri, qlist, fbcount, todo);
+            k_linear_local<LW, LT, true, false><<<dim3(cdiv(tiles, 4), B), 256, 0, s>>>(img, out, C, H, W, mask, mask_is_f32, mask_batch_stride, rowstart, tri, qlist, fbcount, todo);
+        }
         k_linear_tri<<<dim3(cdiv(n, 4 * LQ), B), 256, 0, s>>>(img, out, C, H, W, sites, qlist, fbcount, tri, unresolved, bcount, blist);
     } else
     k_linear_tri<<<dim3(cdiv(n, 4 * LQ), B), 256, 0, s>>>(img, out, C, H, W, sites, qlist, counts, tri, unresolved, bcount, blist);

@@ -755,7 +755,7 @@ def _site_list(mask):
     return np.stack([xs, ys], 1)
 
 
-@pytest.mark.parametrize("local", [1, 0])
+@pytest.mark.parametrize("local", [1, 2, 0])
 @pytest.mark.parametrize("case", ["random64", "ring_only", "no_corners", "golden_view"])
 def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case, local):
     """texture_gen_method='linear' (ours_utils.py:610-643 -> scipy griddata linear = qhull Delaunay + barycentric interpolation).
@@ -777,7 +777,8 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case, local):
         m2 = np.repeat(m[None].astype(np.float32), 3, 0)
     sites = m2[0] != 0
     want = oinp.reference_linear_inpaint_scipy(img, m2)
-    # local = 1: the 16x16-tile window pass first (round 3), the global scans only for what it cannot certify; 0: global scans only
+    # local = 1: two window passes over 16x16 tiles (28x28 then 48x48 windows, round 5), the global scans only for what they cannot
+    # certify; 2: the 48x48 window pass only (round 3); 0: global scans only
     old_local = pd['lib'].lib().pdhip_debug_set_linear_local(local)
     try:
         got, tri = pd['ou'].linear_fill(T(img[None]), T(sites[None]), return_triangles=True)
