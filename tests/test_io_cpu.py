@@ -191,3 +191,16 @@ def test_reference_yaml_configs_load_verbatim(tmp_path):
     yaml.safe_dump(bad, open(str(tmp_path / 'bad.yaml'), 'w'))
     with pytest.raises(KeyError):
         demo.load_config(str(tmp_path / 'bad.yaml'))
+
+
+def test_host_thread_budget_is_shared_between_the_ranks_of_a_node(monkeypatch):
+    """bench.py / demo.py cap torch's intra-op pool and the writer pool by cpus_per_rank(): the CPUs the cgroup quota and the affinity
+    mask grant (the GPU boxes show 256 logical CPUs and grant 16), divided by torchrun's LOCAL_WORLD_SIZE (one process per GPU)."""
+    n = io_utils.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.delenv('LOCAL_WORLD_SIZE', raising=False)
+    assert io_utils.cpus_per_rank() == n
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert io_utils.cpus_per_rank() == max(1, n // 8)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '100000')
+    assert io_utils.cpus_per_rank() == 1
