@@ -756,7 +756,7 @@ def _site_list(mask):
 
 
 @pytest.mark.parametrize("local", [1, 2, 0])
-@pytest.mark.parametrize("case", ["random64", "ring_only", "no_corners", "golden_view"])
+@pytest.mark.parametrize("case", ["random64", "ring_only", "no_corners", "golden_view", "odd_37x53", "sparse_odd_91x45"])
 def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case, local):
     """texture_gen_method='linear' (ours_utils.py:610-643 -> scipy griddata linear = qhull Delaunay + barycentric interpolation).
     The device finds, per unknown pixel, its Delaunay triangle exactly (integer predicates).  Equality with scipy is required
@@ -767,8 +767,8 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case, local):
         g = load_golden("proj_sparse_dense.npz")
         img, m2 = g['ref_sparse'][0].astype(np.float32), g['ref_mask2'][0]
     else:
-        H = W = 64
-        m = rng.uniform(0, 1, (H, W)) > (0.9 if case != "ring_only" else 2.0)
+        H, W = (37, 53) if case == "odd_37x53" else (91, 45) if case == "sparse_odd_91x45" else (64, 64)   # (odd sizes: ragged 8x8 / 16x16 tiles)
+        m = rng.uniform(0, 1, (H, W)) > (0.9 if case not in ("ring_only", "sparse_odd_91x45") else 2.0 if case == "ring_only" else 0.985)
         if case != "no_corners":
             m[0, :] = m[-1, :] = m[:, 0] = m[:, -1] = True      # the reference's images: background border = sites
         else:
@@ -777,7 +777,7 @@ def test_i0_linear_inpaint_vs_scipy_delaunay(pd, case, local):
         m2 = np.repeat(m[None].astype(np.float32), 3, 0)
     sites = m2[0] != 0
     want = oinp.reference_linear_inpaint_scipy(img, m2)
-    # local = 1: two window passes over 16x16 tiles (28x28 then 48x48 windows, round 5), the global scans only for what they cannot
+    # local = 1: two window passes (8x8 tiles / 20x20 windows, then 16x16 tiles / 48x48 windows, round 5), the global scans only for what they cannot
     # certify; 2: the 48x48 window pass only (round 3); 0: global scans only
     old_local = pd['lib'].lib().pdhip_debug_set_linear_local(local)
     try:
