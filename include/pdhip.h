@@ -185,7 +185,7 @@ size_t pdhip_linear_fill_ws_bytes(int B, int H, int W);
 int pdhip_linear_fill(const float* img, float* out, int B, int C, int H, int W, const void* mask, int mask_is_f32,
                       int64_t mask_batch_stride, void* ws, int32_t* tri, void* stream);
 int pdhip_linear_fill_unresolved(const void* ws, int B, int H, int W, int* out, void* stream);
-int pdhip_debug_set_linear_local(int on);   /* tuning / test hook: 1 (default) = two local 16x16-tile window passes (28x28 then 48x48 windows), global scans only for what they cannot certify; 2 = the 48x48 pass only; 0 = global scans only */
+int pdhip_debug_set_linear_local(int on);   /* tuning / test hook: 1 (default) = two local window passes (8x8 tiles with 20x20 windows, then 16x16 tiles with 48x48 windows), global scans only for what they cannot certify; 2 = the 48x48 pass only; 0 = global scans only */
 
 /* test / lab hook: 1 = Uq1-Uq4 run their run-time-view-count kernels even at V = 8 (default 0: the view loop is unrolled at V = 8 and
  * the view selection skips the softmax exponentials where the selected view provably does not depend on them; same results bit for

@@ -269,9 +269,11 @@ __global__ __launch_bounds__(256, 2) void k_linear_tri(const float* __restrict__
 // leaving the window, query outside / on the hull of the window's sites, window overflow -- goes to the global kernel through a
 // fallback list.  Same exact integer predicates in f64.
 // Two window sizes (round 5): a scan costs the window's site count, and most unknown pixels of a splatted view have known pixels a
-// step or two away -- their triangle's circumcircle stays inside a margin of LW1 = 6 pixels.  The first launch (LW_ = LW1, 28 x 28
-// windows: a third of the sites of the 48 x 48 one) settles those and marks what it cannot accept in `todo`; the second launch
-// (LW_ = 16, FROM_TODO) takes only the marked pixels and hands ITS rejects to the global kernel as before.  Where the Delaunay
+// step or two away -- their triangle's circumcircle stays inside a margin of LW1 = 6 pixels.  The first launch (8 x 8 tiles, LW_ = LW1:
+// 20 x 20 windows, a sixth of the sites of the 48 x 48 one) settles those and marks what it cannot accept in `todo`; the second launch
+// (16 x 16 tiles, LW_ = 16, FROM_TODO) takes only the marked pixels and hands ITS rejects to the global kernel as before.  Measured on the
+// bench shape (8 views of 256^2): margins 2 .. 12 on 8 x 8 first tiles 1 548 / 1 361 / 1 273 / 1 140 / 1 081 (6) / 1 123 / 1 228 /
+// 1 210 / 1 349 us; 16 x 16 first tiles 1 342-1 431; one pass (round 3) 2 962.  Where the Delaunay
 // triangle is unique both windows return it; on co-circular sites (several valid triangulations, see the header) the choice may
 // depend on the window, as it does on qhull's merge order in the reference.
 #define LW 16                          // window margin (pixels) of the last local pass
