@@ -56,3 +56,21 @@ def test_bench_two_ranks_rehearsal_carries_the_view_parallel_figure():
     assert "error" not in vp, vp
     assert vp["seconds_per_shape"] > 0 and vp["n1_one_shape_seconds"] > 0 and abs(vp["speedup_vs_n1_one_shape"] - vp["n1_one_shape_seconds"] / vp["seconds_per_shape"]) < 1e-9
     assert len(vp["samples"]) == 3
+
+
+def test_bench_two_ranks_headline_survives_a_side_figure_that_does_not_come_back():
+    """The view-parallel side figure is the only collective after the timed region and has never met N > 1 hardware: with a
+    watchdog that fires at once (--extras-timeout 0.01) every rank leaves, rank 0 having printed the ONE headline line with
+    extras.view_parallel = {error: ...} -- exit code 0, contract fields intact."""
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--ddnm-steps", "2", "--shapes-per-step", "1",
+           "--backend", "gloo", "--one-device", "--extras-timeout", "0.01"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert "error" in d["extras"]["view_parallel"]
