@@ -434,7 +434,16 @@ def main():
     roofline = None
     extras = {}
 
+    print_lock = threading.Lock()
+    printed = [False]
+
     def finish(extras_, from_watchdog=False):
+        # ONE headline line per run, whoever gets here first (a side figure finishing right at its timeout could otherwise
+        # race the watchdog's copy of the line); the guard is taken before any slow work so that the loser does nothing
+        with print_lock:
+            if printed[0]:
+                return
+            printed[0] = True
         calib = None
         if rank == 0 and inpainter is not None and not args.no_extras and not from_watchdog:
             calib = calibrate(dev)
@@ -588,9 +597,20 @@ def main():
         if world > 1 and args.parallel == 'shapes' and not args.no_extras and world <= V:
             # (this side figure is the only collective after the timed region and has never met N > 1 hardware: if it does not come
             # back, every rank leaves through the watchdog and rank 0 still prints the headline line)
-            watchdog = threading.Timer(args.extras_timeout, lambda: (finish(dict(extras, view_parallel=dict(
-                error=f"no result within {args.extras_timeout:.0f} s: side figure abandoned, headline unaffected")), True) if rank == 0 else None,
-                os._exit(0)))
+            def abandon():
+                #  the exit must not depend on finish() returning: an exception in the timer thread would leave rank 0 in the
+                # collective after the other ranks have gone.  Every rank leaves with code 0 -- the headline was measured and printed, and a
+                # non-zero rank would make the launcher report the whole run as failed -- but says so on stderr, so a log shows that the
+                # side figure's collective really did not come back
+                try:
+                    print(f"[bench rank {rank}] view-parallel side figure abandoned after {args.extras_timeout:.0f} s", file=sys.stderr, flush=True)
+                    if rank == 0:
+                        finish(dict(extras, view_parallel=dict(
+                            error=f"no result within {args.extras_timeout:.0f} s: side figure abandoned, headline unaffected")), True)
+                finally:
+                    sys.stdout.flush()
+                    os._exit(0)
+            watchdog = threading.Timer(args.extras_timeout, abandon)
             watchdog.daemon = True
             watchdog.start()
             try:

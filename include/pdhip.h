@@ -37,6 +37,7 @@ extern "C" {
 #define PDHIP_E_UNKNOWN_NAME (-5)   /* pdhip_unet_load_tensor: not a tensor of this architecture (strict=False callers skip it) */
 
 int pdhip_version(void);
+int pdhip_lab_build(void);   /* 0 for a product build; > 0: that many translation units carry a wrong-result PD_LAB_* timing switch (csrc/common.h) -- tests refuse such a library */
 const char* pdhip_last_error(void);
 
 /* ---- P1: ours_utils.get_rendered_hard_mask_and_face_idx_batch, transform + crop part
@@ -312,7 +313,7 @@ int pdhip_debug_set_fold_finalize(int max_batch);   /* largest UNet batch at whi
 int pdhip_debug_set_fold_finalize_chunks(int chunks);   /* above that batch the in-kernel statistics are kept for tensors whose producers left at most this many chunks per image (default 16; 0 = batch rule only); returns the previous value */
 int pdhip_debug_set_conv_sk(int mode, int tile, int splits);   /* small-M conv kernel (in-launch split-K combine): mode 0 never / 1 automatic / 2 every eligible layer; tile 0 auto, 1..4 = 128x128, 128x64, 64x64, 64x32; splits 0 auto */
 int pdhip_debug_set_conv_sk_stages(int stages);   /* lab hook: LDS stage count of the small-M conv kernel (2, 3, 4 where the tile allows; 0 = default) */
-int pdhip_debug_set_conv_sk_kgroups(int kg);   /* lab hook: K-groups (4-wave groups working on alternate K-steps of one tile) per workgroup of the small-M conv kernel: 1, 2, 4 (64-row tiles), 8 = loader-specialised (4 compute + 4 loader waves); 0 = default */
+int pdhip_debug_set_conv_sk_kgroups(int kg);   /* lab hook: K-groups (4-wave groups working on alternate K-steps of one tile) per workgroup of the small-M conv kernel: 1, 2, 4 (64-row tiles), 8 = loader-specialised (4 compute + 4 loader waves), 12 = loader-specialised with EIGHT loader waves (the 128-row tiles; the default of the 128x128 tile since round 5); 0 = default */
 int pdhip_debug_set_attn(int nbuf, int vt_form, int qtiles);   /* lab hook, T >= 128 attention kernel: qtiles = 16-query tiles per wave, 1 (64 queries per workgroup) or 2 (128), 0 automatic; nbuf = LDS chunk buffers, 2 (K / V requested one chunk ahead), 3 (two ahead), 0 automatic; vt_form 1 = V transposed into the workspace by a separate pass and read plainly, 0 = V staged row-major and read with the LDS transpose read */
 int pdhip_debug_set_conv_sk_order(int order);   /* lab hook: tile order of the small-M conv kernel inside an XCD's run: 0 automatic, 1 pixel tiles fastest (weight slices shared through L2), 2 n-tiles fastest */
 /* h0 = silu(GroupNorm32(x)) AND sk = conv1x1(x) (C -> 256 channels) in ONE pass over x: the in_layers normalisation and the

@@ -18,6 +18,7 @@ vp, i32, i64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_doub
 
 _SIGS = {
     'pdhip_version': (C.c_int, []),
+    'pdhip_lab_build': (C.c_int, []),
     'pdhip_last_error': (C.c_char_p, []),
     'pdhip_project_points': (C.c_int, [vp, i32, vp, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp]),
     'pdhip_project_points_shapes': (C.c_int, [vp, i32, i32, vp, i32, vp, i32, i32, f64, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -89,6 +90,10 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)          # AttributeError here == ABI mismatch, fail loudly
             fn.restype, fn.argtypes = res, args
+        if _lib.pdhip_lab_build() != 0 and not os.environ.get('PDHIP_ALLOW_LAB_BUILD'):
+            n, _lib = _lib.pdhip_lab_build(), None
+            raise PdhipError(f"{LIB_PATH} was built with a wrong-result PD_LAB_* timing switch in {n} translation unit(s): rebuild it "
+                             "(make -C pointdreamer_amd/csrc clean all) or set PDHIP_ALLOW_LAB_BUILD=1 for a timing experiment")
     return _lib
 
 

@@ -38,6 +38,24 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
         }                                                                                  \
     } while (0)
 
+// ---- lab builds.  Several PD_LAB_* switches compile deliberately WRONG results into a kernel (a skipped GroupNorm pass, a K loop
+// without one operand stream, no barrier ...) to time what is left.  tools/lab_*.sh write such builds to csrc/build/lab_*.so, never to
+// libpdhip.so, and pass -DPD_LAB_BUILD; should one of the switches reach a translation unit of the shipped library anyway, that unit
+// registers itself here and pdhip_lab_build() (capi.hip) reports it -- tests/test_abi.py and every GPU test session refuse such a library.
+#if defined(PD_LAB_BUILD) || defined(PD_LAB_SKIP_GN) || defined(PD_LAB_SK_NOA) || defined(PD_LAB_SK_NOB) || defined(PD_LAB_SK_NOCOMPUTE) || \
+    defined(PD_LAB_SK_NOGLDS) || defined(PD_LAB_SK_NOBARRIER) || defined(PD_LAB_NOA) || defined(PD_LAB_NOB) || defined(PD_LAB_NOBARRIER) ||     \
+    defined(PD_LAB_NODMA) || defined(PD_LAB_NOEPI) || defined(PD_LAB_NOLDS) || defined(PD_LAB_NOSTORE) || defined(PD_LAB_NOWAIT) ||             \
+    defined(PD_LAB_AP_NOCOMPUTE) || defined(PD_LAB_AP_NOFETCH) || defined(PD_LAB_AP_NOSTORE) || defined(PD_LAB_AP_NOTRANS) ||                   \
+    defined(PD_LAB_AP_LOOSEVM) || defined(PD_LAB_RASTER_LOADONLY) || defined(PD_LAB_RASTER_NORESOLVE) || defined(PD_LAB_RR_NOW) ||             \
+    defined(PD_LAB_RR_NOA) || defined(PD_LAB_RR_NOMFMA)
+#define PD_LAB_WRONG_RESULTS 1
+#endif
+extern int g_lab_units;                                    // translation units built with a wrong-result lab switch (capi.hip)
+struct LabMark { LabMark() { ++g_lab_units; } };
+#ifdef PD_LAB_WRONG_RESULTS
+namespace { LabMark pd_lab_mark_; }
+#endif
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- arithmetic contract: float32, one rounding per op, this order, no FMA.

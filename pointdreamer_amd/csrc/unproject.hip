@@ -514,7 +514,10 @@ __global__ __launch_bounds__(256) void k_view_select_blend_v(const float* __rest
 #pragma unroll
             for (int v = 0; v < VC; ++v)
                 if (((cand >> v) & 1u) && sim[v] > s1) { before = s1; s1 = sim[v]; bi = v; }
-            if (cand != 0u && !(finite && s1 - before >= 1.0e-5f)) {
+            //  the shortcut also needs the winner's weight in f32's NORMAL range: with unnormalised face normals (|n| >~ 50)
+            // sim - mx can fall below -87 ... -104, exp underflows to a denormal or 0 and the reference's argmax then takes the FIRST
+            // zero-weight candidate, not the largest similarity; exp(-80) / 8 is still normal, below that the generic expressions decide
+            if (cand != 0u && !(finite && s1 - before >= 1.0e-5f && s1 - mx > -80.0f)) {
                 // (generic expressions, same order)
                 float ew[VC];
                 float sum = 0.f;

@@ -19,6 +19,10 @@ def _host_u8(t):
     16 ms of a 34 ms shape).  Synchronous mode: a plain blocking copy, `wait` does nothing."""
     if _pool is None:
         return t.cpu().numpy(), (lambda: None)
+    # the producing kernel was enqueued on _lib.stream() = the CURRENT device's current stream; the copy and the event go onto the same
+    # stream only if the tensor lives on that device (ADVICE r5) -- anything else would let the writer read a half-converted image
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise _lib.PdhipError(f"io_utils: image on {t.device} while cuda:{torch.cuda.current_device()} is current (set the device first)")
     host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     host.copy_(t, non_blocking=True)
     ev = torch.cuda.Event()
@@ -58,6 +62,7 @@ def _u8_hwc(img, channels, want_wait=False):
 # small thread pool (the pixel data has already been converted and copied to the host), `flush()` waits and re-raises the first
 # error.  Default is synchronous: the file exists when the save function returns, as in the reference.
 _pool = None
+_pool_workers = 0
 _pending = []
 
 
@@ -90,14 +95,17 @@ def cpus_per_rank():
 
 
 def set_async(on, workers=8):
-    global _pool
+    """Turn the background write queue on / off.  A queue that exists with another worker count is drained and rebuilt (ADVICE r5:
+    `workers` used to be ignored once a pool existed)."""
+    global _pool, _pool_workers
     flush()
+    if _pool is not None and (not on or workers != _pool_workers):
+        _pool.shutdown(wait=True)
+        _pool = None
     if on and _pool is None:
         from concurrent.futures import ThreadPoolExecutor
         _pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix='pdhip-io')
-    elif not on and _pool is not None:
-        _pool.shutdown(wait=True)
-        _pool = None
+        _pool_workers = workers
 
 
 def flush():

@@ -22,13 +22,9 @@ def golden():
     return load_golden
 
 
-# U1 (f16 engine) against the imported reference's fp32 forward: relative L-inf / relative L2 per forward.  SURVEY 8c allowed 2e-2 / 5e-3;
-# round 5 cut the asserted bound to 2x the largest value measured over all routings, batches and boxes of the round
-# (profiles/r05_u1_bounds.txt) -- the reference's own fp16 forward sits 1.1e-3 / 1.3e-3 from its fp32 forward (full config; 1.6e-3 /
-# 1.7e-3 on the small one), and tests/test_gpu_round5.py pins the engine to that fp16 forward directly.
-U1_FP32_LINF, U1_FP32_L2 = 2.7e-3, 2.6e-3                  # full config; measured <= 1.35e-3 / 1.30e-3 over 46 forwards (all routings, batch 1-32)
-U1_ROUTE_LINF, U1_ROUTE_L2 = 3.4e-3, 2.6e-3                # batched vs batch-1 forward of the same image (two f16 routings); measured <= 1.66e-3 / 1.25e-3
-U1_SMALL_FP32_LINF, U1_SMALL_FP32_L2 = 4.5e-3, 3.4e-3      # 64^2 / 32-channel config; measured 2.2e-3 / 1.66e-3
+# U1 bounds live in oracle/bounds.py (shared with __graft_entry__.smoke())
+from oracle.bounds import (U1_FP32_LINF, U1_FP32_L2, U1_ROUTE_LINF, U1_ROUTE_L2,   # noqa: E402,F401
+                           U1_SMALL_FP32_LINF, U1_SMALL_FP32_L2)
 
 
 def note_measured(**kw):

@@ -19,6 +19,7 @@ EXEMPT = re.compile(r'k_hpr_exact|k_linear_(local|tri)')
 def kernels():
     if not os.path.exists(LIB):
         pytest.skip("libpdhip.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    pytest.importorskip('msgpack')                          # (the AMDGPU metadata note is msgpack; not a declared dependency of the product)
     from tools import code_object_notes
     return code_object_notes.kernels(LIB)
 
