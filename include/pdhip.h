@@ -361,6 +361,24 @@ int pdhip_chw_f32_to_hwc_u8(const float* img, int C, int H, int W, uint8_t* out,
 size_t pdhip_unet_head_ws_floats(int N, int H, int W, int C, int Cout);
 int pdhip_unet_head_f32(const void* x, const float* gamma, const float* beta, const float* w_oihw, const float* bias,
                         int N, int H, int W, int C, int Cout, float* y_nchw, float* ws, long long ws_floats, void* stream);
+/* Row-resident convolution of the UNet's 8^2 / 16^2 / 32^2 levels at small batch (csrc/nn_conv_rr.hip): 3x3 (taps 9) or 1x1 (taps 1) conv over
+ * x = [x (Ca channels) | x2 (C - Ca), may be NULL] with the GroupNorm32 (+ FiLM) (+ SiLU) of the input applied while staging -- the pair
+ * `GroupNorm32 -> [scale / shift] -> SiLU -> conv` of ResBlock.in_layers / out_layers (guided_diffusion/unet.py:185-260) as ONE launch; gn_mode 0 raw input,
+ * 1 GroupNorm, 2 GroupNorm + SiLU; statistics from the producers' octet partials partA / partB ([N][chunks][channels / 8][2] = sum, sum of squares);
+ * film rows (scale[C] | shift[C]) or NULL.  xs / xs2 (Cs channels, Cs1 in xs): the ResBlock's skip_connection 1x1 (unet.py:255) appended to the K loop,
+ * raw input, or NULL.  wf: fragment-major weights from pdhip_conv_rr_pack_f16 (source: [Cout_pad][taps * C + Cs] as pdhip_pack_conv_weight_f16 lays them out).
+ * ws: >= 4096 zeroed floats (tickets) + split-K slices; gn_part (may be NULL): octet partials of y, *gn_chunks chunks per image.  H == W in {8, 16, 32}. */
+int pdhip_conv_rr_f16(const void* x, const void* x2, int C, int Ca, int gn_mode, const float* gamma, const float* beta, const float* film,
+                      long long film_stride, const float* partA, int chunksA, const float* partB, int chunksB, const void* xs, const void* xs2, int Cs,
+                      int Cs1, int taps, const void* wf, const float* bias, const void* residual, int res_up, void* y, int N, int H, int W, int Cout,
+                      float* ws, long long ws_floats, float* gn_part, int* gn_chunks, void* stream);
+long long pdhip_conv_rr_weight_halfs(int Cin, int taps, int Cs, int Cout);
+int pdhip_conv_rr_pack_f16(const void* w_packed, int Cin, int taps, int Cs, int Cout, void* wf, void* stream);
+/* test helpers: octet partials of a tensor as a conv epilogue leaves them; the two-pass reference of the fused input transform (k_gn_apply with in-kernel statistics) */
+int pdhip_gn_octet_partials_f16(const void* x, int N, int HW, int C, int chunks, float* part, void* stream);
+int pdhip_gn_apply_parts_f16(const void* x, const void* x2, int Ca, int C, const float* partA, int chunksA, const float* partB, int chunksB, const float* gamma,
+                             const float* beta, const float* film, long long film_stride, int N, int H, int W, int silu, void* y, void* stream);
+int pdhip_debug_set_conv_rr(int mode, int variant, int slabs);   /* row-resident conv: mode 0 never / 1 automatic / 2 every eligible layer; variant 0 auto (1: 8^2, 2: 16^2 whole image, 3: 32^2 bands, 4: 16^2 half image, 5: 8^2 with 128-channel units); slabs 0 auto = K slices of the conv source; returns the previous mode */
 int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim,
                         void* vt_ws /*N*T*C halfs, non-NULL selects the 128-query MFMA kernel for T % 128 == 0, head_dim 64, N*heads % 8 == 0 (QKVAttentionLegacy, unet.py:341-373); the buffer is written only in the transposed-V lab form (pdhip_debug_set_attn); NULL: the 64-query kernel*/, void* stream);
 int pdhip_philox_normal(float* out, long long n, uint64_t seed, uint64_t stream_id, void* stream);

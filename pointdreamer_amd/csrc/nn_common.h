@@ -59,6 +59,47 @@ extern thread_local int g_sk_mode, g_sk_tile, g_sk_splits, g_sk_stages, g_sk_kg,
 int gn_finalize_oct(const float* partA, int Ca, int chunksA, const float* partB, int Cb, int chunksB, int N, int HW, float eps,
                     float* stats, hipStream_t s);
 
+// ---- row-resident convolution of the 8^2 / 16^2 / 32^2 levels at small batch (nn_conv_rr.hip): GroupNorm (+ FiLM) (+ SiLU) of the input
+// applied while staging, weights streamed HBM -> registers from a fragment-major copy, in-launch split-K over K "slabs".
+struct RrIn {                      // one K source: x [N,H,W,Ca] (+ x2 [N,H,W,C-Ca]: never-materialised channel concat)
+    const half_t* x; const half_t* x2; int C, Ca;
+    int gn;                        // 0 raw, 1 GroupNorm, 2 GroupNorm + SiLU (statistics from the producers' octet partials, k_gn_apply's FIN arithmetic)
+    const float* gamma; const float* beta; const float* film; long long film_stride;
+    const float* partA; const float* partB; int chunksA, chunksB; float eps;
+};
+struct RrPlan { int variant, S0, U0, S1, U1, bands, ntiles; };      // variant == 0: not a layer for this kernel
+RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs /*channels of an appended skip 1x1, 0 = none*/, size_t ws_floats);
+size_t conv_rr_weight_halfs(int Cin, int taps, int Cs, int Cout);
+// w_packed: the engine's [Cout_pad][taps * Cin (+ Cs)] layout -> fragment-major [Cout / 16][K-steps][64 lanes][8]
+int conv_rr_pack(const half_t* w_packed, int Cin, int taps, int Cs, int Cout, half_t* dst, hipStream_t s);
+int conv_rr(const RrPlan& pl, const RrIn& in, const RrIn* skip, int taps, const half_t* wf, const float* bias, const half_t* residual, int res_up,
+            half_t* Y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, float* gn_part, int* gn_chunks, hipStream_t s);
+extern thread_local int g_rr_mode, g_rr_variant, g_rr_slabs;            // tuning / test hooks (pdhip_debug_set_conv_rr)
+#define PD_RR_MAX_PART_LOADS 8    // octet-partial loads per thread of the in-kernel statistics: chunks / slots of a source must not exceed it
+
+// ---- the GroupNorm (+ FiLM) (+ SiLU) element map (nn_norm.hip's k_gn_apply and nn_conv_rr.hip's staging: ONE definition, bit-identical results)
+// x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to f16 (or feeds the f32 head,
+// tolerance 1e-3) and the divide was half of this HBM-bound kernel's VALU work
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// One element of GroupNorm (+ FiLM) (+ SiLU) with the reference's f16 tensor between the ops.  Every f32 result is made opaque
+// before it is rounded to f16: left alone, the compiler fuses an op with the conversion behind it (v_fma_mixlo_f16: ONE rounding) in
+// some copies of the loop and not in others -- the 4-pixel main loop and the 1-pixel tail of k_gn_apply differed by one f16 ulp in
+// 4e-5 of the elements, so a result depended on the pixels-per-thread a launch happened to pick.
+__device__ __forceinline__ float gn_round_f16(float f) { asm("" : "+v"(f)); return (float)(half_t)f; }
+template <bool OUT_F32, bool FILM>
+__device__ __forceinline__ float gn_elem(float x, float ga, float gb, float t1, float sh, int silu) {
+    float f = __builtin_fmaf(x, ga, gb);
+    if (!OUT_F32) f = gn_round_f16(f);                                   // GroupNorm32 returns x.dtype (f16)
+    if (FILM) {
+        f = gn_round_f16(f * t1);
+        f = gn_round_f16(f + sh);
+    }
+    if (silu) { f = silu_f(f); if (!OUT_F32) f = gn_round_f16(f); }
+    return f;
+}
+
+
 // ---- normalisation / elementwise (nn_norm.hip)
 // GroupNorm(32) statistics of X [N,HW,C] f16 -> stats [N][32][2] (mean, rstd) f32.  ws: N*chunks*32*2 floats.
 int gn_stats(const half_t* X, int N, int HW, int C, float eps, float* stats, float* ws, size_t ws_floats, hipStream_t s);

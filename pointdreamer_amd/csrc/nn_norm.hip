@@ -166,26 +166,7 @@ int gn_table(const float* stats, const float* gamma, const float* beta, const fl
     return PDHIP_OK;
 }
 
-// x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to f16 (or feeds the f32 head,
-// tolerance 1e-3) and the divide was half of this HBM-bound kernel's VALU work
-__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-// One element of GroupNorm (+ FiLM) (+ SiLU) with the reference's f16 tensor between the ops.  Every f32 result is made opaque
-// before it is rounded to f16: left alone, the compiler fuses an op with the conversion behind it (v_fma_mixlo_f16: ONE rounding) in
-// some copies of the loop and not in others -- the 4-pixel main loop and the 1-pixel tail of k_gn_apply differed by one f16 ulp in
-// 4e-5 of the elements, so a result depended on the pixels-per-thread a launch happened to pick.
-__device__ __forceinline__ float gn_round_f16(float f) { asm("" : "+v"(f)); return (float)(half_t)f; }
-template <bool OUT_F32, bool FILM>
-__device__ __forceinline__ float gn_elem(float x, float ga, float gb, float t1, float sh, int silu) {
-    float f = __builtin_fmaf(x, ga, gb);
-    if (!OUT_F32) f = gn_round_f16(f);                                   // GroupNorm32 returns x.dtype (f16)
-    if (FILM) {
-        f = gn_round_f16(f * t1);
-        f = gn_round_f16(f + sh);
-    }
-    if (silu) { f = silu_f(f); if (!OUT_F32) f = gn_round_f16(f); }
-    return f;
-}
+// (silu_f, gn_round_f16, gn_elem: nn_common.h -- shared with the row-resident conv, which applies the same element map while staging)
 
 // grid (pixel chunks, N).  thread -> (pixel sub-slot, channel octet): the octet's affine constants live in
 // registers for the whole chunk; consecutive threads touch consecutive 16-byte octets (full 128-B lines).

@@ -59,6 +59,13 @@ _reg('pdhip_debug_set_conv_sk_stages', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk_kgroups', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_sk_order', C.c_int, [i32])
 _reg('pdhip_debug_set_attn', C.c_int, [i32, i32, i32])
+_reg('pdhip_debug_set_conv_rr', C.c_int, [i32, i32, i32])
+_reg('pdhip_conv_rr_weight_halfs', C.c_longlong, [i32, i32, i32, i32])
+_reg('pdhip_conv_rr_pack_f16', C.c_int, [vp, i32, i32, i32, i32, vp, vp])
+_reg('pdhip_gn_octet_partials_f16', C.c_int, [vp, i32, i32, i32, i32, vp, vp])
+_reg('pdhip_gn_apply_parts_f16', C.c_int, [vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, vp, C.c_longlong, i32, i32, i32, i32, vp, vp])
+_reg('pdhip_conv_rr_f16', C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, C.c_longlong, vp, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp,
+                                   i32, i32, i32, i32, vp, C.c_longlong, vp, C.POINTER(C.c_int), vp])
 _reg('pdhip_debug_conv3x3_apply', C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_attention_f16', C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp])
 _reg('pdhip_philox_normal', C.c_int, [vp, C.c_longlong, u64, u64, vp])

@@ -1,0 +1,186 @@
+"""Round-6 GPU parity tests: the row-resident convolution of the 8^2 / 16^2 / 32^2 levels (csrc/nn_conv_rr.hip: GroupNorm (+ FiLM) + SiLU applied
+while staging, weights streamed from a fragment-major copy, in-launch split-K over slabs, a ResBlock's skip 1x1 riding along), stand-alone against
+torch fp32 and against the engine's own two-pass form, and the whole UNet with the new route forced on / off."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, note_measured, U1_FP32_LINF, U1_FP32_L2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope="module")
+def nn():
+    assert torch.cuda.is_available()
+    from pointdreamer_amd import _lib
+    import pointdreamer_amd.ddnm_inpainting as di
+    return dict(L=_lib.lib(), lib=_lib, di=di)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _pack_rr(L, w3, w1):
+    """w3 [Cout, Cin, k, k] f32 (+ w1 [Cout, Cs] of an appended skip 1x1) -> the engine's [Cout][taps * Cin + Cs] f16 layout -> fragment-major."""
+    Cout, Cin, k, _ = w3.shape
+    taps = k * k
+    wp = w3.permute(0, 2, 3, 1).reshape(Cout, taps * Cin)
+    Cs = 0
+    if w1 is not None:
+        Cs = w1.shape[1]
+        wp = torch.cat([wp, w1], dim=1)
+    wp = wp.half().contiguous().to(DEV)
+    wf = torch.empty((L.pdhip_conv_rr_weight_halfs(Cin, taps, Cs, Cout),), dtype=torch.float16, device=DEV)
+    assert L.pdhip_conv_rr_pack_f16(_ptr(wp), Cin, taps, Cs, Cout, _ptr(wf), _stream()) == 0, L.pdhip_last_error()
+    return wf
+
+
+def _rr(L, x, x2, gn, gamma, beta, film, parts, xs, xs2, taps, wf, bias, res, res_up, N, H, W, Cout, ws, want_part=True):
+    Ca = x.shape[-1]
+    Cc = Ca + (x2.shape[-1] if x2 is not None else 0)
+    Cs1 = xs.shape[-1] if xs is not None else 0
+    Cs = Cs1 + (xs2.shape[-1] if xs2 is not None else 0)
+    y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.float16, device=DEV)
+    part = torch.full((N * 16 * (Cout // 8) * 2,), float('nan'), dtype=torch.float32, device=DEV) if want_part else None
+    chunks = C.c_int(-1)
+    pa, ca, pb, cb = parts if parts is not None else (None, 0, None, 0)
+    rc = L.pdhip_conv_rr_f16(_ptr(x), _ptr(x2), Cc, Ca, gn, _ptr(gamma), _ptr(beta), _ptr(film), 2 * Cc, _ptr(pa), ca, _ptr(pb), cb, _ptr(xs), _ptr(xs2), Cs,
+                             Cs1, taps, _ptr(wf), _ptr(bias), _ptr(res), res_up, _ptr(y), N, H, W, Cout, _ptr(ws), ws.numel(), _ptr(part), C.byref(chunks),
+                             _stream())
+    assert rc == 0, L.pdhip_last_error()
+    torch.cuda.synchronize()
+    return y, part, chunks.value
+
+
+def _parts(L, t, N, HW, chunks):
+    Cc = t.shape[-1]
+    p = torch.empty((N * chunks * (Cc // 8) * 2,), dtype=torch.float32, device=DEV)
+    assert L.pdhip_gn_octet_partials_f16(_ptr(t), N, HW, Cc, chunks, _ptr(p), _stream()) == 0, L.pdhip_last_error()
+    return p
+
+
+CASES = [
+    # N, HW, Ca, Cb, Cout, gn, film, skip (Cs1, Cs2), res (0 none, 1 same size, 2 half resolution), chunksA, chunksB, variant, slabs
+    (1, 8, 1024, 0, 1024, 2, True, None, 1, 1, 0, 0, 0),            # 8^2 ResBlock conv2 (FiLM, residual): the weight stream
+    (1, 8, 1024, 1024, 1024, 2, False, None, 0, 1, 1, 0, 0),        # 8^2 decoder conv1 over the virtual concat (64 channels per group)
+    (1, 8, 1024, 0, 1024, 2, True, (1024, 1024), 0, 1, 0, 0, 0),    # 8^2 decoder conv2 + the skip 1x1 over the concat block input
+    (2, 8, 512, 0, 256, 0, False, None, 0, 0, 0, 5, 0),             # raw input (down / up blocks), batch 2, 128-channel units
+    (1, 8, 256, 0, 512, 1, False, None, 0, 1, 0, 5, 2),             # GroupNorm without SiLU, 8 channels per group, two slabs forced
+    (1, 16, 1024, 0, 1024, 2, True, None, 2, 4, 0, 0, 0),           # 16^2 conv2 of an up block: residual read at half resolution; producer left 4 chunks
+    (1, 16, 1024, 512, 1024, 2, False, None, 0, 1, 4, 0, 0),        # 16^2 decoder conv1 over a 1536-channel concat (48 channels per group)
+    (1, 16, 512, 0, 1024, 2, False, None, 0, 1, 0, 0, 4),           # 16^2 encoder 512 -> 1024, four slabs forced (one unit each)
+    (1, 16, 1024, 0, 1024, 2, True, (1024, 512), 0, 1, 0, 0, 0),    # 16^2 decoder conv2 + skip over a 1536-channel block input
+    (2, 16, 256, 0, 128, 2, True, None, 1, 2, 0, 2, 1),             # batch 2, unsplit
+    (1, 32, 512, 0, 512, 2, True, None, 1, 4, 0, 0, 0),             # 32^2 conv2: eight 4-row bands per image, halo rows from the neighbouring bands
+    (1, 32, 512, 256, 512, 2, False, None, 0, 16, 4, 0, 0),         # 32^2 decoder conv1 over a 768-channel concat (24 per group), 16 producer chunks
+    (1, 32, 512, 0, 512, 2, True, (512, 256), 0, 4, 0, 0, 0),       # 32^2 decoder conv2 + skip
+    (3, 32, 128, 0, 64, 0, False, None, 2, 0, 0, 0, 0),             # raw, batch 3, half-resolution residual
+]
+
+
+@pytest.mark.parametrize("N,HW,Ca,Cb,Cout,gn,film,skip,res,chA,chB,variant,slabs", CASES)
+def test_conv_rr_vs_torch_fp32_and_two_pass_form(nn, N, HW, Ca, Cb, Cout, gn, film, skip, res, chA, chB, variant, slabs):
+    """k_conv_rr against (i) torch fp32 on the same f16 operands: GroupNorm32 -> FiLM -> SiLU -> conv3x3 (+ skip 1x1 + residual), (ii) the
+    engine's two-pass form -- k_gn_apply with in-kernel statistics, then the SAME kernel on the materialised tensor: bit-identical (one
+    definition of the element map, the statistics summed in the same order), (iii) itself when repeated (deterministic combine), and its
+    GroupNorm octet partials against sums over its own output."""
+    L = nn['L']
+    H = W = HW
+    Cc = Ca + Cb
+    g = torch.Generator().manual_seed(17 * HW + Ca + 3 * Cb + Cout + gn)
+    x = (torch.randn((N, H, W, Cc), generator=g) * 1.3 + 0.2).half()
+    gamma = (1 + 0.2 * torch.randn((Cc,), generator=g)); beta = 0.2 * torch.randn((Cc,), generator=g)
+    fl = (0.3 * torch.randn((N, 2 * Cc), generator=g)) if film else None
+    w3 = (torch.randn((Cout, Cc, 3, 3), generator=g) / math.sqrt(9 * Cc)).half().float()
+    b = (0.1 * torch.randn((Cout,), generator=g)).half().float()
+    xs = w1 = None
+    if skip:
+        Cs = skip[0] + skip[1]
+        xs = (torch.randn((N, H, W, Cs), generator=g) * 0.8).half()
+        w1 = (torch.randn((Cout, Cs), generator=g) / math.sqrt(Cs)).half().float()
+    r = None
+    if res == 1:
+        r = torch.randn((N, H, W, Cout), generator=g).half()
+    elif res == 2:
+        r = torch.randn((N, H // 2, W // 2, Cout), generator=g).half()
+    # ---- torch fp32 reference
+    xin = x.float().permute(0, 3, 1, 2)
+    if gn:
+        xin = F.group_norm(xin, 32, gamma, beta, eps=1e-5)
+        if film:
+            xin = xin * (1 + fl[:, :Cc, None, None].half().float()) + fl[:, Cc:, None, None].half().float()
+        if gn == 2:
+            xin = F.silu(xin)
+    ref = F.conv2d(xin, w3, b, padding=1)
+    if skip:
+        ref = ref + F.conv2d(xs.float().permute(0, 3, 1, 2), w1[:, :, None, None])
+    if r is not None:
+        rr = r.float().permute(0, 3, 1, 2)
+        ref = ref + (F.interpolate(rr, scale_factor=2, mode='nearest') if res == 2 else rr)
+    ref = ref.permute(0, 2, 3, 1)
+    # ---- device operands
+    xd = x.to(DEV)
+    xa = xd[..., :Ca].contiguous(); xb = xd[..., Ca:].contiguous() if Cb else None
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    fd = fl.to(DEV) if film else None
+    parts = None
+    if gn:
+        parts = (_parts(L, xa, N, H * W, chA), chA, _parts(L, xb, N, H * W, chB) if Cb else None, chB)
+    xsa = xsb = None
+    if skip:
+        xsd = xs.to(DEV)
+        xsa = xsd[..., :skip[0]].contiguous(); xsb = xsd[..., skip[0]:].contiguous() if skip[1] else None
+    wf = _pack_rr(L, w3, w1)
+    rd = r.to(DEV) if r is not None else None
+    ws = torch.zeros((4096 + 4 * 1024 * 1024,), dtype=torch.float32, device=DEV)
+    bdv = b.to(DEV)
+    old = L.pdhip_debug_set_conv_rr(2, variant, slabs)
+    try:
+        y1, p1, ch = _rr(L, xa, xb, gn, gd, bd, fd, parts, xsa, xsb, 9, wf, bdv, rd, 1 if res == 2 else 0, N, H, W, Cout, ws)
+        y2, p2, _ = _rr(L, xa, xb, gn, gd, bd, fd, parts, xsa, xsb, 9, wf, bdv, rd, 1 if res == 2 else 0, N, H, W, Cout, ws)
+        assert torch.equal(y1, y2) and torch.equal(p1[: N * ch * (Cout // 8) * 2], p2[: N * ch * (Cout // 8) * 2])
+        scale = ref.abs().max().item()
+        err = (y1.float().cpu() - ref).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-3, (err, scale)
+        # octet partials of the output: chunk c of image n = the rows of band c
+        assert ch >= 1 and (H * W) % ch == 0
+        yv = y1.float().reshape(N, ch, (H * W) // ch, Cout // 8, 8)
+        want = torch.stack([yv.sum(dim=(2, 4)), (yv * yv).sum(dim=(2, 4))], dim=-1)
+        got = p1[: N * ch * (Cout // 8) * 2].reshape(N, ch, Cout // 8, 2)
+        assert torch.allclose(got, want, rtol=2e-4, atol=2e-2), (got - want).abs().max().item()
+        if gn:
+            # two-pass form: the stand-alone GroupNorm-apply kernel (statistics from the same partials) -> the same conv kernel on its output
+            h = torch.empty_like(xd)
+            rc = L.pdhip_gn_apply_parts_f16(_ptr(xa), _ptr(xb), Ca, Cc, _ptr(parts[0]), chA, _ptr(parts[2]), chB, _ptr(gd), _ptr(bd), _ptr(fd), 2 * Cc, N, H, W,
+                                            1 if gn == 2 else 0, _ptr(h), _stream())
+            assert rc == 0, L.pdhip_last_error()
+            y3, _, _ = _rr(L, h, None, 0, None, None, None, None, xsa, xsb, 9, wf, bdv, rd, 1 if res == 2 else 0, N, H, W, Cout, ws, want_part=False)
+            assert torch.equal(y1, y3), (y1.float() - y3.float()).abs().max().item()
+    finally:
+        L.pdhip_debug_set_conv_rr(old, 0, 0)
+    assert torch.all(ws[:4096] == 0)                       # the tickets reset themselves
+
+
+def test_conv_rr_refuses_what_it_does_not_serve(nn):
+    L = nn['L']
+    x = torch.zeros((1, 12, 12, 128), dtype=torch.float16, device=DEV)
+    y = torch.zeros((1, 12, 12, 64), dtype=torch.float16, device=DEV)
+    wf = torch.zeros((4096,), dtype=torch.float16, device=DEV)
+    ws = torch.zeros((8192,), dtype=torch.float32, device=DEV)
+    ch = C.c_int(0)
+    rc = L.pdhip_conv_rr_f16(_ptr(x), None, 128, 128, 0, None, None, None, 0, None, 0, None, 0, None, None, 0, 0, 9, _ptr(wf), None, None, 0, _ptr(y), 1, 12, 12,
+                             64, _ptr(ws), ws.numel(), None, C.byref(ch), _stream())
+    assert rc != 0 and b'row-resident' in L.pdhip_last_error()
