@@ -68,7 +68,8 @@ struct RrIn {                      // one K source: x [N,H,W,Ca] (+ x2 [N,H,W,C-
     const float* partA; const float* partB; int chunksA, chunksB; float eps;
 };
 struct RrPlan { int variant, S0, U0, S1, U1, bands, ntiles; };      // variant == 0: not a layer for this kernel
-RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs /*channels of an appended skip 1x1, 0 = none*/, size_t ws_floats);
+RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs /*channels of an appended skip 1x1, 0 = none*/, size_t ws_floats,
+                    bool want_gn = false /*the caller will ask for the in-staging GroupNorm: only the variants that carry it*/);
 size_t conv_rr_weight_halfs(int Cin, int taps, int Cs, int Cout);
 // w_packed: the engine's [Cout_pad][taps * Cin (+ Cs)] layout -> fragment-major [Cout / 16][K-steps][64 lanes][8]
 int conv_rr_pack(const half_t* w_packed, int Cin, int taps, int Cs, int Cout, half_t* dst, hipStream_t s);

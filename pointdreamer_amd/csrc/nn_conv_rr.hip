@@ -90,7 +90,7 @@ namespace {
 
 #ifdef PD_LAB_RR_STAMP                                      // (lab builds only: where one workgroup's time goes, s_memtime cycles of wave 0)
 __device__ unsigned long long g_rr_stamps[256 * 16];
-#define RR_STAMP(k) do { if (tid == 0) lab_t[k] = __builtin_readcyclecounter(); } while (0)
+#define RR_STAMP(k) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); lab_t[k] += t_ - lab_prev; lab_prev = t_; } } while (0)    // time spent in the phase ENDING at stamp k, summed over the units
 #else
 #define RR_STAMP(k) do {} while (0)
 #endif
@@ -119,7 +119,8 @@ struct RrCfg {
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
-template <int W, int MT, int NF, int CS>
+// GNF: the in-staging GroupNorm path compiled in (the large-tile variants leave it out: its constants cost ~80 registers they do not have)
+template <int W, int MT, int NF, int CS, bool GNF>
 __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
     using G = RrCfg<W, MT, NF, CS>;
     constexpr int TR = G::TR, ROWS = G::ROWS, RS = G::RS, PS = G::PS, PP = G::PP, PXI = G::PXI, UP = G::UP;
@@ -128,8 +129,9 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef PD_LAB_RR_STAMP
     unsigned long long lab_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long lab_prev = __builtin_readcyclecounter();
+    lab_t[15] = lab_prev;
 #endif
-    RR_STAMP(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave;                                 // this wave's K share: 32-channel steps wk * JW .. of every unit
     const int H = a.H;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
     const int units = second ? a.U1 : a.U0;
     const int unit0 = (second ? slab - a.S0 : slab) * units;
     const int ks_src0 = second ? a.taps0 * (a.src[0].C >> 5) : 0;          // first K-step of this source in the weight fragments
-    const int sgn = sr->gn;
+    const int sgn = GNF ? sr->gn : 0;
 
     // ---- halo columns: zero once (staging never writes them); LDS pixel (ry, 0) and (ry, W + 1)
     for (int q = tid; q < ROWS * 2 * PP; q += 256) {
@@ -517,10 +519,11 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
 #endif
 }
 
-template <int W, int MT, int NF, int CS>
+template <int W, int MT, int NF, int CS, bool GNF = true>
 int launch_rr(const RrArgs& a, int grid, hipStream_t s) {
     using G = RrCfg<W, MT, NF, CS>;
-    auto kern = k_conv_rr<W, MT, NF, CS>;
+    PD_REQUIRE(GNF || (a.src[0].gn == 0 && a.src[1].gn == 0), "conv_rr: this tile variant has no in-staging GroupNorm");
+    auto kern = k_conv_rr<W, MT, NF, CS, GNF>;
     if (G::SMEM > 65536) PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
     kern<<<grid, 256, G::SMEM, s>>>(a);
     PD_LAUNCH_CHECK();
@@ -566,6 +569,8 @@ int conv_rr_pack(const half_t* w_packed, int Cin, int taps, int Cs, int Cout, ha
 //   5: W = 8,  whole image,               16 channels, 128-channel units
 //   6: W = 32, 4-row bands,               16 channels, 128-channel units (twice the tiles: the 32^2 layers can run unsplit)
 //   7: W = 16, half image,                16 channels, 128-channel units
+//   8: W = 64, 4-row bands (256 pixels),  32 channels, 128-channel units
+//   (W = 128, 2-row bands: measured 40.6 us against k_conv_sk's 25.8 at 128^2 / 256 -> 256 and 34 spilled registers -- not kept)
 static bool rr_variant(int v, int* w, int* mt, int* nf, int* cs) {
     switch (v) {
         case 1: *w = 8; *mt = 4; *nf = 1; *cs = 256; return true;
@@ -574,21 +579,44 @@ static bool rr_variant(int v, int* w, int* mt, int* nf, int* cs) {
         case 5: *w = 8; *mt = 4; *nf = 1; *cs = 128; return true;
         case 6: *w = 32; *mt = 8; *nf = 1; *cs = 128; return true;
         case 7: *w = 16; *mt = 8; *nf = 1; *cs = 128; return true;
+        case 8: *w = 64; *mt = 16; *nf = 2; *cs = 128; return true;
     }
     return false;
 }
-RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs, size_t ws_floats) {
+RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs, size_t ws_floats, bool want_gn) {
     RrPlan p{0, 0, 0, 0, 0, 0, 0};
     if (g_rr_mode == 0 || H != W || (taps != 9 && taps != 1)) return p;
-    int v = g_rr_variant;
-    if (v == 0) v = W == 8 ? 1 : W == 16 ? 2 : W == 32 ? 3 : 0;
-    int vw, mt, nf, cs;
+    // Candidate tile variants of the image width, smallest channel tile first.  Rule read off tools/bench_rr.py (profiles/r06_rr_bench_standalone.txt):
+    // the variant whose tiles come closest to one workgroup per CU with the FEWEST K slabs wins -- every slab beyond the first costs a
+    // write-through publish, a ticket round trip and a re-read of the slices by the last arriver (~4 us of a 10 us launch).
+    static const int cand8[] = {1, 0}, cand16[] = {7, 2, 0}, cand32[] = {6, 3, 0}, cand64[] = {8, 0};
+    const int* cand = W == 8 ? cand8 : W == 16 ? cand16 : W == 32 ? cand32 : W == 64 ? cand64 : nullptr;
+    if (cand == nullptr) return p;
+    int v = g_rr_variant, vw = 0, mt = 0, nf = 0, cs = 0;
+    if (v == 0) {
+        for (int k = 0; cand[k] != 0; ++k) {
+            int w_, mt_, nf_, cs_;
+            rr_variant(cand[k], &w_, &mt_, &nf_, &cs_);
+            if (want_gn && (cand[k] == 6 || cand[k] == 7 || cand[k] >= 8)) continue;      // (the variants without the in-staging GroupNorm)
+            if (Cin % cs_ != 0 || Cs % cs_ != 0 || Cout % (nf_ * 16) != 0) continue;
+            v = cand[k];
+            if ((long long)N * (H * W / (mt_ * 16)) * (Cout / (nf_ * 16)) <= 256) break;        // fits one round of workgroups: take it; else try the next (larger) tile
+        }
+    }
     if (!rr_variant(v, &vw, &mt, &nf, &cs) || vw != W) return p;
     if (Cin % cs != 0 || Cs % cs != 0 || Cout % (nf * 16) != 0) return p;
     const int bands = H * W / (mt * 16);
     const int ntiles = Cout / (nf * 16);
     const long long tiles = (long long)N * bands * ntiles;
     if (tiles > 4096) return p;
+    // automatic routing: the launches a same-box A/B of the DDNM step favours (profiles/r06_rr_ab.txt): batch 1-2 at 8^2 ... 32^2 (batch 4 at
+    // 8^2 only: from batch 4 up k_conv_sk's larger tiles win back what the slabs cost), batch 1 at 64^2 for the 512+-channel layers without an
+    // appended skip (256 -> 512 there: 20 us against 16)
+    if (g_rr_mode != 2) {
+        // (with an appended skip 1x1 the slabs of 1x1 units are the long pole: 16-27 us against k_conv_sk<10>'s 15-23 at every level -- not routed)
+        const bool ok = Cs == 0 && (W <= 32 ? (N <= 2 || (N <= 4 && W == 8)) : (W == 64 && N == 1 && Cin >= 512));
+        if (!ok) return p;
+    }
     // slabs: enough workgroups to put ~one on every CU, every slab a whole number of units, at most 8 conv slabs (the last arriver re-reads them all)
     const int u0 = Cin / cs, u1 = Cs / cs;
     int s0 = g_rr_slabs > 0 ? g_rr_slabs : (int)std::max<long long>(1, (256 + tiles / 2) / tiles);
@@ -596,12 +624,11 @@ RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs, si
     while (u0 % s0 != 0) --s0;
     int s1 = 0;
     if (u1 > 0) {
-        // the skip's K per slab ~ the conv's K per slab (9 taps x u0 / s0 units): u1 / s1 ~ 9 u0 / s0
+        // the skip's K per slab ~ the conv's K per slab (9 taps x u0 / s0 units): u1 / s1 ~ 9 u0 / s0.  (Cutting it by UNIT count instead --
+        // a 1x1 unit costs two barriers and a staging round trip like a 3x3 one -- measured worse: 12 slabs to combine at the 8^2 level.)
         s1 = std::max(1, std::min(u1, (int)((long long)u1 * s0 / ((long long)taps * u0) + 1)));
         while (u1 % s1 != 0) --s1;
     }
-    // automatic routing: small launches only (the big-tile kernels own the rest)
-    if (g_rr_mode != 2 && tiles * (s0 + s1) > 1024) return p;
     if ((size_t)tiles * (s0 + s1) * mt * nf * 256 + PD_SK_TICKET_FLOATS > ws_floats && s0 + s1 > 1) return p;
     p.variant = v; p.S0 = s0; p.U0 = u0 / s0; p.S1 = s1; p.U1 = s1 ? u1 / s1 : 0; p.bands = bands; p.ntiles = ntiles;
     return p;
@@ -651,8 +678,9 @@ int conv_rr(const RrPlan& pl, const RrIn& in, const RrIn* skip, int taps, const 
         case 2: return launch_rr<16, 8, 2, 128>(a, grid, s);
         case 3: return launch_rr<32, 8, 2, 128>(a, grid, s);
         case 5: return launch_rr<8, 4, 1, 128>(a, grid, s);
-        case 6: return launch_rr<32, 8, 1, 128>(a, grid, s);
-        case 7: return launch_rr<16, 8, 1, 128>(a, grid, s);
+        case 6: return launch_rr<32, 8, 1, 128, false>(a, grid, s);
+        case 7: return launch_rr<16, 8, 1, 128, false>(a, grid, s);
+        case 8: return launch_rr<64, 16, 2, 128, false>(a, grid, s);
     }
     set_error("conv_rr: unknown variant %d", pl.variant);
     return PDHIP_E_ARG;
@@ -715,7 +743,7 @@ extern "C" int pdhip_conv_rr_f16(const void* x, const void* x2, int C, int Ca, i
                                  void* y, int N, int H, int W, int Cout, float* ws, long long ws_floats, float* gn_part, int* gn_chunks,
                                  void* stream) {
     PD_REQUIRE(x && wf && y, "pdhip_conv_rr_f16: null argument");
-    const pdnn::RrPlan pl = pdnn::conv_rr_plan(N, H, W, C, Cout, taps, xs ? Cs : 0, ws ? (size_t)ws_floats : 0);
+    const pdnn::RrPlan pl = pdnn::conv_rr_plan(N, H, W, C, Cout, taps, xs ? Cs : 0, ws ? (size_t)ws_floats : 0, gn_mode != 0);
     PD_REQUIRE(pl.variant != 0, "pdhip_conv_rr_f16: not a layer for the row-resident kernel (N=%d H=%d W=%d Cin=%d Cout=%d taps=%d Cs=%d)", N, H, W, C, Cout, taps, xs ? Cs : 0);
     pdnn::RrIn in{(const pdnn::half_t*)x, (const pdnn::half_t*)x2, C, x2 ? Ca : C, gn_mode, gamma, beta, film, film_stride, partA, partB, chunksA, chunksB, 1e-5f};
     pdnn::RrIn sk{(const pdnn::half_t*)xs, (const pdnn::half_t*)xs2, Cs, xs2 ? Cs1 : Cs, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1e-5f};

@@ -17,10 +17,11 @@ using namespace pdnn;
 
 namespace {
 
-struct ConvW { half_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, cout_pad = 0, taps = 0; bool have_w = false, have_b = false; };
+struct ConvW { half_t* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, cout_pad = 0, taps = 0; bool have_w = false, have_b = false;
+               half_t* wf = nullptr; };   // wf: fragment-major copy for the row-resident kernel (nn_conv_rr.hip), the 3x3 convs of the <= 64^2 levels; packed at load time
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; bool have_g = false, have_b = false; };
 struct ResB { std::string name; int cin, cout, mode; NormW n1, n2; ConvW c1, c2, skip; long long emb_off; bool has_skip; bool have_ew = false, have_eb = false;
-              half_t* c2s_w = nullptr; float* c2s_b = nullptr; bool c2s_ready = false; };   // conv2 with the skip 1x1 appended to its K loop (conv_sk_skip), built by pdhip_unet_load_tensor once its four sources are loaded
+              half_t* c2s_w = nullptr; float* c2s_b = nullptr; bool c2s_ready = false; half_t* c2s_wf = nullptr; int hw = 0; };   // hw: resolution the block's convs run at   // conv2 with the skip 1x1 appended to its K loop (conv_sk_skip), built by pdhip_unet_load_tensor once its four sources are loaded
 struct AttB { std::string name; int c; NormW n; ConvW qkv, proj; };
 struct Block { int kind; int idx; };          // 0 conv_in, 1 res, 2 attn
 
@@ -202,6 +203,17 @@ int run_conv(Ctx& c, const Act& x, const ConvW& w, const half_t* residual, Act* 
     const bool prof = x.p2 == nullptr && conv_uses_halo(c.N, cH, cW, w.cin, w.cout, w.cout_pad, w.taps, c.u->splitk_floats) &&
                       conv3x3_halo_splits(c.N, cH, cW, w.cin, w.cout, w.cout_pad, c.u->splitk_floats) == 1;
     if (prof) PD_TRY(prof_begin(c, 2.0 * c.N * cH * cW * (double)w.cout * 9.0 * w.cin));
+    // small batch, <= 64^2: the row-resident kernel (register-resident fragment-major weights, halo staged once per channel chunk)
+    if (w.wf != nullptr && w.taps == 9 && x.p2 == nullptr && apply_table == nullptr && in_up == 0 && !prof) {
+        const RrPlan pl = conv_rr_plan(c.N, cH, cW, w.cin, w.cout, 9, 0, c.u->splitk_floats);
+        if (pl.variant != 0) {
+            const RrIn in{x.p, nullptr, w.cin, w.cin, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1e-5f};
+            int chunks = 0;
+            PD_TRY(conv_rr(pl, in, nullptr, 9, w.wf, w.b, residual, res_up, out->p, c.N, cH, cW, w.cout, c.u->splitk_ws, c.u->splitk_floats, part, &chunks, c.s));
+            if (part != nullptr && chunks > 0) { out->gn_part = part; out->gn_chunks = chunks; out->Ca = w.cout; }
+            return PDHIP_OK;
+        }
+    }
     int fused = 0;
     int rc = conv_igemm(x.p, w.w, w.b, residual, out->p, c.N, cH, cW, w.cin, w.cout, w.cout_pad, w.taps, c.u->zero_page, c.s,
                         c.u->splitk_ws, c.u->splitk_floats, part, &fused, x.p2, x.p2 ? x.Ca : 0, apply_table, res_up, in_up);
@@ -272,7 +284,8 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
                          ((Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&      // nearest x2: index arithmetic in conv2's
                            conv_uses_halo(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) &&   // residual read
                            conv3x3_halo_splits(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, c.u->splitk_floats) == 1) ||
-                          (g_fuse_gn == 0 && conv_routes_sk(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats)));   // (round 4: k_conv_sk's epilogue too)
+                          (g_fuse_gn == 0 && conv_routes_sk(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats)) ||   // (round 4: k_conv_sk's epilogue too)
+                          (g_fuse_gn == 0 && rb.c2.wf != nullptr && conv_rr_plan(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, 9, 0, c.u->splitk_floats).variant != 0));   // (round 6: k_conv_rr's)
     if (rb.mode != 0) {
         xr.H = Ho; xr.W = Wo;
         xr.p = arena_take(c.u, (size_t)c.N * Ho * Wo * x.C);     // (the sizing pass always reserves it: routing may differ later)
@@ -311,6 +324,21 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     if (rb.has_skip && !fuse_skip && !c.dry && g_fold_skip != 0 && rb.mode == 0 && rb.c2s_w != nullptr && rb.skip.taps == 1 &&
         (x.p2 == nullptr || (x.Ca % 64 == 0 && (x.C - x.Ca) % 64 == 0)) &&
         !conv_uses_halo(c.N, h1.H, h1.W, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) && !can_fuse_gn(c, h1, rb.c2)) {
+        const RrPlan rp = rb.c2s_wf != nullptr && (x.p2 == nullptr || (x.Ca % 128 == 0 && (x.C - x.Ca) % 128 == 0))
+                              ? conv_rr_plan(c.N, h1.H, h1.W, rb.c2.cin, rb.cout, 9, rb.skip.cin, c.u->splitk_floats) : RrPlan{0, 0, 0, 0, 0, 0, 0};
+        if (rp.variant != 0) {                           // round 6: conv2 + skip 1x1 as slabs of one row-resident launch
+            PD_REQUIRE(rb.c2.have_w && rb.c2.have_b && rb.skip.have_w && rb.skip.have_b && rb.c2s_ready, "unet: conv2 / skip weights of %s not loaded", rb.name.c_str());
+            PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
+            *out = Act{nullptr, rb.cout, h1.H, h1.W};
+            out->p = arena_take(c.u, (size_t)c.N * h1.H * h1.W * rb.cout);
+            float* part = reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((h1.H * h1.W + 15) / 16) * (rb.cout / 8) * 2 * 2));
+            const RrIn in{h2.p, nullptr, rb.c2.cin, rb.c2.cin, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1e-5f};
+            const RrIn sk_in{x.p, x.p2, x.C, x.p2 ? x.Ca : x.C, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 1e-5f};
+            int chunks = 0;
+            PD_TRY(conv_rr(rp, in, &sk_in, 9, rb.c2s_wf, rb.c2s_b, nullptr, 0, out->p, c.N, h1.H, h1.W, rb.cout, c.u->splitk_ws, c.u->splitk_floats, part, &chunks, c.s));
+            if (chunks > 0) { out->gn_part = part; out->gn_chunks = chunks; out->Ca = rb.cout; }
+            return PDHIP_OK;
+        }
         const SkPlan pl = conv_sk_plan(c.N, h1.H, h1.W, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, false, c.u->splitk_floats, rb.skip.cin);
         if (pl.bm > 0) {
             PD_REQUIRE(rb.c2.have_w && rb.c2.have_b && rb.skip.have_w && rb.skip.have_b, "unet: conv2 / skip weights of %s not loaded", rb.name.c_str());
@@ -448,8 +476,8 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
     auto is_att = [&](int ds) { for (int a : u->att_ds) if (a == ds) return true; return false; };
     auto fail = [&](int rc) { for (void* p : u->owned) (void)hipFree(p); delete u; return rc; };
     long long emb_rows = 0;
-    auto add_res = [&](const std::string& name, int cin, int cout, int mode) -> int {
-        ResB rb; rb.name = name; rb.cin = cin; rb.cout = cout; rb.mode = mode; rb.has_skip = cin != cout;
+    auto add_res = [&](const std::string& name, int cin, int cout, int mode, int hw) -> int {
+        ResB rb; rb.name = name; rb.cin = cin; rb.cout = cout; rb.mode = mode; rb.has_skip = cin != cout; rb.hw = hw;
         rb.emb_off = emb_rows; emb_rows += 2 * cout;
         u->res.push_back(rb);
         return (int)u->res.size() - 1;
@@ -468,7 +496,7 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
         for (int r = 0; r < num_res_blocks; ++r) {
             std::vector<Block> layers;
             const int o = u->mult[level] * u->mc;
-            layers.push_back(Block{1, add_res("input_blocks." + std::to_string(n) + ".0", ch, o, 0)});
+            layers.push_back(Block{1, add_res("input_blocks." + std::to_string(n) + ".0", ch, o, 0, image_size / ds)});
             ch = o;
             if (is_att(ds)) layers.push_back(Block{2, add_att("input_blocks." + std::to_string(n) + ".1", ch)});
             u->input.push_back(layers);
@@ -476,15 +504,15 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
             ++n;
         }
         if (level != n_mult - 1) {
-            u->input.push_back({Block{1, add_res("input_blocks." + std::to_string(n) + ".0", ch, ch, 1)}});
+            u->input.push_back({Block{1, add_res("input_blocks." + std::to_string(n) + ".0", ch, ch, 1, image_size / (ds * 2))}});
             chans.push_back(ch);
             ds *= 2;
             ++n;
         }
     }
-    u->middle.push_back(Block{1, add_res("middle_block.0", ch, ch, 0)});
+    u->middle.push_back(Block{1, add_res("middle_block.0", ch, ch, 0, image_size / ds)});
     u->middle.push_back(Block{2, add_att("middle_block.1", ch)});
-    u->middle.push_back(Block{1, add_res("middle_block.2", ch, ch, 0)});
+    u->middle.push_back(Block{1, add_res("middle_block.2", ch, ch, 0, image_size / ds)});
     n = 0;
     for (int level = n_mult - 1; level >= 0; --level) {
         for (int i = 0; i < num_res_blocks + 1; ++i) {
@@ -492,12 +520,12 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
             const int o = u->mc * u->mult[level];
             std::vector<Block> layers;
             const std::string base = "output_blocks." + std::to_string(n) + ".";
-            layers.push_back(Block{1, add_res(base + "0", ch + ich, o, 0)});
+            layers.push_back(Block{1, add_res(base + "0", ch + ich, o, 0, image_size / ds)});
             ch = o;
             int k = 1;
             if (is_att(ds)) { layers.push_back(Block{2, add_att(base + std::to_string(k), ch)}); ++k; }
             if (level && i == num_res_blocks) {
-                layers.push_back(Block{1, add_res(base + std::to_string(k), ch, ch, 2)});
+                layers.push_back(Block{1, add_res(base + std::to_string(k), ch, ch, 2, image_size / (ds / 2))});
                 ds /= 2;
             }
             u->output.push_back(layers);
@@ -516,6 +544,12 @@ extern "C" int pdhip_unet_create(int image_size, int model_channels, int num_res
         if (rb.has_skip && rb.mode == 0 && rb.cin % 64 == 0 && rb.cout % 64 == 0) {       // fused [conv2 | skip] weights (built at the first forward that routes there)
             chk(dalloc(u, &rb.c2s_w, (size_t)rb.c2.cout_pad * (9 * (size_t)rb.cout + rb.cin)));
             chk(dalloc(u, &rb.c2s_b, (size_t)rb.cout));
+        }
+        // fragment-major copies for the row-resident kernel (small-batch route of the <= 64^2 levels; +~1 GB at the 256^2 config: 288 GB HBM)
+        if (rb.hw <= 64 && rb.cin % 128 == 0 && rb.cout % 128 == 0) {
+            chk(dalloc(u, &rb.c1.wf, conv_rr_weight_halfs(rb.cin, 9, 0, rb.cout)));
+            chk(dalloc(u, &rb.c2.wf, conv_rr_weight_halfs(rb.cout, 9, 0, rb.cout)));
+            if (rb.c2s_w != nullptr) chk(dalloc(u, &rb.c2s_wf, conv_rr_weight_halfs(rb.cout, 9, rb.cin, rb.cout)));
         }
         if (rc) return fail(rc);
     }
@@ -635,6 +669,7 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
         PD_REQUIRE(shape[0] == c.cout && shape[1] == c.cin, "pdhip_unet_load_tensor: %s: shape mismatch", name_c);
         k_pack_conv<<<grid_for(numel), 256, 0, s>>>(data, is_f16, c.cout, c.cin, c.taps, c.w);
         PD_LAUNCH_CHECK();
+        if (c.wf != nullptr) PD_TRY(conv_rr_pack(c.w, c.cin, c.taps, 0, c.cout, c.wf, s));      // (same stream: ordered behind the repack above)
         c.have_w = true;
         return PDHIP_OK;
     };
@@ -684,6 +719,7 @@ extern "C" int pdhip_unet_load_tensor(pdhip_unet* u, const char* name_c, const v
             rb.c2s_ready = false;
             if (rb.c2.have_w && rb.c2.have_b && rb.skip.have_w && rb.skip.have_b && rb.skip.taps == 1) {
                 PD_TRY(fuse_skip_weights(rb.c2.w, 9 * rb.c2.cin, rb.skip.w, rb.skip.cin, rb.c2.cout_pad, rb.c2.b, rb.skip.b, rb.cout, rb.c2s_w, rb.c2s_b, s));
+                if (rb.c2s_wf != nullptr) PD_TRY(conv_rr_pack(rb.c2s_w, rb.c2.cin, 9, rb.skip.cin, rb.cout, rb.c2s_wf, s));
                 rb.c2s_ready = true;
             }
             return PDHIP_OK;

@@ -147,6 +147,8 @@ def test_conv_rr_vs_torch_fp32_and_two_pass_form(nn, N, HW, Ca, Cb, Cout, gn, fi
     rd = r.to(DEV) if r is not None else None
     ws = torch.zeros((4096 + 4 * 1024 * 1024,), dtype=torch.float32, device=DEV)
     bdv = b.to(DEV)
+    if gn and variant == 0:
+        variant = {8: 1, 16: 2, 32: 3}[HW]                 # (the two-pass comparison below must run the SAME tile variant: the raw-input form would pick the 16-channel tiles)
     old = L.pdhip_debug_set_conv_rr(2, variant, slabs)
     try:
         y1, p1, ch = _rr(L, xa, xb, gn, gd, bd, fd, parts, xsa, xsb, 9, wf, bdv, rd, 1 if res == 2 else 0, N, H, W, Cout, ws)
@@ -184,3 +186,49 @@ def test_conv_rr_refuses_what_it_does_not_serve(nn):
     rc = L.pdhip_conv_rr_f16(_ptr(x), None, 128, 128, 0, None, None, None, 0, None, 0, None, 0, None, None, 0, 0, 9, _ptr(wf), None, None, 0, _ptr(y), 1, 12, 12,
                              64, _ptr(ws), ws.numel(), None, C.byref(ch), _stream())
     assert rc != 0 and b'row-resident' in L.pdhip_last_error()
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / b.abs().max()).item(), ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def full_model(nn):
+    from oracle import unet as ounet
+    cfg = ounet.make_config(256, 256, 2, "32,16,8", 64, True)
+    w = ounet.random_weights(cfg, 12)
+    m = nn['di'].UNetModel(max_batch=8, device=DEV, **nn['di'].IMAGENET_256)
+    m.load_state_dict(w, strict=True)
+    del w
+    return m
+
+
+@pytest.mark.parametrize("N", [1, 2, 4, 8])
+def test_unet_full_with_and_without_the_row_resident_route(nn, full_model, N):
+    """The 552.8 M-parameter UNet at batch 1 / 2 / 4 / 8 with the row-resident conv route (automatic: 8^2 ... 64^2 levels by batch), with every
+    eligible layer forced onto it, and with the route off (round 5's kernels): each against the reference's fp32 forward (unet_full.npz, the
+    suite's U1 bound), the routings against each other in the batched-vs-batch-1 tolerance class, every forward deterministic."""
+    L = nn['L']
+    g = load_golden('unet_full.npz')
+    st = int(g['stride'])
+    x = torch.from_numpy(g['x']).to(DEV).repeat(N, 1, 1, 1).contiguous()
+    t = torch.from_numpy(g['t']).to(DEV).repeat(N).contiguous()
+    outs = {}
+    for mode in (1, 2, 0):
+        old = L.pdhip_debug_set_conv_rr(mode, 0, 0)
+        try:
+            outs[mode] = full_model(x, t).cpu()
+            again = full_model(x, t).cpu()
+        finally:
+            L.pdhip_debug_set_conv_rr(old, 0, 0)
+        assert torch.equal(outs[mode], again), mode
+        for b in range(N):
+            linf, l2 = _rel(outs[mode][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+            note_measured(test='unet_full_fp32_rr', batch=N, mode=mode, linf=linf, l2=l2)
+            assert linf <= U1_FP32_LINF and l2 <= U1_FP32_L2, (N, mode, b, linf, l2)
+    for mode in (1, 2):
+        linf, l2 = _rel(outs[mode], outs[0])
+        assert linf <= 4e-3 and l2 <= 2.5e-3, (N, mode, linf, l2)
+    if N <= 2:
+        assert not torch.equal(outs[1], outs[0]), "the automatic route must actually take the new kernel at small batch"

@@ -11,7 +11,8 @@ P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 SHAPES = [  # (H, Cin, Cout, Cs) -- Cs: channels of the block input when the ResBlock's skip 1x1 rides along (decoder conv2), else 0
     (8, 1024, 1024, 0), (8, 2048, 1024, 0), (8, 1024, 1024, 2048),
     (16, 1024, 1024, 0), (16, 2048, 1024, 0), (16, 512, 1024, 0), (16, 1024, 1024, 1536),
-    (32, 512, 512, 0), (32, 1024, 512, 0), (32, 512, 512, 768), (32, 256, 512, 0)]
+    (32, 512, 512, 0), (32, 1024, 512, 0), (32, 512, 512, 768), (32, 256, 512, 0),
+    (64, 512, 512, 0), (64, 1024, 512, 0), (64, 256, 512, 0), (64, 512, 512, 768), (128, 256, 256, 0), (128, 512, 256, 0), (128, 256, 256, 512)]
 ap = argparse.ArgumentParser()
 ap.add_argument('--shapes', type=int, nargs='*', default=None)
 ap.add_argument('--variants', type=int, nargs='*', default=[0])
@@ -110,15 +111,12 @@ for si, (H, Cin, Cout, Cs) in enumerate(SHAPES):
                     fn = C.CDLL(_lib.LIB_PATH).pdhip_lab_rr_read_stamps
                     assert fn(buf, 4096) == 0
                     st = np.array(buf, dtype=np.uint64).astype(np.int64).reshape(256, 16)
-                    st = st[st[:, 0] > 0]
-                    names = ['start', 'loads issued', 'stats', 'sync+raw store', 'transform+sync', 'mfma', 'exchange', 'publish+ticket', 'combine', 'epilogue']
-                    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
-                    d = []
-                    for k in range(1, 10):
-                        m = (st[:, k] > 0) & (st[:, k - 1] > 0)
-                        d.append(f"{names[k]} {np.median(st[m, k] - st[m, k - 1]) if m.any() else -1:.0f}")
-                    last = st[st[:, 9] > 0]
-                    row.append("\n        [last unit of a workgroup, cycles: " + ", ".join(d) + f" | whole workgroup (finishers) {np.median(last[:, 9] - last[:, 0]) if len(last) else -1:.0f}; start spread {st[:, 0].max() - st[:, 0].min()}]")
+                    st = st[st[:, 15] > 0]
+                    names = ['-', 'prologue + first loads issued', 'statistics', 'sync + act wait + raw store', 'transform + next act issued + sync', 'mfma + next weights issued', 'exchange', 'publish + ticket', 'combine', 'epilogue']
+                    fin = st[st[:, 9] > 0]
+                    d = [f"{names[k]} {np.median(fin[:, k]):.0f}" for k in range(1, 10)] if len(fin) else []
+                    row.append("\n        [cycles per phase summed over the units, median over the finishing workgroups: " + ", ".join(d) +
+                               f" | sum {np.median(fin[:, 1:10].sum(1)) if len(fin) else -1:.0f}]")
             print(f"   rr variant {v}: " + "  ".join(row))
         L.pdhip_debug_set_conv_rr(1, 0, 0)
         del wps, wfs
