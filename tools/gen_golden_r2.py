@@ -13,8 +13,15 @@ Build container only:  python -m tools.gen_golden_r2 [p1 o1 triptych clock]
                      complete_unseen_by neighbor) on CPU.  Stand-ins for the absent third-party packages: kaolin camera
                      (oracle/camera.py), nvdiffrast.rasterize (oracle/project.py), open3d hidden_point_removal (oracle: scipy
                      qhull), torchvision Resize, kaolin sided_distance / uniform_laplacian, trimesh helpers (tools/ref_harness.py).
-                     The geometry is the build's stand-in UV sphere (POCO / xatlas are upstream of the path).  `optimize_from`
-                     is recorded both off (exact stages only) and -- separately, see gen_clock(optimize=True) -- on.
+                     The geometry is the build's stand-in UV sphere (POCO / xatlas are upstream of the path).  `optimize_from` is off
+                     here (exact stages only); the optimisation loop is pinned on its own by optimize_*.npz below.
+  optimize_*.npz     SURVEY 8f-1: pointdreamer.ours_utils.optimize_color (:1583-1785) -- the reference's own Adam(5e-2) / StepLR(15, 0.5) loop,
+                     f64 bilinear lookup, L1 loss masked by foreground and shrunk visibility -- run here on the CPU with V = 3 views at its
+                     hard-wired 1024^2 render size, atlas 64^2 and 128^2, 3 and 100 iterations, with and without the shrunk visibility.
+                     Stand-ins: nvdiffrast.rasterize / interpolate (the oracle's rasteriser + barycentric interpolation),
+                     kaolin.render.mesh.texture_mapping (grid_sample, align_corners=False, border: its published behaviour), kaolin's
+                     camera-matrix helpers and prepare_vertices (their results are unused on the nvdiffrast branch), torchvision Resize,
+                     and `device='cuda'` in one torch.ones call of the unused attribute list (dropped).
 Inputs that come from the build's generators are stored as inputs; every `ref_*` array was computed by reference code."""
 import io
 import os
@@ -260,11 +267,73 @@ def gen_clock():
     print('clock: visible fraction', cap['point_validation'].mean(), 'painted', cap['painted'].mean(), 'atlas mean', atlas.mean())
 
 
+def gen_optimize():
+    """optimize_{A}_{its}_{shr}.npz: inputs + the atlas the REFERENCE's optimize_color returns (ours_utils.py:1583-1785)."""
+    import types
+    import torch.nn.functional as F
+    ou, up, u2 = rh.import_reference()
+    seen = install_raster_stub()
+    nv = sys.modules['nvdiffrast'].torch
+
+    def interpolate(attr, rast, tri, **kw):              # nvdiffrast.torch.interpolate(uvs, rast, face_uvs_idx) -> (values,)
+        fid = rast[..., 3].long().numpy() - 1
+        bary = oproj.raster_barycentrics(seen['pos'], seen['faces'], fid, fid.shape[1])
+        return (torch.from_numpy(oproj.interpolate(attr.detach().cpu().numpy().astype(np.float32), tri.detach().cpu().numpy().astype(np.int64), fid, bary)),)
+    _rast = nv.rasterize
+
+    def rasterize(glctx, pos, tri, resolution, grad_db=False, **kw):
+        seen['faces'] = tri.detach().cpu().numpy().astype(np.int64)
+        return _rast(glctx, pos, tri, resolution, grad_db=grad_db, **kw)
+    nv.rasterize, nv.interpolate = rasterize, interpolate
+    ou.dr = nv; ou.nvdiffrast = sys.modules['nvdiffrast']
+    kal = sys.modules['kaolin']
+
+    def texture_mapping(texture_coords, atlas, mode='bilinear'):   # kaolin.render.mesh.texture_mapping: uv in [0,1], v up -> [B,H,W,C]
+        g = texture_coords * 2.0 - 1.0
+        g = torch.stack([g[..., 0], -g[..., 1]], -1)
+        return F.grid_sample(atlas, g, mode=mode, align_corners=False, padding_mode='border').permute(0, 2, 3, 1)
+    kal.render.mesh.texture_mapping = texture_mapping
+    kal.render.mesh.prepare_vertices = lambda *a, **k: (None, None, None)
+    cam_mod = sys.modules.get('kaolin.render.camera') or kal.render.camera
+    cam_mod.generate_transformation_matrix = lambda e, l, u_: torch.zeros((len(e), 4, 3))
+    cam_mod.generate_perspective_projection = lambda fovy, ratio=1.0: torch.zeros((3, 1))
+    cam_mod.perspective_camera = lambda *a, **k: None
+    sys.modules['kaolin.render.camera'] = cam_mod
+    # `torch.ones(..., device='cuda')` (ours_utils.py:1671, an attribute list the nvdiffrast branch never reads): drop the device
+    proxy = types.ModuleType('torch_cpu_proxy')
+    proxy.__dict__.update(torch.__dict__)
+    proxy.ones = lambda *a, device=None, **k: torch.ones(*a, **k)
+    ou.torch = proxy
+    torch.manual_seed(0)
+    V, R, r = 3, 128, 64
+    verts, faces, lut = synthetic.uv_sphere(10, 20)
+    cams, base_dirs, eyes, ups = ocam.create_cameras(V, 1.6, R)
+    pr = oproj.project_batch(cams, verts, verts[:8], True, 0.05)
+    uvs_np, tex_idx = synthetic.uv_sphere_uvs(10, 20, A=64, gutter=2)      # (what xatlas would hand over as `uvs`, `mesh_tex_idx`)
+    sf = np.array([1.0, 0.9, 1.1], np.float32)
+    tcams = [TorchCam(c) for c in cams]
+    g = np.random.default_rng(5)
+    for A, its, use_shr in ((64, 3, True), (64, 100, True), (64, 100, False), (128, 3, False), (128, 100, True)):
+        atlas0 = g.random((3, A, A), dtype=np.float32)
+        inp = g.random((V, 3, r, r), dtype=np.float32)
+        shr = (g.random((V, A, A)) > 0.3) if use_shr else None
+        atlas, images = ou.optimize_color(t(atlas0.copy()), t(inp.copy()), t(verts), t(faces), t(uvs_np), t(tex_idx), tcams, t(eyes), None, t(ups),
+                                          t(pr['uv_centers']), t(pr['uv_scales']), 0.05, t(sf), None,
+                                          shrinked_per_view_per_pixel_visibility=None if shr is None else t(shr), lr=5e-2, iterations=its)
+        images = images.detach()
+        np.savez_compressed(os.path.join(OUT, f'optimize_{A}_{its}_{int(use_shr)}.npz'), atlas0=atlas0, inpainted=inp, verts=verts, faces=faces, uvs=uvs_np,
+                            mesh_tex_idx=tex_idx, cam_params=np.stack([c.params for c in cams]), cam_res=np.int64(R), uv_centers=pr['uv_centers'],
+                            uv_scales=pr['uv_scales'], padding=np.float32(0.05), scale_factors=sf, shrinked=np.zeros((0,), bool) if shr is None else shr,
+                            iterations=np.int64(its), ref_atlas=atlas.detach().numpy().astype(np.float32),
+                            ref_images_mean=images.mean(dim=(2, 3)).numpy(), ref_images_small=images[:, :, ::16, ::16].numpy().astype(np.float32))
+        print('optimize', A, its, use_shr, float((atlas.detach().numpy() - atlas0).__abs__().max()))
+
+
 if __name__ == '__main__':
     assert rh.available()
-    which = sys.argv[1:] or ['p1', 'o1', 'triptych', 'clock']
+    which = sys.argv[1:] or ['p1', 'o1', 'triptych', 'clock', 'optimize']
     os.makedirs(OUT, exist_ok=True)
     for w in which:
-        dict(p1=gen_p1, o1=gen_o1, triptych=gen_triptych, clock=gen_clock)[w]()
+        dict(p1=gen_p1, o1=gen_o1, triptych=gen_triptych, clock=gen_clock, optimize=gen_optimize)[w]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
