@@ -207,6 +207,10 @@ int pdhip_texel_visibility(const float* cam_params, int V, const float* gb_pos /
  *      out[K,V,A,A] u8.  ws: 2*V*A*A bytes. */
 int pdhip_nbf_shrink(const uint8_t* mask /*[A,A]*/, const uint8_t* visibility /*[V,A,A]*/, int V, int A,
                      const int32_t* kernels, int K, uint8_t* out, uint8_t* ws, void* stream);
+/* Bit-packed transport of boolean texel maps (no reference counterpart: the reference is single-GPU; SURVEY 8(e) prices the view-parallel
+ * all-gather record with its visibility maps bit-packed): bit i of out word w = (in[64 w + i] != 0); n % 64 == 0; 16-byte aligned byte side. */
+int pdhip_pack_bits(const uint8_t* in /*[n] 0 / non-0*/, long long n, uint64_t* out /*[n / 64]*/, void* stream);
+int pdhip_unpack_bits(const uint64_t* in /*[n / 64]*/, long long n, uint8_t* out /*[n] 0 / 1*/, void* stream);
 /* the reference's always-on debug triptychs `others/shrink_per_view_edge/{v}.png` (unproject.py:459-474): per view
  * [visibility + background edges (red) + view edges (blue) | view edge mask | border mask of `kernel`] with 10 white columns
  * between panels, rows reversed; out [V][A][3A+20][3] u8 (HWC), ws (2V+1)*A*A bytes. */

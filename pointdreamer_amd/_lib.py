@@ -56,6 +56,8 @@ _SIGS = {
     'pdhip_debug_set_unproject_generic': (C.c_int, [i32]),
     'pdhip_texel_visibility': (C.c_int, [vp, i32, vp, vp, i32, vp, vp, f64, vp, i32, f32, vp, vp]),
     'pdhip_nbf_shrink': (C.c_int, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
+    'pdhip_pack_bits': (C.c_int, [vp, C.c_longlong, vp, vp]),
+    'pdhip_unpack_bits': (C.c_int, [vp, C.c_longlong, vp, vp]),
     'pdhip_nbf_triptych': (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
     'pdhip_view_select_blend': (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp, i32, vp, i32,
                                           vp, vp, vp, vp]),

@@ -4,6 +4,7 @@
 // produced on demand by pdhip_compact_texels (row-major order == boolean-mask order).
 // Compiled with -ffp-contract=off (arithmetic contract in oracle/unproject.py).
 #include "common.h"
+#include <algorithm>
 using namespace pdhip;
 
 #define MAXV 32
@@ -191,6 +192,39 @@ __global__ __launch_bounds__(256) void k_pack_bits16(const uint8_t* __restrict__
         m |= __shfl_xor(m, 2);
         if ((gi & 3) == 0) (second ? out_b : out_a)[gi >> 2] = m;
     }
+}
+
+// ---- bit-packed transport of boolean texel maps (the view-parallel all-gather record carries the raw and the K shrunk
+// visibility maps of a view as 64-texel words -- 128 KiB per 1024^2 map instead of 1 MiB).  Bit i of word w = (in[64 w + i] != 0),
+// i.e. as a byte stream: bit b of byte j = element 8 j + b.  n must be a multiple of 64.
+__global__ __launch_bounds__(256) void k_unpack_bits(const unsigned long long* __restrict__ in, long long nwords, uint8_t* __restrict__ out) {
+    // thread = 16 output bytes (a quarter word): one 16-byte store per thread, whole 128-byte lines per 8 threads
+    const long long t0 = blockIdx.x * (long long)blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+    for (long long g = t0; g < nwords * 4; g += nt) {
+        const unsigned int m = (unsigned int)(in[g >> 2] >> (16 * (int)(g & 3))) & 0xffffu;
+        uint4 q;
+        unsigned int* qq = reinterpret_cast<unsigned int*>(&q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned int b = (m >> (4 * k)) & 0xfu;
+            qq[k] = (b & 1u) | ((b & 2u) << 7) | ((b & 4u) << 14) | ((b & 8u) << 21);
+        }
+        reinterpret_cast<uint4*>(out)[g] = q;
+    }
+}
+extern "C" int pdhip_pack_bits(const uint8_t* in, long long n, uint64_t* out, void* stream) {
+    PD_REQUIRE(in && out && n > 0 && n % 64 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0, "pdhip_pack_bits: n must be a multiple of 64, input 16-byte aligned");
+    const long long groups = n / 16;
+    k_pack_bits16<<<(int)std::min<long long>((groups + 255) / 256, 4096), 256, 0, as_stream(stream)>>>(in, groups, reinterpret_cast<unsigned long long*>(out), nullptr, 0, nullptr);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
+}
+extern "C" int pdhip_unpack_bits(const uint64_t* in, long long n, uint8_t* out, void* stream) {
+    PD_REQUIRE(in && out && n > 0 && n % 64 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "pdhip_unpack_bits: n must be a multiple of 64, output 16-byte aligned");
+    const long long nwords = n / 64;
+    k_unpack_bits<<<(int)std::min<long long>((nwords * 4 + 255) / 256, 4096), 256, 0, as_stream(stream)>>>(reinterpret_cast<const unsigned long long*>(in), nwords, out);
+    PD_LAUNCH_CHECK();
+    return PDHIP_OK;
 }
 
 #define NBF_RB 32

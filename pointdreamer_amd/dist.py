@@ -5,7 +5,7 @@ Two partitionings, one process per GPU (torch.distributed; backend 'nccl' == RCC
   * view-parallel (this module): the V views of ONE shape are split across ranks.  A rank owns, for its views, everything that
     is per-view: P1-P6 (project / raster / visibility / sparse image), the DDNM inpainting (> 99 % of the time), Uq1-Uq2 (texel
     visibility) and N1-N3 (NBF shrink).  ONE all_gather then moves, per view, the inpainted image (3 r^2 f32), the raw and the
-    shrunk texel visibility (A^2 bytes each level) and four crop parameters; the cross-view part -- Uq3-Uq5 view selection,
+    shrunk texel visibility (A^2 BITS each level: 64-texel words) and four crop parameters; the cross-view part -- Uq3-Uq5 view selection,
     blend, dilation and the optional completion / optimisation stages -- runs replicated on every rank (34 P bytes of work),
     so every rank returns the full atlas and no second collective exists.
 The stage functions are injectable so the sharding / gather logic is testable on CPU with gloo."""
@@ -35,14 +35,54 @@ def all_gather_views(local, n_views, rank, world, group=None, force_collective=F
     return torch.cat(pieces, 0)
 
 
+def pack_bits(t):
+    """Boolean / 0-1 byte tensor [..., n] (n % 64 == 0) -> uint8 [..., n / 8], bit b of byte j = element 8 j + b (the 64-texel words of the
+    NBF kernels as a byte stream).  Device tensors go through pdhip_pack_bits; host tensors (the gloo tests of the gather logic, with injected
+    stages) through the same arithmetic in torch -- identical bytes."""
+    flat = t.reshape(-1).contiguous()
+    n = flat.numel()
+    assert n % 64 == 0, "bit-packed maps need a multiple of 64 texels"
+    if flat.is_cuda:
+        from . import _lib
+        src = flat.view(torch.uint8) if flat.dtype == torch.bool else flat.to(torch.uint8)
+        out = torch.empty((n // 8,), dtype=torch.uint8, device=flat.device)
+        _lib.check(_lib.lib().pdhip_pack_bits(_lib.ptr(src), n, _lib.ptr(out), _lib.stream()), 'pdhip_pack_bits')
+    else:
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32)
+        out = ((flat != 0).reshape(-1, 8).to(torch.int32) * w).sum(1).to(torch.uint8)
+    return out.reshape(tuple(t.shape[:-1]) + (t.shape[-1] // 8,))
+
+
+def unpack_bits(b, n):
+    """Inverse of pack_bits: uint8 [..., n / 8] -> bool [..., n]."""
+    flat = b.reshape(-1).contiguous()
+    total = flat.numel() * 8
+    if flat.is_cuda:
+        from . import _lib
+        out = torch.empty((total,), dtype=torch.uint8, device=flat.device)
+        _lib.check(_lib.lib().pdhip_unpack_bits(_lib.ptr(flat), total, _lib.ptr(out), _lib.stream()), 'pdhip_unpack_bits')
+        out = out.view(torch.bool)
+    else:
+        sh = torch.arange(8, dtype=torch.int32)
+        out = ((flat.to(torch.int32).unsqueeze(1) >> sh) & 1).reshape(-1).to(torch.bool)
+    return out.reshape(tuple(b.shape[:-1]) + (n,))
+
+
+def record_bytes(img_shape, A, K):
+    """Bytes of one view's record: image f32 + (1 + K) bit-packed A x A maps + four f32 crop parameters."""
+    return 4 * img_shape[0] * img_shape[1] * img_shape[2] + (1 + K) * (A * A // 8) + 16
+
+
 def pack_view_records(inpainted, vis, per_kernel, uv_centers, uv_scales, scale_factors):
-    """One byte record per view: [image f32 | visibility u8 | K shrunk levels u8 | centre x, centre y, scale, factor f32]."""
+    """One byte record per view: [image f32 | visibility, 1 bit per texel | K shrunk levels, 1 bit per texel | centre x, centre y, scale,
+    factor f32] -- SURVEY 8(e)'s payload: 786 KB + (1 + K) x 128 KiB per view at r = 256, A = 1024 (round 5 shipped the maps as bytes: 2.8 MB)."""
     v = inpainted.shape[0]
     dev = inpainted.device
+    A2 = vis.shape[-1] * vis.shape[-2]
     par = torch.cat([uv_centers.reshape(v, 2).float(), uv_scales.reshape(v, 1).float(), scale_factors.reshape(v, 1).float()], 1)
     parts = [inpainted.reshape(v, -1).float().contiguous().view(torch.uint8),
-             vis.reshape(v, -1).contiguous().view(torch.uint8),
-             per_kernel.permute(1, 0, 2, 3).reshape(v, -1).contiguous().view(torch.uint8),
+             pack_bits(vis.reshape(v, A2)),
+             pack_bits(per_kernel.permute(1, 0, 2, 3).reshape(v, -1, A2)).reshape(v, -1),
              par.contiguous().view(torch.uint8)]
     return torch.cat([p.to(dev) for p in parts], 1).contiguous()
 
@@ -52,10 +92,11 @@ def unpack_view_records(rec, img_shape, A, K):
     uv_centers [V,1,2], uv_scales [V,1,1], scale_factors [V])."""
     V = rec.shape[0]
     n_img = 4 * img_shape[0] * img_shape[1] * img_shape[2]
+    nb = A * A // 8
     o = 0
     img = rec[:, o:o + n_img].contiguous().view(torch.float32).reshape(V, *img_shape); o += n_img
-    vis = rec[:, o:o + A * A].contiguous().view(torch.bool).reshape(V, A, A); o += A * A
-    pk = rec[:, o:o + K * A * A].contiguous().view(torch.bool).reshape(V, K, A, A).permute(1, 0, 2, 3).contiguous(); o += K * A * A
+    vis = unpack_bits(rec[:, o:o + nb].contiguous(), A * A).reshape(V, A, A); o += nb
+    pk = unpack_bits(rec[:, o:o + K * nb].contiguous().reshape(V, K, nb), A * A).reshape(V, K, A, A).permute(1, 0, 2, 3).contiguous(); o += K * nb
     par = rec[:, o:o + 16].contiguous().view(torch.float32).reshape(V, 4)
     return img, vis, pk, par[:, 0:2].reshape(V, 1, 2).contiguous(), par[:, 2].reshape(V, 1, 1).contiguous(), par[:, 3].contiguous()
 

@@ -139,3 +139,24 @@ def test_all_gather_views_forced_collective_world1_gloo():
         assert torch.equal(out, rec) and out.data_ptr() != rec.data_ptr()
     finally:
         dist.destroy_process_group()
+
+
+def test_view_record_is_bit_packed():
+    """SURVEY 8(e) payload: image f32 + raw and K shrunk visibility maps at ONE BIT per texel + four crop parameters; pack / unpack are inverse
+    and the byte stream is the NBF kernels' 64-texel words (bit b of byte j = texel 8 j + b)."""
+    sys.path.insert(0, ROOT)
+    from pointdreamer_amd import dist as pdist
+    assert pdist.record_bytes((3, 256, 256), 1024, 1) == 786432 + 2 * 131072 + 16
+    assert 8 * pdist.record_bytes((3, 256, 256), 1024, 1) < 9e6           # 8.4 MB per shape (round 5: 23 MB with byte maps)
+    g = torch.Generator().manual_seed(0)
+    V, A, K, r = 3, 16, 2, 4
+    img = torch.randn((V, 3, r, r), generator=g)
+    vis = torch.rand((V, A, A), generator=g) > 0.4
+    pk = torch.rand((K, V, A, A), generator=g) > 0.6
+    uvc, uvs, sf = torch.rand((V, 1, 2), generator=g), torch.rand((V, 1, 1), generator=g) + 1, torch.rand((V,), generator=g)
+    rec = pdist.pack_view_records(img, vis, pk, uvc, uvs, sf)
+    assert rec.shape == (V, pdist.record_bytes((3, r, r), A, K)) and rec.dtype == torch.uint8
+    i2, v2, p2, c2, s2, f2 = pdist.unpack_view_records(rec, (3, r, r), A, K)
+    assert torch.equal(i2, img) and torch.equal(v2, vis) and torch.equal(p2, pk) and torch.equal(c2, uvc) and torch.equal(s2, uvs) and torch.equal(f2, sf)
+    b = pdist.pack_bits(torch.tensor([[1, 0, 0, 0, 0, 0, 0, 0, 0, 1] + [0] * 54], dtype=torch.uint8))
+    assert b.shape == (1, 8) and b[0, 0] == 1 and b[0, 1] == 2 and int(b[0, 2:].sum()) == 0

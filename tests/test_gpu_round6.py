@@ -258,3 +258,18 @@ def test_optimize_color_vs_reference_fixture(nn, name):
         assert np.abs(im.double().mean(dim=(2, 3)).cpu().numpy() - g['ref_images_mean']).max() <= 2e-3
     untouched = (g['ref_atlas'][0] == g['atlas0']).all(0)
     assert untouched.any() and np.array_equal(a.cpu().numpy()[0][:, untouched], g['atlas0'][:, untouched])
+
+
+def test_bit_packed_maps_device_equals_host(nn):
+    """pdhip_pack_bits / pdhip_unpack_bits (the view-parallel record's visibility maps): the device bytes equal the host arithmetic of
+    pointdreamer_amd.dist.pack_bits, unpack inverts pack, at the shipped size (8 views x 1024^2)."""
+    from pointdreamer_amd import dist as pdist
+    g = torch.Generator().manual_seed(1)
+    m = torch.rand((8, 1024 * 1024), generator=g) > 0.37
+    host = pdist.pack_bits(m)
+    dev = pdist.pack_bits(m.to(DEV))
+    assert dev.is_cuda and dev.shape == (8, 131072) and torch.equal(dev.cpu(), host)
+    back = pdist.unpack_bits(dev, 1024 * 1024)
+    assert back.dtype == torch.bool and torch.equal(back.cpu(), m)
+    m8 = (m.to(torch.uint8) * 7).to(DEV)                     # any non-zero byte is a set bit
+    assert torch.equal(pdist.pack_bits(m8).cpu(), host)
