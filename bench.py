@@ -581,6 +581,24 @@ def main():
                                                         "views (pdhip_*_shapes), hidden-point removal on)", value=3600.0 / ds8, ms_per_shape=ds8 * 1e3,
                                                  ms_per_shape_geometry_kept=dk8 * 1e3)
                 del st8
+                # the same with RAGGED meshes (configs[4] with real data: every shape its own mesh -- 8 820 ... 11 220 faces -- and chart mask;
+                # shapes.stack pads vertices / faces to the largest, the stages stay one launch each)
+                rg = []
+                for k, (st_, sl_) in enumerate(((45, 98), (50, 100), (47, 104), (52, 96), (49, 110), (55, 102), (46, 100), (51, 108))):
+                    sk = synthetic.make_shape(30000, A, stacks=st_, slices=sl_, seed=7100 + k, gutter=2 + (k % 3))
+                    rg.append(dict(coords=T(sk['points']), colors=T(sk['colors']), vertices=T(sk['vertices']), faces=T(sk['faces']), f_normals=T(sk['f_normals']),
+                                   xatlas=dict(gb_pos=T(sk['gb_pos']), mask=T(sk['mask']), per_atlas_pixel_face_id=T(sk['per_atlas_pixel_face_id']))))
+                assert shp.uniform(rg) and shp.ragged(rg)
+                runr = lambda: shp.colorize_shapes(shp.stack(rg), camera_info, V, RES, CAM_RES, **skw)
+                for _ in range(3):
+                    runr()
+                sync(); t1 = time.perf_counter()
+                for _ in range(30):
+                    runr()
+                sync(); dr8 = (time.perf_counter() - t1) / 30 / 8
+                extras['nearest_stacked']['ms_per_shape_ragged_meshes'] = dr8 * 1e3
+                extras['nearest_stacked']['ragged_faces'] = [int(x_['faces'].shape[0]) for x_ in rg]
+                del rg
             except Exception as e:                      # noqa: BLE001
                 extras['nearest_stacked'] = dict(error=str(e)[:200])
             one(cfg)

@@ -1,4 +1,5 @@
-"""BASELINE configs[4] (a batch of shapes per GPU), round 4: S independent shapes of EQUAL sizes through the texturing path with ONE
+"""BASELINE configs[4] (a batch of shapes per GPU), round 4: S independent shapes (equal cloud and atlas sizes; meshes of ANY sizes since round 6,
+padded by `stack`) through the texturing path with ONE
 launch per stage for all of them (`pdhip_*_shapes`, include/pdhip.h) instead of S launches (or S HIP graphs) per stage.
 
 Per-shape inputs are stacked: coords / colors [S,N,3], vertices [S,Vn,3], faces [S,F,3], f_normals [S,F,3], gb_pos [S,A,A,3],
@@ -22,9 +23,11 @@ _EYES = {}
 
 
 def uniform(shapes):
-    """Can these shape dicts (pipeline.colorize_meshes_batched) be stacked?  Equal tensor shapes throughout, every tensor of every shape
-    on the SAME device (the caller checks that it is a CUDA device), and atlas maps with the leading singleton dimension stack() indexes away (gb_pos [1, A, A, 3], mask
-    [1, A, A, 1], face ids [1, A, A]) -- anything else takes the per-shape route instead of failing inside torch.stack / [0]."""
+    """Can these shape dicts (pipeline.colorize_meshes_batched) be stacked?  Equal cloud size N and atlas size A, every tensor of every shape
+    on the SAME device (the caller checks that it is a CUDA device), and atlas maps with the leading singleton dimension stack() indexes away
+    (gb_pos [1, A, A, 3], mask [1, A, A, 1], face ids [1, A, A]).  The MESHES may differ in vertex and face count (round 6, BASELINE
+    configs[4]: real POCO meshes do): `stack` pads them -- see there.  Clouds of different sizes take the per-shape route (a padded point
+    would take part in the largest-index-wins splat)."""
     def sig(sh):
         x = sh['xatlas']
         ts = (sh['coords'], sh['colors'], sh['vertices'], sh['faces'], sh['f_normals'], x['gb_pos'], x['mask'], x['per_atlas_pixel_face_id'])
@@ -33,20 +36,42 @@ def uniform(shapes):
         if not (x['gb_pos'].dim() == 4 and x['mask'].dim() == 4 and x['per_atlas_pixel_face_id'].dim() == 3 and
                 x['gb_pos'].shape[0] == 1 and x['mask'].shape[0] == 1 and x['per_atlas_pixel_face_id'].shape[0] == 1):
             return None
-        return tuple((tuple(t.shape), t.device) for t in ts)
+        if not (sh['vertices'].dim() == 2 and sh['faces'].dim() == 2 and sh['f_normals'].shape == (sh['faces'].shape[0], 3) and
+                sh['vertices'].shape[0] >= 1 and sh['faces'].shape[0] >= 1):
+            return None
+        return tuple((tuple(t.shape), t.device) for t in (sh['coords'], sh['colors'], x['gb_pos'], x['mask'], x['per_atlas_pixel_face_id']))
     if len(shapes) < 1:
         return False
     s0 = sig(shapes[0])
     return s0 is not None and all(sig(sh) == s0 for sh in shapes[1:])
 
 
+def ragged(shapes):
+    """True when the meshes of a stackable batch differ in vertex or face count (the stacked tensors then carry padding)."""
+    return len({(sh['vertices'].shape[0], sh['faces'].shape[0]) for sh in shapes}) > 1
+
+
 def stack(shapes):
     """Shape dicts -> the stacked tensors `colorize_shapes` takes (one copy of every input; callers that texture many batches of the
-    same mesh / atlas keep the geometry part)."""
+    same mesh / atlas keep the geometry part).  Meshes of different sizes are padded to the largest: vertices with copies of the shape's
+    vertex 0 (the crop bounds of P1 are a min / max over the vertices: unchanged), faces with the degenerate triangle (0, 0, 0) (zero area:
+    culled by the rasteriser's set-up, never a face id), face normals with zeros (indexed by real face ids only) -- every per-shape result
+    stays bit-identical to colorize_one_mesh's (tested), at one launch per stage for the whole batch (the reference loops shape by shape:
+    demo.py:455-462)."""
+    vmax = max(sh['vertices'].shape[0] for sh in shapes)
+    fmax = max(sh['faces'].shape[0] for sh in shapes)
+
+    def pad_rows(t, n, fill_row):
+        if t.shape[0] == n:
+            return t
+        return torch.cat([t, fill_row.to(t.dtype).reshape(1, -1).expand(n - t.shape[0], -1)], 0)
     cat = lambda f: torch.stack([f(sh) for sh in shapes], 0).contiguous()
+    z3 = lambda t: torch.zeros((3,), dtype=t.dtype, device=t.device)
     return dict(coords=cat(lambda s: s['coords'].float()), colors=cat(lambda s: s['colors'].float()),
-                vertices=cat(lambda s: s['vertices'].float()), faces=cat(lambda s: s['faces'].to(torch.int32)),
-                f_normals=cat(lambda s: s['f_normals'].float()), gb_pos=cat(lambda s: s['xatlas']['gb_pos'][0].float()),
+                vertices=cat(lambda s: pad_rows(s['vertices'].float(), vmax, s['vertices'][0].float())),
+                faces=cat(lambda s: pad_rows(s['faces'].to(torch.int32), fmax, z3(s['faces'].to(torch.int32)))),
+                f_normals=cat(lambda s: pad_rows(s['f_normals'].float(), fmax, z3(s['f_normals'].float()))),
+                gb_pos=cat(lambda s: s['xatlas']['gb_pos'][0].float()),
                 mask=cat(lambda s: s['xatlas']['mask'][0]), face_id=cat(lambda s: s['xatlas']['per_atlas_pixel_face_id'][0].to(torch.int64)))
 
 
