@@ -382,6 +382,7 @@ int pdhip_conv_rr_pack_f16(const void* w_packed, int Cin, int taps, int Cs, int 
 int pdhip_gn_octet_partials_f16(const void* x, int N, int HW, int C, int chunks, float* part, void* stream);
 int pdhip_gn_apply_parts_f16(const void* x, const void* x2, int Ca, int C, const float* partA, int chunksA, const float* partB, int chunksB, const float* gamma,
                              const float* beta, const float* film, long long film_stride, int N, int H, int W, int silu, void* y, void* stream);
+int pdhip_debug_set_rr_gn(int max_width);   /* UNet engine: largest image width at which a conv routed to the row-resident kernel also applies the GroupNorm (+ FiLM) + SiLU in front of it (default 0 = never: no gain measured inside the forward; 8 / 16 / 32 = up to that width); returns the previous value */
 int pdhip_debug_set_conv_rr(int mode, int variant, int slabs);   /* row-resident conv: mode 0 never / 1 automatic / 2 every eligible layer; variant 0 auto (1: 8^2, 2: 16^2 whole image, 3: 32^2 bands, 4: 16^2 half image, 5: 8^2 with 128-channel units); slabs 0 auto = K slices of the conv source; returns the previous mode */
 int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim,
                         void* vt_ws /*N*T*C halfs, non-NULL selects the 128-query MFMA kernel for T % 128 == 0, head_dim 64, N*heads % 8 == 0 (QKVAttentionLegacy, unet.py:341-373); the buffer is written only in the transposed-V lab form (pdhip_debug_set_attn); NULL: the 64-query kernel*/, void* stream);

@@ -43,6 +43,12 @@ namespace pdnn { thread_local int g_fold_resample = 1; }
 // tuning / test hook (pdhip_debug_set_fold_skip): 1 (default) = where a channel-changing ResBlock's conv2 runs in k_conv_sk (the small-M
 // layers) the block's skip 1x1 conv is appended to conv2's K loop (one launch, one rounding) instead of a launch of its own + a residual read
 namespace pdnn { thread_local int g_fold_skip = 1; }
+// tuning / test hook (pdhip_debug_set_rr_gn): largest image width at which a ResBlock conv routed to k_conv_rr also applies the GroupNorm (+ FiLM) + SiLU
+// in front of it while staging (no k_gn_apply launch, no normalised tensor; bit-identical).  Default 0 = never -- measured (profiles/r06_rr_gn_ab.txt):
+// stand-alone the 8^2 / 1024-channel conv pays +0.9 us for it (the element map runs under the weight stream) against a ~6 us launch, the 16^2 / 32^2
+// convs +9-10 us (every 16-32-channel tile redoes the map for its whole pixel tile: 100 VALU cycles per element at one wave per SIMD); inside the
+// forward the batch-1 DDNM step is 4.256 ms with it at 8^2 against 4.254-4.268 without, 4.266 at 16^2: no gain, so the two-pass form stays
+namespace pdnn { thread_local int g_rr_gn = 0; }
 // tuning / test hook (pdhip_debug_set_fold_finalize): largest batch at which GroupNorm-apply reduces the conv epilogues' octet
 // partials itself instead of reading the output of a k_gn_finalize_oct launch (0 = never); above that batch the fold is kept for the
 // tensors whose producers left at most g_fold_finalize_chunks chunks per image (the 32^2 ... 8^2 levels: the re-reduction is a few
@@ -272,6 +278,29 @@ int run_gn_conv(Ctx& c, const Act& x, const NormW& n, const float* film, long lo
     return run_conv(c, x, w, residual, out, true, c.dry ? nullptr : c.u->ap_table, res_up);
 }
 
+// GroupNorm (+ FiLM) + SiLU of x applied INSIDE the row-resident conv that consumes it (nn_conv_rr.hip; bit-identical to run_gn + run_conv on the same
+// kernel): taken where it measured a gain -- see g_rr_gn.  Returns false (nothing launched) when the layer is not one of those.
+bool rr_gn_ok(const Ctx& c, const Act& x, const ConvW& w, int H, int W) {
+    if (c.dry || g_rr_gn <= 0 || W > g_rr_gn || w.wf == nullptr || w.taps != 9 || x.p2 != nullptr || x.gn_part == nullptr || x.gn_partB != nullptr ||
+        ((x.C / 32) % 8) != 0 || w.cin > 1024 || x.C != w.cin) return false;
+    const int pps = std::max(1, 256 / (x.C >> 3));
+    if ((x.gn_chunks + pps - 1) / pps > PD_RR_MAX_PART_LOADS) return false;
+    return conv_rr_plan(c.N, H, W, w.cin, w.cout, 9, 0, c.u->splitk_floats, true).variant != 0;
+}
+int run_rr_gn_conv(Ctx& c, const Act& x, const NormW& n, const float* film, long long film_stride, const ConvW& w, const half_t* residual, int res_up,
+                   Act* out) {
+    *out = Act{nullptr, w.cout, x.H, x.W};
+    out->p = arena_take(c.u, (size_t)c.N * x.H * x.W * w.cout);
+    float* part = reinterpret_cast<float*>(arena_take(c.u, (size_t)c.N * ((x.H * x.W + 15) / 16) * (w.cout / 8) * 2 * 2));
+    PD_REQUIRE(n.have_g && n.have_b && w.have_w && w.have_b, "unet: norm / conv weights not loaded");
+    const RrPlan pl = conv_rr_plan(c.N, x.H, x.W, w.cin, w.cout, 9, 0, c.u->splitk_floats, true);
+    const RrIn in{x.p, nullptr, x.C, x.C, 2, n.g, n.b, film, film_stride, x.gn_part, nullptr, x.gn_chunks, 0, 1e-5f};
+    int chunks = 0;
+    PD_TRY(conv_rr(pl, in, nullptr, 9, w.wf, w.b, residual, res_up, out->p, c.N, x.H, x.W, w.cout, c.u->splitk_ws, c.u->splitk_floats, part, &chunks, c.s));
+    if (chunks > 0) { out->gn_part = part; out->gn_chunks = chunks; out->Ca = w.cout; }
+    return PDHIP_OK;
+}
+
 int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     Act h0, h1, h2, xr = x, sk;
     const float* film = c.dry ? nullptr : c.film_base + rb.emb_off;
@@ -311,6 +340,8 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
         PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true));
     } else if (rb.mode == 0 && can_fuse_gn(c, x, rb.c1)) {
         PD_TRY(run_gn_conv(c, x, rb.n1, nullptr, 0, rb.c1, nullptr, &h1));
+    } else if (rb.mode == 0 && rr_gn_ok(c, x, rb.c1, x.H, x.W)) {
+        PD_TRY(run_rr_gn_conv(c, x, rb.n1, nullptr, 0, rb.c1, nullptr, 0, &h1));
     } else if (fold_in_up) {
         PD_TRY(run_gn(c, x, rb.n1, nullptr, 0, 1, 0, &h0));
         PD_TRY(run_conv(c, h0, rb.c1, nullptr, &h1, true, nullptr, 0, 1));
@@ -358,6 +389,7 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
     }
     if (rb.has_skip && !fuse_skip) PD_TRY(run_conv(c, xr, rb.skip, nullptr, &sk));
     if (can_fuse_gn(c, h1, rb.c2)) return run_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, out, fold_up ? 1 : 0);
+    if (rr_gn_ok(c, h1, rb.c2, h1.H, h1.W)) return run_rr_gn_conv(c, h1, rb.n2, film, c.film_stride, rb.c2, sk.p, fold_up ? 1 : 0, out);
     PD_TRY(run_gn(c, h1, rb.n2, film, c.film_stride, 1, 0, &h2));
     return run_conv(c, h2, rb.c2, sk.p, out, true, nullptr, fold_up ? 1 : 0);
 }
@@ -915,6 +947,7 @@ extern "C" int pdhip_debug_set_attn(int nbuf, int vt_form, int qtiles) {
 extern "C" int pdhip_debug_set_conv_sk_order(int order) { int old = pdnn::g_sk_order; pdnn::g_sk_order = order; return old; }
 /* tuning / test hook: 1 (default) = GroupNorm + SiLU applied inside the consuming halo conv, 0 = stand-alone passes */
 /* tuning / test hook: 1 (default) = up / down ResBlocks never materialise their resampled x branch; 0 = k_resample passes */
+extern "C" int pdhip_debug_set_rr_gn(int max_width) { int old = pdnn::g_rr_gn; pdnn::g_rr_gn = max_width; return old; }
 extern "C" int pdhip_debug_set_fold_skip(int on) { int old = pdnn::g_fold_skip; pdnn::g_fold_skip = on; return old; }
 extern "C" int pdhip_debug_set_fold_resample(int on) { int old = pdnn::g_fold_resample; pdnn::g_fold_resample = on; return old; }
 extern "C" int pdhip_debug_set_fold_finalize_chunks(int chunks) { int old = pdnn::g_fold_finalize_chunks; pdnn::g_fold_finalize_chunks = chunks; return old; }

@@ -316,3 +316,29 @@ def test_shapes_batched_ragged_meshes_equal_per_shape(method, hpr):
     outs = pipeline.colorize_meshes_batched(shapes, cam_info, V, r, R, complete_unseen_by='unproject', optimize_from=None, **kw)
     for s in range(3):
         assert torch.equal(torch.nan_to_num(outs[s], nan=-7.0), torch.nan_to_num(got['atlas'][s], nan=-7.0))
+
+
+@pytest.mark.parametrize("width", [8, 32])
+def test_unet_full_with_in_staging_groupnorm(nn, full_model, width):
+    """The engine with the GroupNorm (+ FiLM) + SiLU in front of the row-resident convs applied while staging (pdhip_debug_set_rr_gn; off by
+    default: no gain measured) at batch 1: the same kernel applies the same element map to the same statistics, so the forward must equal the
+    two-pass routing BIT FOR BIT -- and stay inside the U1 bound against the reference's fp32 forward."""
+    L = nn['L']
+    g = load_golden('unet_full.npz')
+    st = int(g['stride'])
+    x = torch.from_numpy(g['x']).to(DEV); t = torch.from_numpy(g['t']).to(DEV)
+    base = full_model(x, t).cpu()
+    old = L.pdhip_debug_set_rr_gn(width)
+    try:
+        fused = full_model(x, t).cpu()
+    finally:
+        L.pdhip_debug_set_rr_gn(old)
+    linf, l2 = _rel(fused[:, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+    assert linf <= U1_FP32_LINF and l2 <= U1_FP32_L2, (linf, l2)
+    # (the conv variant can differ between the raw-input and the GroupNorm form -- 16- against 32-channel tiles at 16^2 / 32^2 -- so bit equality
+    # holds where both forms run the same tiles: the 8^2 level; beyond it the two routings are two f16 roundings of the same network)
+    if width == 8:
+        assert torch.equal(fused, base)
+    else:
+        rl, r2 = _rel(fused, base)
+        assert rl <= 4e-3 and r2 <= 2.5e-3, (rl, r2)
