@@ -194,6 +194,10 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
         int npv = 0;
         half8 av[UP];
         half8 wf[JW][UT][NF];
+        // DBW (the variants with few fragment registers): the NEXT unit's fragments are requested into a shadow set before the MFMAs of this unit and
+        // copied over behind them (36 v_mov against ~2 000 cycles of exposed L2 latency per unit when they were requested after the MFMAs)
+        constexpr bool DBW = JW * UT * NF * 4 <= 40;
+        half8 wf2[DBW ? JW : 1][DBW ? UT : 1][DBW ? NF : 1];
 
         // statistics inputs of unit u (in-order vmcnt: they are requested BEFORE the unit's other loads, which may still fly when these are needed)
         auto issue_stats = [&](int u) {
@@ -252,7 +256,8 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
         };
         // the wave's weight fragments of the unit: K-steps (32-channel step j, tap t), all NF channel fragments -- one coalesced 1 KiB buffer
         // load each, lane offset in the VGPR, everything else in the SGPR
-        auto issue_w = [&](int u) {
+        auto issue_w = [&](int u, auto shadow_tag) {
+            constexpr bool SH = decltype(shadow_tag)::value;
             const int c0 = (unit0 + u) * CS;
             const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wf), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
@@ -262,14 +267,16 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
 #pragma unroll
                 for (int t = 0; t < UT; ++t)
 #pragma unroll
-                    for (int f = 0; f < NF; ++f)
-                        wf[jw][t][f] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (((n0 >> 4) + f) * a.KS + ks + t) * 1024, RR_W_AUX));
+                    for (int f = 0; f < NF; ++f) {
+                        const half8 v = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane * 16, (((n0 >> 4) + f) * a.KS + ks + t) * 1024, RR_W_AUX));
+                        if constexpr (SH) wf2[jw][t][f] = v; else wf[jw][t][f] = v;
+                    }
             }
         };
 
         if (sgn) issue_stats(0);
         issue_act(0);
-        issue_w(0);
+        issue_w(0, std::false_type{});
         RR_STAMP(1);
 #pragma unroll 1
         for (int u = 0; u < units; ++u) {
@@ -341,6 +348,7 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
             if (u + 1 < units) {
                 if (sgn) issue_stats(u + 1);
                 issue_act(u + 1);
+                if constexpr (DBW) issue_w(u + 1, std::true_type{});
             }
             rr_sync();
             RR_STAMP(4);
@@ -368,7 +376,18 @@ __global__ __launch_bounds__(256) void k_conv_rr(const RrArgs a) {
                     __builtin_amdgcn_sched_barrier(0);     // pin the order: read r + PD, then the MFMAs of item r
                 });
             }
-            if (u + 1 < units) issue_w(u + 1);             // (the fragment registers are free again)
+            if (u + 1 < units) {
+                if constexpr (DBW) {
+#pragma unroll
+                    for (int jw = 0; jw < JW; ++jw)
+#pragma unroll
+                        for (int t = 0; t < UT; ++t)
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) wf[jw][t][f] = wf2[jw][t][f];
+                } else {
+                    issue_w(u + 1, std::false_type{});        // (the fragment registers are free again)
+                }
+            }
             RR_STAMP(5);
         }
     };
