@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
-timeout 900 python -m pytest tests/test_gpu_round6.py -x -q > gpurun_out/r06/t_rr.log 2>&1; grep -n "passed\|failed" gpurun_out/r06/t_rr.log | tail -2
-timeout 900 python tools/bench_rr.py --shapes 3 5 7 8 10 --variants 0 --slabs 0 --no-gn > gpurun_out/r06/bench_rr_dbw.txt 2>&1; cat gpurun_out/r06/bench_rr_dbw.txt
-for rr in 0 1 0 1; do
-python tools/time_unet.py --rr $rr --batches 1 2 --iters 20 --sampler-steps 20 --out gpurun_out/r06/unet_latency_rr$rr.json > gpurun_out/r06/unet_latency_rr$rr.log 2>&1
-echo "rr=$rr"; grep -h batch gpurun_out/r06/unet_latency_rr$rr.log | tail -2 | cut -c1-120
-done > gpurun_out/r06/rr_ab2.txt 2>&1; cat gpurun_out/r06/rr_ab2.txt
+timeout 900 python tools/pmc_run.py gpurun_out/r06/pmc_attn.json --filter k_attention_t64 --sets sq lds misc -- python $GRAFT_REPO_ROOT/tools/bench_attn.py --iters 10 > gpurun_out/r06/pmc_attn.log 2>&1; tail -3 gpurun_out/r06/pmc_attn.log; python -c "
+import json; d=json.load(open('gpurun_out/r06/pmc_attn.json'))['kernels']
+for k,v in d.items(): print(k, {a:b for a,b in v.items() if 'frac' in a or 'util' in a or a in ('SQ_INSTS_VALU','SQ_INSTS_MFMA','SQ_INSTS_LDS','SQ_INSTS_SALU','SQ_WAVES','launches')})
+"
