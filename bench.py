@@ -610,6 +610,27 @@ def main():
             d1 = float(np.median(d1s))
             extras['ddnm_one_shape'] = dict(metric="seconds per shape, configs[2] with one shape per step (UNet batch 8); median of 3", seconds=d1,
                                             samples=d1s, value=3600.0 / d1)
+            # view-parallel PROJECTION from this GPU's own latencies (configs[3] cannot be measured on one GPU): a rank of an 8-GPU run
+            # inpaints ONE view (UNet batch 1), of a 4- / 2-GPU run two / four -- 20 sampler steps each, timed here; everything that is
+            # not the sampler (per-view geometry, the all-gather, the replicated blend) is taken from the one-shape run above
+            try:
+                ng = args.ddnm_steps
+                vp = {}
+                g_ = torch.Generator(device='cpu').manual_seed(3)
+                for gpus, b in ((8, 1), (4, 2), (2, 4), (1, 8)):
+                    im = torch.rand((b, 3, RES, RES), generator=g_).to(dev); mk = (torch.rand((b, RES, RES), generator=g_) > 0.5).float().to(dev)
+                    inpainter.inpaint_views(im * mk[:, None], mk, n_steps=3)
+                    sync(); t1 = time.perf_counter()
+                    inpainter.inpaint_views(im * mk[:, None], mk, n_steps=20)
+                    sync(); vp[gpus] = (time.perf_counter() - t1) / 20
+                rest = max(d1 - ng * vp[1], 0.0)                       # one-shape time that is not the batch-8 sampler
+                extras['view_parallel_projection'] = dict(
+                    metric="configs[3] projected from single-GPU latencies: one-shape seconds / (ddnm_steps x sampler step at V / G views per rank + the "
+                           "non-sampler rest of a shape); NOT a measurement of N > 1 hardware",
+                    sampler_step_ms={f"batch_{8 // k_}": v_ * 1e3 for k_, v_ in vp.items()}, non_sampler_seconds=rest,
+                    projected_speedup={f"{k_}_gpus": d1 / (ng * v_ + rest) for k_, v_ in vp.items() if k_ > 1})
+            except Exception as e:                      # noqa: BLE001
+                extras['view_parallel_projection'] = dict(error=str(e)[:200])
         # the north_star's scaling claim (configs[3]): ONE shape, its 8 views sharded over the ranks, one RCCL all_gather -- run after the
         # timed region on every rank, next to the same shape on rank 0 alone (UNet batch 8), so the line carries the speed-up itself
         if world > 1 and args.parallel == 'shapes' and not args.no_extras and world <= V:
