@@ -38,7 +38,7 @@ __device__ __forceinline__ void rr_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n
 // as eight gn_elem calls (bit-identical), but written so that the eight dependency chains advance TOGETHER.  Called element by element
 // the opaque `asm("" : "+v"(f))` statements of gn_round_f16 -- which keep hipcc from fusing an op with the f16 rounding behind it -- stay in
 // program order, i.e. one element's whole chain (14 dependent VALU ops, two of them transcendental) ran before the next one started:
-// ~200 cycles per element at one wave per SIMD (12 us of a 16^2 conv).  SiLU by a select, not a branch.
+// ~200 cycles per element at one wave per SIMD (12 us of a 16^2 conv).
 template <bool FILM>
 __device__ __forceinline__ void rr_gn_vec8(half8& hv, const float (&ga)[8], const float (&gb)[8], const float (&t1)[8], const float (&sh)[8], bool silu) {
     float f[8], g[8];
@@ -54,9 +54,13 @@ __device__ __forceinline__ void rr_gn_vec8(half8& hv, const float (&ga)[8], cons
         RR_ALL(asm("" : "+v"(f[e])))
         RR_ALL(f[e] = (float)(half_t)f[e])
     }
-    RR_ALL(g[e] = silu_f(f[e]))
-    RR_ALL(asm("" : "+v"(g[e])))
-    RR_ALL(hv[e] = silu ? (half_t)g[e] : (half_t)f[e])
+    if (silu) {                                            // (wave-uniform: GroupNorm without SiLU -- the attention norm -- skips the two transcendentals)
+        RR_ALL(g[e] = silu_f(f[e]))
+        RR_ALL(asm("" : "+v"(g[e])))
+        RR_ALL(hv[e] = (half_t)g[e])
+    } else {
+        RR_ALL(hv[e] = (half_t)f[e])
+    }
 #undef RR_ALL
 }
 

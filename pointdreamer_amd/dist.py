@@ -36,36 +36,31 @@ def all_gather_views(local, n_views, rank, world, group=None, force_collective=F
 
 
 def pack_bits(t):
-    """Boolean / 0-1 byte tensor [..., n] (n % 64 == 0) -> uint8 [..., n / 8], bit b of byte j = element 8 j + b (the 64-texel words of the
-    NBF kernels as a byte stream).  Device tensors go through pdhip_pack_bits; host tensors (the gloo tests of the gather logic, with injected
-    stages) through the same arithmetic in torch -- identical bytes."""
+    """Boolean / 0-1 byte DEVICE tensor [..., n] (n % 64 == 0) -> uint8 [..., n / 8], bit b of byte j = element 8 j + b (the 64-texel words of
+    the NBF kernels as a byte stream): pdhip_pack_bits.  (The gloo tests of the gather logic run with injected host stages and inject their own
+    host packer with them -- `stages['pack_bits']` / `stages['unpack_bits']`; nothing here computes on the CPU.)"""
+    from . import _lib
     flat = t.reshape(-1).contiguous()
     n = flat.numel()
+    if not flat.is_cuda:
+        raise _lib.PdhipError("dist.pack_bits packs device tensors (pdhip_pack_bits); host-side callers inject stages['pack_bits']")
     assert n % 64 == 0, "bit-packed maps need a multiple of 64 texels"
-    if flat.is_cuda:
-        from . import _lib
-        src = flat.view(torch.uint8) if flat.dtype == torch.bool else flat.to(torch.uint8)
-        out = torch.empty((n // 8,), dtype=torch.uint8, device=flat.device)
-        _lib.check(_lib.lib().pdhip_pack_bits(_lib.ptr(src), n, _lib.ptr(out), _lib.stream()), 'pdhip_pack_bits')
-    else:
-        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32)
-        out = ((flat != 0).reshape(-1, 8).to(torch.int32) * w).sum(1).to(torch.uint8)
+    src = flat.view(torch.uint8) if flat.dtype == torch.bool else flat.to(torch.uint8)
+    out = torch.empty((n // 8,), dtype=torch.uint8, device=flat.device)
+    _lib.check(_lib.lib().pdhip_pack_bits(_lib.ptr(src), n, _lib.ptr(out), _lib.stream()), 'pdhip_pack_bits')
     return out.reshape(tuple(t.shape[:-1]) + (t.shape[-1] // 8,))
 
 
 def unpack_bits(b, n):
-    """Inverse of pack_bits: uint8 [..., n / 8] -> bool [..., n]."""
+    """Inverse of pack_bits: uint8 device tensor [..., n / 8] -> bool [..., n] (pdhip_unpack_bits)."""
+    from . import _lib
     flat = b.reshape(-1).contiguous()
+    if not flat.is_cuda:
+        raise _lib.PdhipError("dist.unpack_bits unpacks device tensors (pdhip_unpack_bits); host-side callers inject stages['unpack_bits']")
     total = flat.numel() * 8
-    if flat.is_cuda:
-        from . import _lib
-        out = torch.empty((total,), dtype=torch.uint8, device=flat.device)
-        _lib.check(_lib.lib().pdhip_unpack_bits(_lib.ptr(flat), total, _lib.ptr(out), _lib.stream()), 'pdhip_unpack_bits')
-        out = out.view(torch.bool)
-    else:
-        sh = torch.arange(8, dtype=torch.int32)
-        out = ((flat.to(torch.int32).unsqueeze(1) >> sh) & 1).reshape(-1).to(torch.bool)
-    return out.reshape(tuple(b.shape[:-1]) + (n,))
+    out = torch.empty((total,), dtype=torch.uint8, device=flat.device)
+    _lib.check(_lib.lib().pdhip_unpack_bits(_lib.ptr(flat), total, _lib.ptr(out), _lib.stream()), 'pdhip_unpack_bits')
+    return out.view(torch.bool).reshape(tuple(b.shape[:-1]) + (n,))
 
 
 def record_bytes(img_shape, A, K):
@@ -73,30 +68,32 @@ def record_bytes(img_shape, A, K):
     return 4 * img_shape[0] * img_shape[1] * img_shape[2] + (1 + K) * (A * A // 8) + 16
 
 
-def pack_view_records(inpainted, vis, per_kernel, uv_centers, uv_scales, scale_factors):
+def pack_view_records(inpainted, vis, per_kernel, uv_centers, uv_scales, scale_factors, pack=None):
     """One byte record per view: [image f32 | visibility, 1 bit per texel | K shrunk levels, 1 bit per texel | centre x, centre y, scale,
     factor f32] -- SURVEY 8(e)'s payload: 786 KB + (1 + K) x 128 KiB per view at r = 256, A = 1024 (round 5 shipped the maps as bytes: 2.8 MB)."""
+    pack = pack or pack_bits
     v = inpainted.shape[0]
     dev = inpainted.device
     A2 = vis.shape[-1] * vis.shape[-2]
     par = torch.cat([uv_centers.reshape(v, 2).float(), uv_scales.reshape(v, 1).float(), scale_factors.reshape(v, 1).float()], 1)
     parts = [inpainted.reshape(v, -1).float().contiguous().view(torch.uint8),
-             pack_bits(vis.reshape(v, A2)),
-             pack_bits(per_kernel.permute(1, 0, 2, 3).reshape(v, -1, A2)).reshape(v, -1),
+             pack(vis.reshape(v, A2)),
+             pack(per_kernel.permute(1, 0, 2, 3).reshape(v, -1, A2)).reshape(v, -1),
              par.contiguous().view(torch.uint8)]
     return torch.cat([p.to(dev) for p in parts], 1).contiguous()
 
 
-def unpack_view_records(rec, img_shape, A, K):
+def unpack_view_records(rec, img_shape, A, K, unpack=None):
     """Inverse of pack_view_records for all V views: (inpainted [V,3,r,r], vis [V,A,A] bool, per_kernel [K,V,A,A] bool,
     uv_centers [V,1,2], uv_scales [V,1,1], scale_factors [V])."""
+    unpack = unpack or unpack_bits
     V = rec.shape[0]
     n_img = 4 * img_shape[0] * img_shape[1] * img_shape[2]
     nb = A * A // 8
     o = 0
     img = rec[:, o:o + n_img].contiguous().view(torch.float32).reshape(V, *img_shape); o += n_img
-    vis = unpack_bits(rec[:, o:o + nb].contiguous(), A * A).reshape(V, A, A); o += nb
-    pk = unpack_bits(rec[:, o:o + K * nb].contiguous().reshape(V, K, nb), A * A).reshape(V, K, A, A).permute(1, 0, 2, 3).contiguous(); o += K * nb
+    vis = unpack(rec[:, o:o + nb].contiguous(), A * A).reshape(V, A, A); o += nb
+    pk = unpack(rec[:, o:o + K * nb].contiguous().reshape(V, K, nb), A * A).reshape(V, K, A, A).permute(1, 0, 2, 3).contiguous(); o += K * nb
     par = rec[:, o:o + 16].contiguous().view(torch.float32).reshape(V, 4)
     return img, vis, pk, par[:, 0:2].reshape(V, 1, 2).contiguous(), par[:, 2].reshape(V, 1, 1).contiguous(), par[:, 3].contiguous()
 
@@ -178,9 +175,9 @@ def colorize_one_mesh_view_parallel(coords, colors, vertices, faces, f_normals, 
         uvc = pre['uv_centers'] if torch.is_tensor(pre['uv_centers']) else torch.full((v, 1, 2), float(pre['uv_centers'] or 0.0), device=dev)
         uvs = pre['uv_scales'] if torch.is_tensor(pre['uv_scales']) else torch.full((v, 1, 1), float(pre['uv_scales'] or 2.0), device=dev)
         sf = pre['scale_factors'] if torch.is_tensor(pre['scale_factors']) else torch.ones((v,), device=dev)
-        rec = pack_view_records(local, vis_l, pk_l, uvc, uvs, sf)
+        rec = pack_view_records(local, vis_l, pk_l, uvc, uvs, sf, pack=st.get('pack_bits'))
         rec = all_gather_views(rec, view_num, rank, world, group, **({'force_collective': True} if force_collective else {}))  # the one collective
-        inpainted, vis, per_kernel, uvc_a, uvs_a, sf_a = unpack_view_records(rec, tuple(local.shape[1:]), A, K)
+        inpainted, vis, per_kernel, uvc_a, uvs_a, sf_a = unpack_view_records(rec, tuple(local.shape[1:]), A, K, unpack=st.get('unpack_bits'))
         pre_all = dict(uv_centers=uvc_a, uv_scales=uvs_a, padding=pre['padding'], scale_factors=sf_a, mesh_depths=None)
         atlas = st['after'](pre_all, inpainted, vis, per_kernel, vertices, faces, f_normals, xatlas_dict, camera_info, res, cam_res,
                             edge_dilate_kernels, complete_unseen_by, optimize_from)

@@ -21,6 +21,21 @@ def _free_port():
     return p
 
 
+def host_pack_bits(t):
+    """The byte stream pdhip_pack_bits produces (bit b of byte j = element 8 j + b), in torch on the host: injected with the host stages of the
+    gloo tests (the product's own packer is the HIP kernel and refuses host tensors)."""
+    flat = t.reshape(-1)
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32)
+    out = ((flat != 0).reshape(-1, 8).to(torch.int32) * w).sum(1).to(torch.uint8)
+    return out.reshape(tuple(t.shape[:-1]) + (t.shape[-1] // 8,))
+
+
+def host_unpack_bits(b, n):
+    sh = torch.arange(8, dtype=torch.int32)
+    out = ((b.reshape(-1).to(torch.int32).unsqueeze(1) >> sh) & 1).reshape(-1).to(torch.bool)
+    return out.reshape(tuple(b.shape[:-1]) + (n,))
+
+
 def _worker(rank, world, port, n_views, ret):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -72,7 +87,7 @@ def _worker(rank, world, port, n_views, ret):
             None, None, None, None, None, dict(gb_pos=None, mask=torch.zeros((1, A, A, 1)), per_atlas_pixel_face_id=None),
             dict(cams=list(range(n_views)), base_dirs=None, eye_positions=None), n_views, r, 8, rank, world, shape_key=3,
             refine_point_validation_by_remove_abnormal_depth=True, refine_res=256,
-            stages=dict(before=before, inpaint=inpaint, visibility=visibility, after=after))
+            stages=dict(before=before, inpaint=inpaint, visibility=visibility, after=after, pack_bits=host_pack_bits, unpack_bits=host_unpack_bits))
         expect = (full * 2.0 + 1.0).sum(0).permute(1, 2, 0)
         assert torch.equal(atlas, expect), "every rank must hold the full atlas built from all views"
         assert calls['inpaint'] == (len(mine), 3 * n_views + mine.start, n_views), \
@@ -154,9 +169,11 @@ def test_view_record_is_bit_packed():
     vis = torch.rand((V, A, A), generator=g) > 0.4
     pk = torch.rand((K, V, A, A), generator=g) > 0.6
     uvc, uvs, sf = torch.rand((V, 1, 2), generator=g), torch.rand((V, 1, 1), generator=g) + 1, torch.rand((V,), generator=g)
-    rec = pdist.pack_view_records(img, vis, pk, uvc, uvs, sf)
+    rec = pdist.pack_view_records(img, vis, pk, uvc, uvs, sf, pack=host_pack_bits)
     assert rec.shape == (V, pdist.record_bytes((3, r, r), A, K)) and rec.dtype == torch.uint8
-    i2, v2, p2, c2, s2, f2 = pdist.unpack_view_records(rec, (3, r, r), A, K)
+    i2, v2, p2, c2, s2, f2 = pdist.unpack_view_records(rec, (3, r, r), A, K, unpack=host_unpack_bits)
     assert torch.equal(i2, img) and torch.equal(v2, vis) and torch.equal(p2, pk) and torch.equal(c2, uvc) and torch.equal(s2, uvs) and torch.equal(f2, sf)
-    b = pdist.pack_bits(torch.tensor([[1, 0, 0, 0, 0, 0, 0, 0, 0, 1] + [0] * 54], dtype=torch.uint8))
+    b = host_pack_bits(torch.tensor([[1, 0, 0, 0, 0, 0, 0, 0, 0, 1] + [0] * 54], dtype=torch.uint8))
+    with pytest.raises(Exception):
+        pdist.pack_bits(torch.zeros((1, 64), dtype=torch.uint8))      # the product packer is the HIP kernel: host tensors are refused, not packed on the CPU
     assert b.shape == (1, 8) and b[0, 0] == 1 and b[0, 1] == 2 and int(b[0, 2:].sum()) == 0

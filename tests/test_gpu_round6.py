@@ -269,7 +269,8 @@ def test_bit_packed_maps_device_equals_host(nn):
     from pointdreamer_amd import dist as pdist
     g = torch.Generator().manual_seed(1)
     m = torch.rand((8, 1024 * 1024), generator=g) > 0.37
-    host = pdist.pack_bits(m)
+    w8 = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32)
+    host = (m.reshape(-1, 8).to(torch.int32) * w8).sum(1).to(torch.uint8).reshape(8, 131072)      # bit b of byte j = element 8 j + b
     dev = pdist.pack_bits(m.to(DEV))
     assert dev.is_cuda and dev.shape == (8, 131072) and torch.equal(dev.cpu(), host)
     back = pdist.unpack_bits(dev, 1024 * 1024)

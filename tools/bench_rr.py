@@ -22,9 +22,15 @@ ap.add_argument('--iters', type=int, default=40)
 ap.add_argument('--fixed', action='store_true')
 ap.add_argument('--no-gn', action='store_true', help='raw input (gn mode 0): the conv alone')
 ap.add_argument('--no-old', action='store_true')
+ap.add_argument('--taps', type=int, default=9, help='1: the 1x1 convs (qkv / proj shapes via --shape)')
+ap.add_argument('--gn-mode', type=int, default=2, help='1 = GroupNorm without SiLU (attention norm), 2 = with SiLU')
+ap.add_argument('--shape', type=int, nargs=4, action='append', default=None, metavar=('H', 'CIN', 'COUT', 'CS'))
 ap.add_argument('--lib', default=None)
 ap.add_argument('--stamps', action='store_true', help='lab stamp build (tools/lab_unit.sh NAME nn_conv_rr -DPD_LAB_RR_STAMP): per-phase cycles of wave 0, median over the workgroups')
 a = ap.parse_args()
+if a.shape:
+    SHAPES = [tuple(x) for x in a.shape]; a.shapes = None
+TAPS = a.taps
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib)
     os.environ['PDHIP_ALLOW_LAB_BUILD'] = '1'
@@ -52,7 +58,7 @@ for si, (H, Cin, Cout, Cs) in enumerate(SHAPES):
         continue
     for N in a.batches:
         W = H
-        K = 9 * Cin + Cs
+        K = TAPS * Cin + Cs
         pad = (Cout + 127) // 128 * 128
         wbytes = Cout * K * 2
         nb = 1 if a.fixed else max(2, int(400e6 // wbytes) + 1)
@@ -65,8 +71,8 @@ for si, (H, Cin, Cout, Cs) in enumerate(SHAPES):
         wps = [(torch.randn((pad, K), device=dev) * 0.02).half() for _ in range(nb)]
         wfs = []
         for wp in wps:
-            wf = torch.empty((L.pdhip_conv_rr_weight_halfs(Cin, 9, Cs, Cout),), dtype=torch.float16, device=dev)
-            assert L.pdhip_conv_rr_pack_f16(P(wp), Cin, 9, Cs, Cout, P(wf), S()) == 0, L.pdhip_last_error()
+            wf = torch.empty((L.pdhip_conv_rr_weight_halfs(Cin, TAPS, Cs, Cout),), dtype=torch.float16, device=dev)
+            assert L.pdhip_conv_rr_pack_f16(P(wp), Cin, TAPS, Cs, Cout, P(wf), S()) == 0, L.pdhip_last_error()
             wfs.append(wf)
         b = torch.zeros(Cout, device=dev)
         y = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev)
@@ -74,16 +80,16 @@ for si, (H, Cin, Cout, Cs) in enumerate(SHAPES):
         gp = torch.empty((N * 16 * (Cout // 8) * 2,), device=dev)
         ch = C.c_int(0)
         fl = 2.0 * N * H * W * Cout * K
-        gn = 0 if a.no_gn else 2
+        gn = 0 if a.no_gn else a.gn_mode
         line = f"N{N} {H}x{W} Cin{Cin} Cout{Cout} skip{Cs}  {fl/1e9:6.1f} GFLOP  weights {wbytes/1e6:5.1f} MB x{nb}"
         if not a.no_old and Cs == 0:
             L.pdhip_debug_set_conv_splitk(P(ws), ws.numel(), 0)
-            wold = [w_[:, :9 * Cin].contiguous() for w_ in wps]
+            wold = [w_[:, :TAPS * Cin].contiguous() for w_ in wps]
 
             def old(i):
                 if gn:
-                    L.pdhip_gn_apply_parts_f16(P(x), None, Cin, Cin, P(part), 1, None, 0, P(gamma), P(beta), P(film), 2 * Cin, N, H, W, 1, P(h), S())
-                rc = L.pdhip_conv2d_nhwc_f16(P(h if gn else x), P(wold[i % nb]), P(b), None, P(y), N, H, W, Cin, Cout, pad, 9, P(zp), S())
+                    L.pdhip_gn_apply_parts_f16(P(x), None, Cin, Cin, P(part), 1, None, 0, P(gamma), P(beta), P(film) if gn == 2 else None, 2 * Cin, N, H, W, 1 if gn == 2 else 0, P(h), S())
+                rc = L.pdhip_conv2d_nhwc_f16(P(h if gn else x), P(wold[i % nb]), P(b), None, P(y), N, H, W, Cin, Cout, pad, TAPS, P(zp), S())
                 assert rc == 0, L.pdhip_last_error()
             prev = L.pdhip_debug_set_conv_rr(0, 0, 0)
             t_old = timeit(old, a.iters)
@@ -98,7 +104,7 @@ for si, (H, Cin, Cout, Cs) in enumerate(SHAPES):
                 L.pdhip_debug_set_conv_rr(2, v, sl)
 
                 def new(i):
-                    rc = L.pdhip_conv_rr_f16(P(x), None, Cin, Cin, gn, P(gamma), P(beta), P(film), 2 * Cin, P(part), 1, None, 0, P(xs), None, Cs, Cs, 9,
+                    rc = L.pdhip_conv_rr_f16(P(x), None, Cin, Cin, gn, P(gamma), P(beta), P(film) if gn == 2 else None, 2 * Cin, P(part), 1, None, 0, P(xs), None, Cs, Cs, TAPS,
                                              P(wfs[i % nb]), P(b), None, 0, P(y), N, H, W, Cout, P(ws), ws.numel(), P(gp), C.byref(ch), S())
                     return rc
                 if new(0) != 0:
