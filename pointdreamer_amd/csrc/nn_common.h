@@ -51,7 +51,7 @@ int conv_sk(const SkPlan& pl, const half_t* X, const half_t* Wt, const float* bi
             int Cin, int Cout, int Cout_pad, int taps, const half_t* zero_page, hipStream_t s, float* ws, size_t ws_floats, float* gn_part,
             int* gn_fused, const half_t* X2, int Cin1, int res_up = 0);      // res_up: residual = half-resolution tensor read with nearest x2
 // conv_igemm's routing decision for a single-source layer without input transform: does it go to k_conv_sk? (nn_gemm.hip)
-bool conv_routes_sk(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats);
+bool conv_routes_small(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats);
 extern thread_local int g_sk_mode, g_sk_tile, g_sk_splits, g_sk_stages, g_sk_kg, g_sk_order;                         // tuning / test hooks (pdhip_debug_set_conv_sk)
 #define PD_SK_TICKET_FLOATS 4096
 // combine per-(chunk, channel-octet) partial sums written by the conv epilogue ([N][chunks][C/8][2]) of one tensor, or of
@@ -77,6 +77,12 @@ int conv_rr(const RrPlan& pl, const RrIn& in, const RrIn* skip, int taps, const 
             half_t* Y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, float* gn_part, int* gn_chunks, hipStream_t s);
 extern thread_local int g_rr_mode, g_rr_variant, g_rr_slabs;            // tuning / test hooks (pdhip_debug_set_conv_rr)
 #define PD_RR_MAX_PART_LOADS 8    // octet-partial loads per thread of the in-kernel statistics: chunks / slots of a source must not exceed it
+
+// ---- 3x3 conv on 256-pixel x 64-channel halo tiles, K unsplit (nn_conv_ht.hip): the 64^2 / 128^2 levels at batch 1-2
+bool conv_ht_routes(int N, int H, int W, int Cin, int Cout, int Cout_pad);
+int conv_ht(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W, int Cin, int Cout,
+            int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_chunks, int res_up);
+extern thread_local int g_ht_mode;
 
 // ---- the GroupNorm (+ FiLM) (+ SiLU) element map (nn_norm.hip's k_gn_apply and nn_conv_rr.hip's staging: ONE definition, bit-identical results)
 // x * sigmoid(x); v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the result is rounded to f16 (or feeds the f32 head,

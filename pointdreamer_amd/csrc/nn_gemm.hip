@@ -572,10 +572,12 @@ bool conv_uses_halo(int N, int H, int W, int Cin, int Cout, int Cout_pad, int ta
 
 // THE routing decision of conv_igemm() -- the one copy of it (run_res predicts the route of conv2 to decide whether the
 // up-sampled x branch needs materialising; a second copy of the predicate could drift from the one that launches): 0 = halo-resident
-// kernel, 1 = k_conv_sk (plan in *plan), 2 = the implicit-GEMM kernel.
+// kernel, 1 = k_conv_sk (plan in *plan), 2 = the implicit-GEMM kernel, 3 = k_conv_ht (256 x 64 halo tiles: the 64^2 / 128^2 levels at batch 1-2).
 int conv_route(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats, bool two_source, bool in_up,
                bool apply, SkPlan* plan) {
     if (!two_source && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats)) return 0;
+    if (taps == 9 && !two_source && !in_up && !apply && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0 &&
+        conv_ht_routes(N, H, W, Cin, Cout, Cout_pad)) return 3;
     if (!in_up && !apply && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
         const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, two_source, splitk_ws_floats);
         if (pl.bm > 0) {
@@ -585,8 +587,9 @@ int conv_route(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, s
     }
     return 2;
 }
-bool conv_routes_sk(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats) {
-    return conv_route(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats, false, false, false, nullptr) == 1;
+bool conv_routes_small(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, size_t splitk_ws_floats) {   // k_conv_sk or k_conv_ht
+    const int r = conv_route(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats, false, false, false, nullptr);
+    return r == 1 || r == 3;
 }
 
 int splitk_reduce(const float* partial, int splits, long long M, int Cout, const float* bias, const half_t* residual, half_t* Y,
@@ -619,6 +622,12 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
         const size_t hfl = hws != nullptr ? splitk_ws_floats - PD_SK_TICKET_FLOATS : 0;
         return conv3x3_halo(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, gn_fused, hws, hfl, apply_table,
                             res_up, in_up);
+    }
+    if (route == 3) {
+        int chunks = 0;
+        const int rc = conv_ht(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, &chunks, res_up);
+        if (gn_fused) *gn_fused = chunks;
+        return rc;
     }
     // small-M layers (output tiles do not fill the chip): small tiles, deep staging, split-K combined inside the launch
     if (route == 1) {

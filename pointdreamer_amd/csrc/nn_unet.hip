@@ -313,7 +313,7 @@ int run_res(Ctx& c, const Act& x, ResB& rb, Act* out) {
                          ((Wo <= 256 && (Wo != 256 || Ho % 4 == 0) &&      // nearest x2: index arithmetic in conv2's
                            conv_uses_halo(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats) &&   // residual read
                            conv3x3_halo_splits(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, c.u->splitk_floats) == 1) ||
-                          (g_fuse_gn == 0 && conv_routes_sk(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats)) ||   // (round 4: k_conv_sk's epilogue too)
+                          (g_fuse_gn == 0 && conv_routes_small(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, rb.c2.cout_pad, 9, c.u->splitk_floats)) ||   // (round 4 / 6: k_conv_sk's and k_conv_ht's epilogues too)
                           (g_fuse_gn == 0 && rb.c2.wf != nullptr && conv_rr_plan(c.N, Ho, Wo, rb.c2.cin, rb.c2.cout, 9, 0, c.u->splitk_floats).variant != 0));   // (round 6: k_conv_rr's)
     if (rb.mode != 0) {
         xr.H = Ho; xr.W = Wo;

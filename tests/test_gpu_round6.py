@@ -343,3 +343,83 @@ def test_unet_full_with_in_staging_groupnorm(nn, full_model, width):
     else:
         rl, r2 = _rel(fused, base)
         assert rl <= 4e-3 and r2 <= 2.5e-3, (rl, r2)
+
+
+@pytest.mark.parametrize("N,HW,Cin,Cout,res", [(1, 128, 256, 256, 0), (1, 64, 512, 512, 1), (2, 64, 256, 512, 0), (1, 128, 64, 128, 2), (1, 64, 96, 72, 1),
+                                              (3, 32, 128, 64, 2), (1, 64, 32, 64, 0), (2, 128, 32, 8, 1)])
+def test_conv_ht_vs_torch_fp32(nn, N, HW, Cin, Cout, res):
+    """k_conv_ht (nn_conv_ht.hip: 256-pixel x 64-channel halo tiles, K unsplit, loader waves + multiplier waves, LDS-DMA double buffering)
+    against F.conv2d in fp32 on the same f16 operands (+ residual, same size or read at half resolution), repeated launches bit-identical,
+    GroupNorm octet partials = sums over its own output.  Cout = 72 / 8: a partial channel tile (Cout_pad 128); Cin = 32 / 96: one chunk and an
+    odd number of chunks (the K loop is unrolled by two)."""
+    L = nn['L']
+    H = W = HW
+    g = torch.Generator().manual_seed(HW + Cin + 3 * Cout + res)
+    x = torch.randn((N, H, W, Cin), generator=g).half()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / math.sqrt(9 * Cin)).half().float()
+    b = (0.1 * torch.randn((Cout,), generator=g)).half().float()
+    r = None
+    if res == 1:
+        r = torch.randn((N, H, W, Cout), generator=g).half()
+    elif res == 2:
+        r = torch.randn((N, H // 2, W // 2, Cout), generator=g).half()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=1)
+    if r is not None:
+        rr = r.float().permute(0, 3, 1, 2)
+        ref = ref + (F.interpolate(rr, scale_factor=2, mode='nearest') if res == 2 else rr)
+    ref = ref.permute(0, 2, 3, 1)
+    pad = (Cout + 127) // 128 * 128
+    wp = torch.zeros((pad, 9 * Cin), dtype=torch.float16, device=DEV)
+    wd = w.contiguous().to(DEV)
+    assert L.pdhip_pack_conv_weight_f16(_ptr(wd), Cout, Cin, 9, _ptr(wp), _stream()) == 0
+    zp = torch.zeros((128,), dtype=torch.float16, device=DEV)
+    xd, bd = x.to(DEV), b.to(DEV)
+    rd = r.to(DEV) if r is not None else None
+    outs = []
+    for _ in range(2):
+        y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.float16, device=DEV)
+        part = torch.full((N * (H * W // 256) * (Cout // 8) * 2,), float('nan'), dtype=torch.float32, device=DEV)
+        ch = C.c_int(-1)
+        rc = L.pdhip_conv_ht_f16(_ptr(xd), _ptr(wp), _ptr(bd), _ptr(rd), 1 if res == 2 else 0, _ptr(y), N, H, W, Cin, Cout, pad, _ptr(zp), _ptr(part),
+                                 C.byref(ch), _stream())
+        assert rc == 0, L.pdhip_last_error()
+        torch.cuda.synchronize()
+        outs.append((y, part))
+    y, part = outs[0]
+    assert torch.equal(y, outs[1][0]) and torch.equal(part, outs[1][1])
+    scale = ref.abs().max().item()
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * scale + 1e-3, (err, scale)
+    assert ch.value == H * W // 256
+    yv = y.float().reshape(N, ch.value, 256, Cout // 8, 8)
+    want = torch.stack([yv.sum(dim=(2, 4)), (yv * yv).sum(dim=(2, 4))], dim=-1)
+    assert torch.allclose(part.reshape(N, ch.value, Cout // 8, 2), want, rtol=2e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("N", [1, 2])
+def test_unet_full_with_and_without_the_halo_tile_route(nn, full_model, N):
+    """The full UNet at batch 1 / 2 with k_conv_ht on its automatic layers (128^2 level, 64^2 level by batch), on every eligible layer, and off:
+    each against the reference's fp32 forward (U1 bound), against each other in the two-roundings tolerance class, every forward deterministic,
+    and the automatic route actually differs from the route without it."""
+    L = nn['L']
+    g = load_golden('unet_full.npz')
+    st = int(g['stride'])
+    x = torch.from_numpy(g['x']).to(DEV).repeat(N, 1, 1, 1).contiguous()
+    t = torch.from_numpy(g['t']).to(DEV).repeat(N).contiguous()
+    outs = {}
+    for mode in (1, 2, 0):
+        old = L.pdhip_debug_set_conv_ht(mode)
+        try:
+            outs[mode] = full_model(x, t).cpu()
+            again = full_model(x, t).cpu()
+        finally:
+            L.pdhip_debug_set_conv_ht(old)
+        assert torch.equal(outs[mode], again), mode
+        for b in range(N):
+            linf, l2 = _rel(outs[mode][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))
+            note_measured(test='unet_full_fp32_ht', batch=N, mode=mode, linf=linf, l2=l2)
+            assert linf <= U1_FP32_LINF and l2 <= U1_FP32_L2, (N, mode, b, linf, l2)
+    for mode in (1, 2):
+        linf, l2 = _rel(outs[mode], outs[0])
+        assert linf <= 4e-3 and l2 <= 2.5e-3, (N, mode, linf, l2)
+    assert not torch.equal(outs[1], outs[0]), "the automatic route must actually take k_conv_ht at batch 1-2"

@@ -50,7 +50,14 @@ def test_shapes_uniform_and_stack_host_logic():
                     xatlas=dict(gb_pos=torch.rand((1, a, a, 3), generator=g), mask=torch.rand((1, a, a, 1), generator=g) > 0.5,
                                 per_atlas_pixel_face_id=torch.randint(-1, f, (1, a, a), generator=g)))
     a, b, c = mk(50, seed=1), mk(50, seed=2), mk(51, seed=3)
-    assert shp.uniform([a, b]) and not shp.uniform([a, c]) and not shp.uniform([a, mk(50, f=8)]) and not shp.uniform([a, mk(50, a=32)])
+    assert shp.uniform([a, b]) and not shp.uniform([a, c]) and not shp.uniform([a, mk(50, a=32)])
+    # (round 6) meshes of different size stack too: vertices / faces are padded (vertex 0, degenerate faces), `ragged` says so
+    g8 = mk(50, vn=12, f=8, seed=7)
+    assert shp.uniform([a, g8]) and shp.ragged([a, g8]) and not shp.ragged([a, b])
+    sr = shp.stack([a, g8])
+    assert sr['vertices'].shape == (2, 12, 3) and sr['faces'].shape == (2, 8, 3) and sr['f_normals'].shape == (2, 8, 3)
+    assert torch.equal(sr['vertices'][0, 10:], a['vertices'][:1].expand(2, 3)) and torch.equal(sr['faces'][0, 7], torch.zeros(3, dtype=torch.int32))
+    assert torch.equal(sr['faces'][1], g8['faces'].int()) and torch.equal(sr['f_normals'][0, 7], torch.zeros(3))
     #  equal shapes are not enough: one device throughout, atlas maps with their leading singleton dimension
     d = mk(50, seed=4); d['colors'] = d['colors'].to('meta')
     e = mk(50, seed=5); e['xatlas'] = dict(e['xatlas'], mask=e['xatlas']['mask'][0])

@@ -1,4 +1,10 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
-timeout 600 python -m pytest tests/test_gpu_round6.py -x -q -k "conv_rr" 2>&1 | tail -2
-timeout 900 python tools/bench_rr.py --taps 1 --gn-mode 1 --shape 8 1024 3072 0 --shape 8 1024 1024 0 --shape 16 1024 3072 0 --shape 16 1024 1024 0 --shape 32 512 1536 0 --shape 32 512 512 0 --variants 0 --slabs 0 1 2 > gpurun_out/r06/bench_rr_1x1.txt 2>&1; cat gpurun_out/r06/bench_rr_1x1.txt
-timeout 900 python tools/bench_rr.py --taps 1 --no-gn --no-old --shape 8 1024 3072 0 --shape 8 1024 1024 0 --shape 16 1024 3072 0 --shape 16 1024 1024 0 --shape 32 512 1536 0 --shape 32 512 512 0 --variants 0 --slabs 0 1 2 > gpurun_out/r06/bench_rr_1x1_nogn.txt 2>&1; cat gpurun_out/r06/bench_rr_1x1_nogn.txt
+timeout 900 python -m pytest tests/test_gpu_round6.py -x -q -k "conv_ht or halo_tile" 2>&1 | tail -3
+O=gpurun_out/r06/ht_ab.txt; : > $O
+for rep in 1 2; do for ht in 0 1; do
+  timeout 600 python tools/time_unet.py --batches 1 2 4 --iters 20 --ht $ht --out gpurun_out/r06/unet_ht$ht.json > /dev/null 2>&1
+  echo "ht=$ht rep=$rep $(python -c "
+import json; r=json.load(open('gpurun_out/r06/unet_ht$ht.json')); print([(x['batch'], x['forward_ms'], x.get('ddnm_step_ms')) for x in (r['rows'] if isinstance(r, dict) else r)])")" >> $O
+done; done
+cat $O
+timeout 900 python tools/bench_ht.py --batches 1 2 4 > gpurun_out/r06/bench_ht_v7b.txt 2>&1; grep -v amdgpu.ids gpurun_out/r06/bench_ht_v7b.txt
