@@ -382,12 +382,14 @@ int pdhip_conv_rr_pack_f16(const void* w_packed, int Cin, int taps, int Cs, int 
 int pdhip_gn_octet_partials_f16(const void* x, int N, int HW, int C, int chunks, float* part, void* stream);
 int pdhip_gn_apply_parts_f16(const void* x, const void* x2, int Ca, int C, const float* partA, int chunksA, const float* partB, int chunksB, const float* gamma,
                              const float* beta, const float* film, long long film_stride, int N, int H, int W, int silu, void* y, void* stream);
-/* 3x3 conv of the UNet's 64^2 / 128^2 levels at small batch on 256-pixel x 64-channel halo tiles, K unsplit (csrc/nn_conv_ht.hip; nn.Conv2d(k=3, padding=1) of
+/* 3x3 conv of the UNet's 64^2 / 128^2 levels at small batch on 256-pixel x 64-channel halo tiles (csrc/nn_conv_ht.hip; nn.Conv2d(k=3, padding=1) of
  * ResBlock.in_layers / out_layers, guided_diffusion/unet.py:185-260): x [N,H,W,Cin] f16, w_packed [Cout_pad][9 * Cin] from pdhip_pack_conv_weight_f16 (Cout_pad % 64 == 0),
- * H == W in {32, 64, 128}; residual optional (res_up: read at half resolution); gn_part (may be NULL): GroupNorm octet partials of y, *gn_chunks = H * W / 256 per image. */
+ * H == W in {32, 64, 128}; residual optional (res_up: read at half resolution); splitk_ws (may be NULL: K unsplit): >= 4096 + tiles * slabs * 16384 floats, the first 4096
+ * zeroed once (self-resetting ticket counters) -- K is cut in 2 / 4 slabs combined inside the launch when the tiles leave half of the CUs idle; gn_part (may be NULL):
+ * GroupNorm octet partials of y, *gn_chunks = H * W / 256 per image. */
 int pdhip_conv_ht_f16(const void* x, const void* w_packed, const float* bias, const void* residual, int res_up, void* y, int N, int H, int W, int Cin, int Cout,
-                      int Cout_pad, const void* zero_page, float* gn_part, int* gn_chunks, void* stream);
-int pdhip_debug_set_conv_ht(int mode);   /* 256 x 64 halo-tile conv: 0 never / 1 automatic (batch 1-2 of the 64^2, 128^2 levels) / 2 every eligible layer; returns the previous mode */
+                      int Cout_pad, const void* zero_page, float* splitk_ws, long long splitk_ws_floats, float* gn_part, int* gn_chunks, void* stream);
+int pdhip_debug_set_conv_ht(int mode, int slabs);   /* 256 x 64 halo-tile conv: mode 0 never / 1 automatic (batch 1-4 of the 64^2, 128^2 levels) / 2 every eligible layer; slabs 0 automatic, 1 / 2 / 4 forced K-slabs; returns the previous mode */
 int pdhip_debug_set_rr_gn(int max_width);   /* UNet engine: largest image width at which a conv routed to the row-resident kernel also applies the GroupNorm (+ FiLM) + SiLU in front of it (default 0 = never: no gain measured inside the forward; 8 / 16 / 32 = up to that width); returns the previous value */
 int pdhip_debug_set_conv_rr(int mode, int variant, int slabs);   /* row-resident conv: mode 0 never / 1 automatic / 2 every eligible layer; variant 0 auto (1: 8^2, 2: 16^2 whole image, 3: 32^2 bands, 4: 16^2 half image, 5: 8^2 with 128-channel units); slabs 0 auto = K slices of the conv source; returns the previous mode */
 int pdhip_attention_f16(const void* qkv /*[N,T,3C]*/, void* out /*[N,T,C]*/, int N, int T, int C, int head_dim,

@@ -79,9 +79,10 @@ extern thread_local int g_rr_mode, g_rr_variant, g_rr_slabs;            // tunin
 #define PD_RR_MAX_PART_LOADS 8    // octet-partial loads per thread of the in-kernel statistics: chunks / slots of a source must not exceed it
 
 // ---- 3x3 conv on 256-pixel x 64-channel halo tiles, K unsplit (nn_conv_ht.hip): the 64^2 / 128^2 levels at batch 1-2
-bool conv_ht_routes(int N, int H, int W, int Cin, int Cout, int Cout_pad);
+bool conv_ht_routes(int N, int H, int W, int Cin, int Cout, int Cout_pad, size_t ws_floats);
+int conv_ht_slabs(int N, int H, int W, int Cin, int Cout_pad, size_t ws_floats);
 int conv_ht(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W, int Cin, int Cout,
-            int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_chunks, int res_up);
+            int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_chunks, int res_up, float* ws, size_t ws_floats);
 extern thread_local int g_ht_mode;
 
 // ---- the GroupNorm (+ FiLM) (+ SiLU) element map (nn_norm.hip's k_gn_apply and nn_conv_rr.hip's staging: ONE definition, bit-identical results)

@@ -63,7 +63,7 @@ template <int WLOG>
 __global__ __launch_bounds__(512) void k_conv_ht(const half_t* __restrict__ X, const half_t* __restrict__ Wt, const float* __restrict__ bias,
                                                  const half_t* __restrict__ residual, half_t* __restrict__ Y, int N, int H, int Cin, int Cout,
                                                  int n_tiles, int total_tiles, const half_t* __restrict__ zero_page, float* __restrict__ gn_part,
-                                                 int res_up) {
+                                                 int res_up, int S, float* __restrict__ slabs, unsigned* __restrict__ tickets) {
     constexpr int W = 1 << WLOG, BM = 256, BN = 64;
     constexpr int RT = BM / W, HW2 = (W + 2 + 7) & ~7, HP = (RT + 2) * HW2;   // tile rows, halo row length in LDS (W + 2 pixels used; a multiple of 8
                                                                       //   keeps the swizzle of a pixel the same one row below), halo pixels
@@ -77,15 +77,16 @@ __global__ __launch_bounds__(512) void k_conv_ht(const half_t* __restrict__ X, c
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kg = lane >> 4;
-    int tile;
+    int tile, slab;                                                   // S K-slabs per tile (S = 1: K unsplit); the slabs of a tile are neighbours in one XCD
     {
-        const int b = blockIdx.x, q = total_tiles >> 3, r = total_tiles & 7, xcd = b & 7, i = b >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        const int units = total_tiles * S, b = blockIdx.x, q = units >> 3, r = units & 7, xcd = b & 7, i = b >> 3;
+        const int unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        tile = unit / S; slab = unit - tile * S;
     }
     const int pt = tile / n_tiles, n0 = (tile - pt * n_tiles) * BN;   // pixel tile, output-channel tile (the n-tiles of a pixel tile share its halo in one L2)
     const int tpi = (H << WLOG) / BM;                                 // pixel tiles per image (= GroupNorm chunks)
     const int img = pt / tpi, tin = pt - img * tpi, ty0 = tin * RT;
-    const int K = 9 * Cin, NCT = Cin >> 5;
+    const int K = 9 * Cin, NCT = (Cin >> 5) / S, cb = slab * NCT;     // chunks of this slab, first chunk
     float4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(512) void k_conv_ht(const half_t* __restrict__ X, c
             for (int k = 0; k < PW; ++k) {
                 const int q = min(k * 4 + lw, NP - 1);                // (wave-uniform)
                 const void* src;
-                if (q < NPA) src = poff[k] == ~0u ? (const void*)(zero_page + ((cq * 8) & 63)) : (const void*)(Xb + poff[k] + (uint32_t)chunk * 64u);
-                else src = (const void*)(Wb + poff[k] + (uint32_t)chunk * 64u);
+                if (q < NPA) src = poff[k] == ~0u ? (const void*)(zero_page + ((cq * 8) & 63)) : (const void*)(Xb + poff[k] + (uint32_t)(cb + chunk) * 64u);
+                else src = (const void*)(Wb + poff[k] + (uint32_t)(cb + chunk) * 64u);
 #if defined(PD_LAB_HT_FILL) && PD_LAB_HT_FILL == 2          // (lab builds, WRONG results: every piece reads the same 1 KiB -- DMA issue + LDS write alone)
                 src = (const void*)(Xb + lane * 16);
 #elif defined(PD_LAB_HT_FILL) && PD_LAB_HT_FILL == 3        // (every piece reads its own CONTIGUOUS 1 KiB: whole 128-byte lines)
@@ -223,6 +224,42 @@ __global__ __launch_bounds__(512) void k_conv_ht(const half_t* __restrict__ X, c
     }
     __syncthreads();                                                  // every fragment read is done: the buffers become the output staging
 
+    // ---- in-launch split-K combine (k_conv_sk's / k_conv_rr's protocol): every slab publishes its f32 accumulators write-through, drains, takes
+    // a ticket; the last arriver sums ALL slices in slab order -- its own included, so the order never depends on who is last -- and goes on
+    if (S > 1) {
+        constexpr int SLICE_BYTES = 16 * 4096;                        // 16 fragments x 256 lanes x 16 bytes
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(slabs + (size_t)tile * S * (SLICE_BYTES / 4), 0, S * SLICE_BYTES, 0x00020000);
+        typedef uint32_t ht_u4 __attribute__((ext_vector_type(4)));
+        if (wave < 4) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ht_u4, acc[f >> 2][f & 3]), rs, slab * SLICE_BYTES + (f * 256 + tid) * 16, 0, /*sc1: write-through*/ 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        volatile int* flag = reinterpret_cast<volatile int*>(smem + 2 * BUF_BYTES);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(S - 1);
+            if (last) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        if (wave < 4) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[f >> 2][f & 3] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < S; ++sp) {
+                float4_t v[16];
+#pragma unroll
+                for (int f = 0; f < 16; ++f)
+                    v[f] = __builtin_bit_cast(float4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, sp * SLICE_BYTES + (f * 256 + tid) * 16, 0, /*sc1*/ 16));
+#pragma unroll
+                for (int f = 0; f < 16; ++f) { acc[f >> 2][f & 3][0] += v[f][0]; acc[f >> 2][f & 3][1] += v[f][1]; acc[f >> 2][f & 3][2] += v[f][2]; acc[f >> 2][f & 3][3] += v[f][3]; }
+            }
+        }
+    }
+
     // ---- epilogue: acc + bias -> f16 -> LDS [pixel][CS_LD] -> 16-byte rows (+ residual) + GroupNorm octet partials of the tile.
     // Lane holds pixel 64 w + 16 i + r16, channels 16 j + 4 kg + 0..3
     half_t* Cs = reinterpret_cast<half_t*>(smem);
@@ -295,13 +332,14 @@ __global__ __launch_bounds__(512) void k_conv_ht(const half_t* __restrict__ X, c
 
 template <int WLOG>
 int launch_ht(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int Cin, int Cout, int Cout_pad,
-              const half_t* zero_page, float* gn_part, int res_up, hipStream_t s) {
+              const half_t* zero_page, float* gn_part, int res_up, int S, float* ws, hipStream_t s) {
     constexpr int W = 1 << WLOG, RT = 256 / W, HP = (RT + 2) * ((W + 2 + 7) & ~7), NP = (HP + 15) / 16 + 36;
     constexpr int smem = 2 * NP * 1024 + 64;
     auto kern = k_conv_ht<WLOG>;
     PD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     const int n_tiles = Cout_pad / 64, total = (int)(((long long)N * H * W / 256) * n_tiles);
-    kern<<<total, 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part, res_up);
+    kern<<<total * S, 512, smem, s>>>(X, Wt, bias, residual, Y, N, H, Cin, Cout, n_tiles, total, zero_page, gn_part, res_up, S,
+                                      ws ? ws + PD_SK_TICKET_FLOATS : nullptr, reinterpret_cast<unsigned*>(ws));
     PD_LAUNCH_CHECK();
     return PDHIP_OK;
 }
@@ -309,6 +347,21 @@ int launch_ht(const half_t* X, const half_t* Wt, const float* bias, const half_t
 }  // namespace
 
 thread_local int g_ht_mode = 1;        // tuning / test hook (pdhip_debug_set_conv_ht): 0 = never, 1 = automatic, 2 = every eligible layer
+thread_local int g_ht_slabs = 0;       //   K-slabs forced (0 = automatic)
+
+// K-slabs of a layer: K is cut in two (four) when the tiles alone leave half (three quarters) of the CUs idle and every slab keeps >= 8 chunks
+// (the combine -- 64 KB published write-through per workgroup, ticket, two slices re-read -- costs ~8 us: 64^2 / batch 1 at 256 input channels
+// 19.6 us in two slabs against 17.1 unsplit, at 512 / 768 / 1 024: 26.7 / 34.3 / 41.7 against 28.7 / 44.8 / 54.7); needs the split-K workspace
+// (tickets + tiles x S x 64 KB of f32 slices)
+int conv_ht_slabs(int N, int H, int W, int Cin, int Cout_pad, size_t ws_floats) {
+    const long long tiles = ((long long)N * H * W / 256) * (Cout_pad / 64);
+    const int nct = Cin >> 5;
+    auto fits = [&](int S) { return nct % S == 0 && tiles <= 4096 && (size_t)tiles * S * 16384 + PD_SK_TICKET_FLOATS <= ws_floats; };
+    if (g_ht_slabs > 0) return fits(g_ht_slabs) ? g_ht_slabs : 1;
+    int S = 1;
+    while (S < 4 && tiles * S * 2 <= 256 && nct / (S * 2) >= 8 && fits(S * 2)) S *= 2;
+    return S;
+}
 
 // does this layer run in k_conv_ht?  Eligible: 3x3, H == W in {32, 64, 128}, whole 256-pixel tiles, 32-channel chunks, single-source input.
 // Automatic (profiles/r06_ht_bench.txt, against the route without it on the same box), at most two rounds of workgroups: the 128^2 level at
@@ -316,33 +369,39 @@ thread_local int g_ht_mode = 1;        // tuning / test hook (pdhip_debug_set_co
 // 48 against 45); the 64^2 level once its tiles fill the chip (batch 2-4: 36 / 66 us against 45 / 84 at batch 2) and at batch 1 (half the
 // chip) up to 768 input channels (17 / 29 / 45 against 20 / 32 / 46; 1 024: 56 against 52); never at 32^2 (k_conv_rr's).  Beyond two rounds
 // the 512 x 128 halo tile owns the layer.
-bool conv_ht_routes(int N, int H, int W, int Cin, int Cout, int Cout_pad) {
+bool conv_ht_routes(int N, int H, int W, int Cin, int Cout, int Cout_pad, size_t ws_floats) {
     if (g_ht_mode == 0 || H != W || (W != 32 && W != 64 && W != 128) || ((long long)H * W) % 256 != 0 || Cin % 32 != 0 || Cout % 8 != 0 ||
         Cout_pad % 64 != 0 || (long long)N * H * W * Cin * 2 > 0x7ffffff0LL || (long long)Cout_pad * 9 * Cin * 2 > 0x7ffffff0LL) return false;
     if (g_ht_mode == 2) return true;
     const long long tiles = ((long long)N * H * W / 256) * (Cout_pad / 64);
     if (tiles > 512) return false;
-    return W == 128 ? (N == 1 || Cin >= 512) : (W == 64 && (tiles >= 256 || Cin <= 768));
+    return W == 128 ? (N == 1 || Cin >= 512) : (W == 64 && (tiles >= 256 || Cin <= 768 || conv_ht_slabs(N, H, W, Cin, Cout_pad, ws_floats) > 1));
 }
 
 int conv_ht(const half_t* X, const half_t* Wt, const float* bias, const half_t* residual, half_t* Y, int N, int H, int W, int Cin, int Cout,
-            int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_chunks, int res_up) {
+            int Cout_pad, const half_t* zero_page, hipStream_t s, float* gn_part, int* gn_chunks, int res_up, float* ws, size_t ws_floats) {
     PD_REQUIRE(X && Wt && Y && zero_page, "conv_ht: null argument");
     PD_REQUIRE(H == W && (W == 32 || W == 64 || W == 128) && Cin % 32 == 0 && Cout % 8 == 0 && Cout_pad % 64 == 0 && Cout_pad >= Cout,
                "conv_ht: unsupported geometry (H=%d W=%d Cin=%d Cout=%d)", H, W, Cin, Cout);
     PD_REQUIRE(res_up == 0 || (residual != nullptr && H % 2 == 0), "conv_ht: an up-sampled residual needs even H, W");
     PD_REQUIRE((long long)N * H * W * Cin * 2 <= 0x7ffffff0LL && (long long)Cout_pad * 9 * Cin * 2 <= 0x7ffffff0LL, "conv_ht: operand beyond the 2 GB buffer range");
     if (gn_chunks) *gn_chunks = gn_part ? H * W / 256 : 0;
-    if (W == 128) return launch_ht<7>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, gn_part, res_up, s);
-    if (W == 64) return launch_ht<6>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, gn_part, res_up, s);
-    return launch_ht<5>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, gn_part, res_up, s);
+    const int S = conv_ht_slabs(N, H, W, Cin, Cout_pad, ws ? ws_floats : 0);
+    if (W == 128) return launch_ht<7>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, gn_part, res_up, S, ws, s);
+    if (W == 64) return launch_ht<6>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, gn_part, res_up, S, ws, s);
+    return launch_ht<5>(X, Wt, bias, residual, Y, N, H, Cin, Cout, Cout_pad, zero_page, gn_part, res_up, S, ws, s);
 }
 
 }  // namespace pdnn
 
 extern "C" int pdhip_conv_ht_f16(const void* x, const void* w_packed, const float* bias, const void* residual, int res_up, void* y, int N, int H, int W, int Cin,
-                                 int Cout, int Cout_pad, const void* zero_page, float* gn_part, int* gn_chunks, void* stream) {
+                                 int Cout, int Cout_pad, const void* zero_page, float* splitk_ws, long long splitk_ws_floats, float* gn_part, int* gn_chunks,
+                                 void* stream) {
     return pdnn::conv_ht((const pdnn::half_t*)x, (const pdnn::half_t*)w_packed, bias, (const pdnn::half_t*)residual, (pdnn::half_t*)y, N, H, W, Cin, Cout, Cout_pad,
-                         (const pdnn::half_t*)zero_page, as_stream(stream), gn_part, gn_chunks, res_up);
+                         (const pdnn::half_t*)zero_page, as_stream(stream), gn_part, gn_chunks, res_up, splitk_ws, splitk_ws ? (size_t)splitk_ws_floats : 0);
 }
-extern "C" int pdhip_debug_set_conv_ht(int mode) { const int old = pdnn::g_ht_mode; pdnn::g_ht_mode = mode; return old; }
+extern "C" int pdhip_debug_set_conv_ht(int mode, int slabs) {
+    const int old = pdnn::g_ht_mode;
+    pdnn::g_ht_mode = mode; pdnn::g_ht_slabs = slabs;
+    return old;
+}

@@ -633,11 +633,11 @@ RrPlan conv_rr_plan(int N, int H, int W, int Cin, int Cout, int taps, int Cs, si
     const long long tiles = (long long)N * bands * ntiles;
     if (tiles > 4096) return p;
     // automatic routing: the launches a same-box A/B of the DDNM step favours (profiles/r06_rr_ab.txt): batch 1-2 at 8^2 ... 32^2 (batch 4 at
-    // 8^2 only: from batch 4 up k_conv_sk's larger tiles win back what the slabs cost), batch 1 at 64^2 for the 512+-channel layers without an
-    // appended skip (256 -> 512 there: 20 us against 16)
+    // 8^2 only: from batch 4 up k_conv_sk's larger tiles win back what the slabs cost).  The 64^2 level at batch 1 (512+-channel layers: 27-30 /
+    // 40 / 51 us at 512 / 768 / 1 024 input channels) went to k_conv_ht's two-slab form when that arrived (27 / 34 / 42 us, profiles/r06_ht_bench.txt)
     if (g_rr_mode != 2) {
         // (with an appended skip 1x1 the slabs of 1x1 units are the long pole: 16-27 us against k_conv_sk<10>'s 15-23 at every level -- not routed)
-        const bool ok = Cs == 0 && (W <= 32 ? (N <= 2 || (N <= 4 && W == 8)) : (W == 64 && N == 1 && Cin >= 512));
+        const bool ok = Cs == 0 && W <= 32 && (N <= 2 || (N <= 4 && W == 8));
         if (!ok) return p;
     }
     // slabs: enough workgroups to put ~one on every CU, every slab a whole number of units, at most 8 conv slabs (the last arriver re-reads them all)

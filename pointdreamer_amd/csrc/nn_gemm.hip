@@ -577,7 +577,7 @@ int conv_route(int N, int H, int W, int Cin, int Cout, int Cout_pad, int taps, s
                bool apply, SkPlan* plan) {
     if (!two_source && conv_uses_halo(N, H, W, Cin, Cout, Cout_pad, taps, splitk_ws_floats)) return 0;
     if (taps == 9 && !two_source && !in_up && !apply && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0 &&
-        conv_ht_routes(N, H, W, Cin, Cout, Cout_pad)) return 3;
+        conv_ht_routes(N, H, W, Cin, Cout, Cout_pad, splitk_ws_floats)) return 3;
     if (!in_up && !apply && g_force_wmw == 0 && g_force_bk == 0 && g_force_stages == 0 && g_force_splits == 0) {
         const SkPlan pl = conv_sk_plan(N, H, W, Cin, Cout, Cout_pad, taps, two_source, splitk_ws_floats);
         if (pl.bm > 0) {
@@ -625,7 +625,7 @@ int conv_igemm(const half_t* X, const half_t* Wt, const float* bias, const half_
     }
     if (route == 3) {
         int chunks = 0;
-        const int rc = conv_ht(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, &chunks, res_up);
+        const int rc = conv_ht(X, Wt, bias, residual, Y, N, H, W, Cin, Cout, Cout_pad, zero_page, s, gn_part, &chunks, res_up, splitk_ws, splitk_ws_floats);
         if (gn_fused) *gn_fused = chunks;
         return rc;
     }

@@ -345,13 +345,15 @@ def test_unet_full_with_in_staging_groupnorm(nn, full_model, width):
         assert rl <= 4e-3 and r2 <= 2.5e-3, (rl, r2)
 
 
-@pytest.mark.parametrize("N,HW,Cin,Cout,res", [(1, 128, 256, 256, 0), (1, 64, 512, 512, 1), (2, 64, 256, 512, 0), (1, 128, 64, 128, 2), (1, 64, 96, 72, 1),
-                                              (3, 32, 128, 64, 2), (1, 64, 32, 64, 0), (2, 128, 32, 8, 1)])
-def test_conv_ht_vs_torch_fp32(nn, N, HW, Cin, Cout, res):
+@pytest.mark.parametrize("N,HW,Cin,Cout,res,slabs", [(1, 128, 256, 256, 0, 0), (1, 64, 512, 512, 1, 0), (2, 64, 256, 512, 0, 0), (1, 128, 64, 128, 2, 0), (1, 64, 96, 72, 1, 0),
+                                                    (3, 32, 128, 64, 2, 0), (1, 64, 32, 64, 0, 0), (2, 128, 32, 8, 1, 0), (1, 64, 512, 512, 1, 1), (1, 64, 256, 200, 2, 2),
+                                                    (1, 32, 256, 128, 1, 4), (2, 32, 64, 64, 0, 2)])
+def test_conv_ht_vs_torch_fp32(nn, N, HW, Cin, Cout, res, slabs):
     """k_conv_ht (nn_conv_ht.hip: 256-pixel x 64-channel halo tiles, K unsplit, loader waves + multiplier waves, LDS-DMA double buffering)
     against F.conv2d in fp32 on the same f16 operands (+ residual, same size or read at half resolution), repeated launches bit-identical,
     GroupNorm octet partials = sums over its own output.  Cout = 72 / 8: a partial channel tile (Cout_pad 128); Cin = 32 / 96: one chunk and an
-    odd number of chunks (the K loop is unrolled by two)."""
+    odd number of chunks (the K loop is unrolled by two).  slabs: K cut in 2 / 4 slabs combined inside the launch (0 = the automatic choice: two
+    slabs for 64^2 / 512 -> 512 at batch 1); the ticket counters must be back at zero afterwards."""
     L = nn['L']
     H = W = HW
     g = torch.Generator().manual_seed(HW + Cin + 3 * Cout + res)
@@ -375,16 +377,23 @@ def test_conv_ht_vs_torch_fp32(nn, N, HW, Cin, Cout, res):
     zp = torch.zeros((128,), dtype=torch.float16, device=DEV)
     xd, bd = x.to(DEV), b.to(DEV)
     rd = r.to(DEV) if r is not None else None
+    ws = torch.zeros((4096 + 4 * 1024 * 1024,), dtype=torch.float32, device=DEV)
+    ws[4096:] = float('nan')
+    old = L.pdhip_debug_set_conv_ht(2, slabs)
     outs = []
     for _ in range(2):
         y = torch.full((N, H, W, Cout), float('nan'), dtype=torch.float16, device=DEV)
         part = torch.full((N * (H * W // 256) * (Cout // 8) * 2,), float('nan'), dtype=torch.float32, device=DEV)
         ch = C.c_int(-1)
-        rc = L.pdhip_conv_ht_f16(_ptr(xd), _ptr(wp), _ptr(bd), _ptr(rd), 1 if res == 2 else 0, _ptr(y), N, H, W, Cin, Cout, pad, _ptr(zp), _ptr(part),
-                                 C.byref(ch), _stream())
+        rc = L.pdhip_conv_ht_f16(_ptr(xd), _ptr(wp), _ptr(bd), _ptr(rd), 1 if res == 2 else 0, _ptr(y), N, H, W, Cin, Cout, pad, _ptr(zp), _ptr(ws), ws.numel(),
+                                 _ptr(part), C.byref(ch), _stream())
         assert rc == 0, L.pdhip_last_error()
         torch.cuda.synchronize()
         outs.append((y, part))
+    L.pdhip_debug_set_conv_ht(old, 0)
+    assert int(ws[:4096].abs().sum().item()) == 0
+    if slabs > 1 or (slabs == 0 and (N, HW, Cin, Cout) == (1, 64, 512, 512)):
+        assert not torch.isnan(ws[4096:4096 + 16384]).any(), "the split form must have been taken"
     y, part = outs[0]
     assert torch.equal(y, outs[1][0]) and torch.equal(part, outs[1][1])
     scale = ref.abs().max().item()
@@ -408,12 +417,12 @@ def test_unet_full_with_and_without_the_halo_tile_route(nn, full_model, N):
     t = torch.from_numpy(g['t']).to(DEV).repeat(N).contiguous()
     outs = {}
     for mode in (1, 2, 0):
-        old = L.pdhip_debug_set_conv_ht(mode)
+        old = L.pdhip_debug_set_conv_ht(mode, 0)
         try:
             outs[mode] = full_model(x, t).cpu()
             again = full_model(x, t).cpu()
         finally:
-            L.pdhip_debug_set_conv_ht(old)
+            L.pdhip_debug_set_conv_ht(old, 0)
         assert torch.equal(outs[mode], again), mode
         for b in range(N):
             linf, l2 = _rel(outs[mode][b:b + 1, :, ::st, ::st], torch.from_numpy(g['ref_out']))

@@ -12,6 +12,7 @@ ap.add_argument('--iters', type=int, default=40)
 ap.add_argument('--lib', default=None)
 ap.add_argument('--shapes', type=int, nargs='*', default=None)
 ap.add_argument('--tag', default='')
+ap.add_argument('--slabs', type=int, nargs='*', default=[1, 0], help='K-slabs of k_conv_ht to time (0 = automatic)')
 a = ap.parse_args()
 if a.lib:
     _lib.LIB_PATH = os.path.abspath(a.lib); os.environ['PDHIP_ALLOW_LAB_BUILD'] = '1'
@@ -50,10 +51,14 @@ for si, (H, Cin, Cout) in enumerate(SHAPES):
         ch = C.c_int(0)
         fl = 2.0 * N * H * W * Cout * 9 * Cin
         L.pdhip_debug_set_conv_splitk(P(ws), ws.numel(), 0)
-        old = L.pdhip_debug_set_conv_ht(0)
+        old = L.pdhip_debug_set_conv_ht(0, 0)
         t_old = timeit(lambda i: L.pdhip_conv2d_nhwc_f16(P(x), P(wps[i % nb]), P(b), None, P(y), N, H, W, Cin, Cout, pad, 9, P(zp), S()), a.iters)
-        L.pdhip_debug_set_conv_ht(old)
         L.pdhip_debug_set_conv_splitk(None, 0, 0)
-        t_new = timeit(lambda i: L.pdhip_conv_ht_f16(P(x), P(wps[i % nb]), P(b), None, 0, P(y), N, H, W, Cin, Cout, pad, P(zp), P(gp), C.byref(ch), S()), a.iters)
-        print(f"{a.tag}N{N} {H}x{W} Cin{Cin} Cout{Cout} {fl / 1e9:6.1f} GFLOP   engine route without k_conv_ht {t_old:6.1f} us ({fl / t_old / 1e9:5.2f} PF/s)   k_conv_ht {t_new:6.1f} us ({fl / t_new / 1e9:5.2f} PF/s)", flush=True)
+        line = f"{a.tag}N{N} {H}x{W} Cin{Cin} Cout{Cout} {fl / 1e9:6.1f} GFLOP   engine route without k_conv_ht {t_old:6.1f} us ({fl / t_old / 1e9:5.2f} PF/s)   k_conv_ht"
+        for sl in a.slabs:
+            L.pdhip_debug_set_conv_ht(2, sl)
+            t_new = timeit(lambda i: L.pdhip_conv_ht_f16(P(x), P(wps[i % nb]), P(b), None, 0, P(y), N, H, W, Cin, Cout, pad, P(zp), P(ws), ws.numel(), P(gp), C.byref(ch), S()), a.iters)
+            line += f"  slabs {sl if sl else 'auto'}: {t_new:6.1f} us ({fl / t_new / 1e9:5.2f} PF/s)"
+        L.pdhip_debug_set_conv_ht(old, 0)
+        print(line, flush=True)
         del wps

@@ -19,6 +19,7 @@ ap.add_argument('--gn-iters', type=int, default=-1, help='pdhip_debug_set_gn_ite
 ap.add_argument('--rr', type=int, default=-1, help='pdhip_debug_set_conv_rr mode (0 off, 1 auto, 2 every eligible layer; -1 = default)')
 ap.add_argument('--rr-gn', type=int, default=-1, help='pdhip_debug_set_rr_gn (largest width with the in-staging GroupNorm; -1 = default)')
 ap.add_argument('--ht', type=int, default=-1, help='pdhip_debug_set_conv_ht mode (0 off, 1 auto, 2 every eligible layer; -1 = default)')
+ap.add_argument('--ht-slabs', type=int, default=0, help='forced K-slabs of k_conv_ht (0 = automatic)')
 ap.add_argument('--out', default='gpurun_out/unet_latency.json')
 ap.add_argument('--graph', type=int, default=0, help='1: also time the forward and the sampler replayed from a HIP graph (torch.cuda.CUDAGraph)')
 ap.add_argument('--sampler-steps', type=int, default=10, help='also time this many DDNM steps through pdhip_ddnm_sample (0 = skip)')
@@ -43,7 +44,7 @@ if a.sk >= 0:
 if a.rr >= 0:
     _lib.lib().pdhip_debug_set_conv_rr(a.rr, 0, 0)
 if a.ht >= 0:
-    _lib.lib().pdhip_debug_set_conv_ht(a.ht)
+    _lib.lib().pdhip_debug_set_conv_ht(a.ht, a.ht_slabs)
 if a.rr_gn >= 0:
     _lib.lib().pdhip_debug_set_rr_gn(a.rr_gn)
 sd = di.random_state_dict(dict(di.IMAGENET_256), seed=0)
