@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace pdhip
 
-extern "C" int pdhip_version(void) { return 206; }
+extern "C" int pdhip_version(void) { return 207; }
 // number of translation units of THIS library that were compiled with a wrong-result PD_LAB_* switch (common.h); 0 for a product build
 extern "C" int pdhip_lab_build(void) { return pdhip::g_lab_units; }
 extern "C" const char* pdhip_last_error(void) { return pdhip::g_err; }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/pdhip.h but not exported"
         assert s in _lib._SIGS, f"{s} has no ctypes signature in pointdreamer_amd/_lib.py"
-    assert L.pdhip_version() >= 206
+    assert L.pdhip_version() >= 207
     assert L.pdhip_lab_build() == 0, "libpdhip.so carries a wrong-result PD_LAB_* timing switch: rebuild it without the flag"
 
 
