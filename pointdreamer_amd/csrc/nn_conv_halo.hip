@@ -202,8 +202,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
     bp += Cin;
     if (PA == 9) {                                                    // keeps the issue order of the steady state (see HL_VMN)
         glds16h(halo_src(PA - 1, cb), ah_dst + piece_off(PA - 1, 0));
+#ifndef PD_LAB_NOPROWAIT                                    // (lab builds, WRONG results: the tile without its exposed first-chunk fill -- what a cross-tile prefetch could hide at most)
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#endif
+    } else {
+#ifndef PD_LAB_NOPROWAIT
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#endif
+    }
     if constexpr (APPLY) {
         // the image's affine table and the validity bytes -> LDS (plain loads: the compiler drains every outstanding LDS-DMA
         // first, which the transform below needs anyway); after the barrier every piece of chunk 0 is visible to every wave
