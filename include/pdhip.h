@@ -389,6 +389,7 @@ int pdhip_gn_apply_parts_f16(const void* x, const void* x2, int Ca, int C, const
  * GroupNorm octet partials of y, *gn_chunks = H * W / 256 per image. */
 int pdhip_conv_ht_f16(const void* x, const void* w_packed, const float* bias, const void* residual, int res_up, void* y, int N, int H, int W, int Cin, int Cout,
                       int Cout_pad, const void* zero_page, float* splitk_ws, long long splitk_ws_floats, float* gn_part, int* gn_chunks, void* stream);
+int pdhip_conv_ht_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, long long splitk_ws_floats, int* routed, int* slabs);   /* host-only: would the engine's automatic routing (conv_route, csrc/nn_gemm.hip) send this 3x3 layer to the halo-tile kernel, and in how many K-slabs */
 int pdhip_debug_set_conv_ht(int mode, int slabs);   /* 256 x 64 halo-tile conv: mode 0 never / 1 automatic (batch 1-4 of the 64^2, 128^2 levels) / 2 every eligible layer; slabs 0 automatic, 1 / 2 / 4 forced K-slabs; returns the previous mode */
 int pdhip_debug_set_rr_gn(int max_width);   /* UNet engine: largest image width at which a conv routed to the row-resident kernel also applies the GroupNorm (+ FiLM) + SiLU in front of it (default 0 = never: no gain measured inside the forward; 8 / 16 / 32 = up to that width); returns the previous value */
 int pdhip_debug_set_conv_rr(int mode, int variant, int slabs);   /* row-resident conv: mode 0 never / 1 automatic / 2 every eligible layer; variant 0 auto (1: 8^2, 2: 16^2 whole image, 3: 32^2 bands, 4: 16^2 half image, 5: 8^2 with 128-channel units); slabs 0 auto = K slices of the conv source; returns the previous mode */

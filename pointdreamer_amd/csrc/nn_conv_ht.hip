@@ -400,6 +400,13 @@ extern "C" int pdhip_conv_ht_f16(const void* x, const void* w_packed, const floa
     return pdnn::conv_ht((const pdnn::half_t*)x, (const pdnn::half_t*)w_packed, bias, (const pdnn::half_t*)residual, (pdnn::half_t*)y, N, H, W, Cin, Cout, Cout_pad,
                          (const pdnn::half_t*)zero_page, as_stream(stream), gn_part, gn_chunks, res_up, splitk_ws, splitk_ws ? (size_t)splitk_ws_floats : 0);
 }
+// host-only: the routing decision for a layer (no launch, no GPU needed)
+extern "C" int pdhip_conv_ht_plan(int N, int H, int W, int Cin, int Cout, int Cout_pad, long long splitk_ws_floats, int* routed, int* slabs) {
+    const size_t wf = splitk_ws_floats > 0 ? (size_t)splitk_ws_floats : 0;
+    if (routed) *routed = pdnn::conv_ht_routes(N, H, W, Cin, Cout, Cout_pad, wf) ? 1 : 0;
+    if (slabs) *slabs = pdnn::conv_ht_slabs(N, H, W, Cin, Cout_pad, wf);
+    return PDHIP_OK;
+}
 extern "C" int pdhip_debug_set_conv_ht(int mode, int slabs) {
     const int old = pdnn::g_ht_mode;
     pdnn::g_ht_mode = mode; pdnn::g_ht_slabs = slabs;

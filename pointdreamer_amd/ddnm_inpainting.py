@@ -62,6 +62,7 @@ _reg('pdhip_debug_set_attn', C.c_int, [i32, i32, i32])
 _reg('pdhip_debug_set_conv_rr', C.c_int, [i32, i32, i32])
 _reg('pdhip_debug_set_rr_gn', C.c_int, [i32])
 _reg('pdhip_debug_set_conv_ht', C.c_int, [i32, i32])
+_reg('pdhip_conv_ht_plan', C.c_int, [i32, i32, i32, i32, i32, i32, C.c_longlong, C.POINTER(C.c_int), C.POINTER(C.c_int)])
 _reg('pdhip_conv_ht_f16', C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, C.c_longlong, vp, C.POINTER(C.c_int), vp])
 _reg('pdhip_conv_rr_weight_halfs', C.c_longlong, [i32, i32, i32, i32])
 _reg('pdhip_conv_rr_pack_f16', C.c_int, [vp, i32, i32, i32, i32, vp, vp])

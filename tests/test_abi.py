@@ -96,3 +96,30 @@ def test_ddnm_schedule_matches_reference_golden_on_host():
     for k in (0, 50, 99):
         ref = [cos[k][n].item() for n in ('sqrt_1m_at', 'sqrt_at', 'sqrt_at_next', 'sigma_t', 'c1', 'c2')]
         assert np.allclose(co[k], ref, rtol=2e-7, atol=0)
+
+
+def test_halo_tile_conv_routing_table_on_host():
+    """pdhip_conv_ht_plan (host-only): the automatic routing of the 256 x 64 halo-tile conv (csrc/nn_conv_ht.hip) over the
+    UNet's 3x3 layer shapes -- 128^2 at batch 1 and at batch 2 from 512 input channels, 64^2 at batch 1-4 (two K-slabs at batch 1 from 512 input
+    channels, which needs the split-K workspace), never 32^2, never beyond two rounds of workgroups."""
+    import ctypes as C
+    import __graft_entry__ as ge
+    ge.build()
+    from pointdreamer_amd import _lib
+    import pointdreamer_amd.ddnm_inpainting  # noqa: F401
+    L = _lib.lib()
+    WS = 16 * 384 * 128 * 128                                # the engine's split-K workspace (nn_unet.hip)
+
+    def plan(N, HW, Cin, Cout, ws=WS):
+        r, s = C.c_int(-1), C.c_int(-1)
+        assert L.pdhip_conv_ht_plan(N, HW, HW, Cin, Cout, (Cout + 127) // 128 * 128, ws, C.byref(r), C.byref(s)) == 0
+        return r.value, s.value
+
+    assert plan(1, 128, 256, 256) == (1, 1) and plan(1, 128, 768, 256) == (1, 1) and plan(1, 128, 512, 512) == (1, 1)
+    assert plan(2, 128, 256, 256)[0] == 0 and plan(2, 128, 512, 256) == (1, 1) and plan(2, 128, 512, 512)[0] == 0     # (1 024 tiles: the 512 x 128 tile's)
+    assert plan(4, 128, 512, 256)[0] == 0
+    assert plan(1, 64, 512, 512) == (1, 2) and plan(1, 64, 1024, 512) == (1, 2) and plan(1, 64, 768, 512) == (1, 2)      # (768 / 32 = 24 chunks: 12 per slab >= 8 -> two slabs)
+    assert plan(1, 64, 256, 512) == (1, 1)                   # 4 chunks per slab would not pay for the combine
+    assert plan(2, 64, 1024, 512) == (1, 1) and plan(4, 64, 512, 512) == (1, 1) and plan(8, 64, 512, 512)[0] == 0
+    assert plan(1, 64, 1024, 512, ws=0) == (0, 1)            # no workspace: unsplit, and at half the chip the 1 024-channel layer is k_conv_sk's
+    assert plan(1, 32, 512, 512)[0] == 0 and plan(1, 256, 256, 256)[0] == 0 and plan(1, 64, 48, 512)[0] == 0             # 32^2 / 256^2 / Cin % 32
