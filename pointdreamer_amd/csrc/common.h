@@ -47,7 +47,7 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
     defined(PD_LAB_NODMA) || defined(PD_LAB_NOEPI) || defined(PD_LAB_NOLDS) || defined(PD_LAB_NOSTORE) || defined(PD_LAB_NOWAIT) ||             \
     defined(PD_LAB_AP_NOCOMPUTE) || defined(PD_LAB_AP_NOFETCH) || defined(PD_LAB_AP_NOSTORE) || defined(PD_LAB_AP_NOTRANS) ||                   \
     defined(PD_LAB_AP_LOOSEVM) || defined(PD_LAB_RASTER_LOADONLY) || defined(PD_LAB_RASTER_NORESOLVE) || defined(PD_LAB_RR_NOW) ||             \
-    defined(PD_LAB_RR_NOA) || defined(PD_LAB_RR_NOMFMA) || defined(PD_LAB_HT_FILL) || defined(PD_LAB_NOPROWAIT)
+    defined(PD_LAB_RR_NOA) || defined(PD_LAB_RR_NOMFMA) || defined(PD_LAB_HT_FILL) || defined(PD_LAB_NOPROWAIT) || defined(PD_LAB_HALO_NOSTORE)
 #define PD_LAB_WRONG_RESULTS 1
 #endif
 extern int g_lab_units;                                    // translation units built with a wrong-result lab switch (capi.hip)

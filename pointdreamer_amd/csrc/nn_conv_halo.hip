@@ -431,13 +431,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(const half_t* __restrict__
                 for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)rv[e]);
             }
             if (col_ok) {
+#ifndef PD_LAB_HALO_NOSTORE                                // (lab builds only, WRONG results: the epilogue without its global stores)
                 *reinterpret_cast<half8*>(Y + o) = v;
+#endif
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; gs += f; gq += f * f; }
             }
         }
     };
     if (residual != nullptr) epilogue(std::true_type{}); else epilogue(std::false_type{});
+#ifdef PD_LAB_HALO_NOSTORE
+    if (gs == 123.456f && gq == 7.f) Y[0] = (half_t)1.f;   // (keeps the staging reads alive)
+#endif
     if (gn_part != nullptr) {                              // [img][chunk][Cout/8][2], chunk = 512-pixel tile of the image
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
